@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own numpy code.
+
+Runs only in the build container (needs /root/reference).  It imports
+
+  * ``nets/np_methods.py``  (numpy only)                      -> G2, G3, G4
+  * ``nets/ron_vgg_320.py`` under a stubbed ``tensorflow``     -> G1 (anchor grids)
+
+and stores inputs (or the seed that regenerates them) together with the outputs the
+reference produced.  Nothing of the reference's source text is stored: the .npz
+files hold arrays only.  Usage:  python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+
+from oracle import np_post, synth  # noqa: E402  (only for softmax/gate, which are TF ops in the reference)
+
+
+def load_np_methods():
+    spec = importlib.util.spec_from_file_location('ref_np_methods', os.path.join(REF, 'nets', 'np_methods.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_ref_ron():
+    """Import nets/ron_vgg_320.py with tensorflow replaced by MagicMocks (anchor code is numpy)."""
+    import importlib.abc
+    import importlib.machinery
+
+    class _Stub(mock.MagicMock):
+        __path__ = []          # looks like a package, so sub-imports are attempted
+        add_arg_scope = staticmethod(lambda f: f)   # decorators must stay pass-through
+
+    class _TFFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, fullname, path, target=None):
+            if fullname == 'tensorflow' or fullname.startswith('tensorflow.'):
+                return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+            return None
+
+        def create_module(self, spec):
+            return _Stub(name=spec.name)
+
+        def exec_module(self, module):
+            pass
+
+    sys.meta_path.insert(0, _TFFinder())
+    sys.path.insert(0, REF)
+    from nets import ron_vgg_320  # noqa
+    return ron_vgg_320
+
+
+def g1_anchors(ron):
+    net = ron.RONNet()
+    layers = net.anchors((320, 320))
+    out = {}
+    for i, (y, x, h, w) in enumerate(layers):
+        out['y%d' % i], out['x%d' % i], out['h%d' % i], out['w%d' % i] = y, x, h, w
+    np.savez_compressed(os.path.join(HERE, 'g1_anchors_ron320.npz'), **out)
+    return layers
+
+
+def g2_decode(npm, anchors):
+    out = {'seed': np.int64(11)}
+    rs = np.random.RandomState(11)
+    for i, a in enumerate(anchors):
+        hh, ww = a[0].shape[:2]
+        loc = rs.randn(1, hh, ww, 10, 4).astype(np.float32)
+        out['loc%d' % i] = loc
+        out['dec%d' % i] = npm.ssd_bboxes_decode(loc, a)
+    np.savez_compressed(os.path.join(HERE, 'g2_decode.npz'), **out)
+
+
+def run_reference_pipeline(npm, predictions, localisations, anchors, select_threshold, top_k, nms_threshold,
+                           bbox_img=(0., 0., 1., 1.)):
+    """notebooks/ssd_notebook.ipynb cell 8, batch 1."""
+    rbbox_img = np.asarray(bbox_img, dtype=np.float32)
+    c, s, b = npm.ssd_bboxes_select(predictions, localisations, anchors, select_threshold=select_threshold,
+                                    img_shape=(320, 320), num_classes=21, decode=True)
+    n_cand = c.shape[0]
+    sel = (c.copy(), s.copy(), b.copy())
+    b = npm.bboxes_clip(rbbox_img, b)
+    c, s, b = npm.bboxes_sort(c, s, b, top_k=top_k)
+    srt = (c.copy(), s.copy(), b.copy())
+    c, s, b = npm.bboxes_nms(c, s, b, nms_threshold=nms_threshold)
+    b = npm.bboxes_resize(rbbox_img, b)
+    return dict(sel=sel, srt=srt, out=(c, s, b), n_cand=n_cand)
+
+
+G3_CASES = [
+    # name, seed, bg, ob, cls_scale, select_thr, nms_thr
+    ('real_s0', 0, 8.0, -4.0, 1.0, 0.01, 0.45),
+    ('real_s1', 1, 8.0, -4.0, 1.0, 0.01, 0.45),
+    ('real_s2', 2, 8.0, -4.0, 1.0, 0.01, 0.40),
+    ('real_s3', 3, 8.0, -3.0, 1.0, 0.01, 0.45),
+    ('mid_s4', 4, 7.0, -3.0, 1.0, 0.01, 0.45),
+    ('dense_s5', 5, 4.0, -2.0, 1.0, 0.01, 0.45),
+    ('thr50_s6', 6, 8.0, -2.0, 3.0, 0.5, 0.45),
+    ('thr50_s7', 7, 6.0, -1.0, 3.0, 0.5, 0.40),
+    ('empty_s8', 8, 30.0, -30.0, 1.0, 0.01, 0.45),
+]
+
+
+def g3_pipeline(npm, anchors):
+    out = {}
+    names = []
+    for name, seed, bg, ob, scale, thr, nms in G3_CASES:
+        cls, obj, loc = synth.head_tensors(seed, batch=1, bg=bg, ob=ob, cls_scale=scale)
+        pred = [np_post.softmax_last(x) for x in cls]
+        objp = [np_post.objectness_from_logits(x) for x in obj]
+        gated = np_post.objectness_gate(pred, objp, 0.03)
+        r = run_reference_pipeline(npm, gated, loc, anchors, thr, 400, nms)
+        sc_sorted = r['srt'][1]
+        # the reference's argsort is unstable: only tie-free cases are pinned row by row
+        assert len(np.unique(r['sel'][1])) == len(r['sel'][1]) or len(np.unique(sc_sorted)) == len(sc_sorted), name
+        names.append(name)
+        out[name + '/params'] = np.array([seed, bg, ob, scale, thr, nms], dtype=np.float64)
+        out[name + '/n_cand'] = np.int64(r['n_cand'])
+        out[name + '/n_sorted'] = np.int64(r['srt'][0].shape[0])
+        out[name + '/classes'] = r['out'][0].astype(np.int64)
+        out[name + '/scores'] = r['out'][1].astype(np.float32)
+        out[name + '/bboxes'] = r['out'][2].astype(np.float32).reshape(-1, 4)
+        out[name + '/sorted_classes'] = r['srt'][0].astype(np.int64)
+        out[name + '/sorted_scores'] = r['srt'][1].astype(np.float32)
+        print('%-10s cand=%6d sorted=%3d kept=%3d' % (name, r['n_cand'], r['srt'][0].shape[0], r['out'][0].shape[0]))
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'g3_pipeline.npz'), **out)
+
+
+def g4_edge(npm):
+    """Hand-built inputs to the individual np_methods steps (sort / clip / nms / resize)."""
+    out = {}
+    f = np.float32
+    # (a) ties: np.argsort(-scores) is unstable, so rows inside a run of equal scores come out in an
+    #     unspecified order (tests compare such runs as sets); the NMS result of this case does not
+    #     depend on that order.  Identical boxes of different class survive.
+    classes = np.array([3, 3, 5, 3, 5, 7, 7, 7], dtype=np.int64)
+    scores = np.array([.5, .9, .5, .5, .9, .25, .25, .75], dtype=f)
+    boxes = np.array([[.1, .1, .5, .5], [.1, .1, .5, .5], [.1, .1, .5, .5], [.12, .1, .5, .52],
+                      [.6, .6, .9, .9], [.0, .0, .2, .2], [.0, .0, .2, .2], [.01, .0, .2, .21]], dtype=f)
+    c, s, b = npm.bboxes_sort(classes, scores, boxes, top_k=400)
+    out['ties/in_classes'], out['ties/in_scores'], out['ties/in_bboxes'] = classes, scores, boxes
+    out['ties/sorted_classes'], out['ties/sorted_scores'], out['ties/sorted_bboxes'] = c, s, b
+    c2, s2, b2 = npm.bboxes_nms(c, s, b, nms_threshold=0.45)
+    out['ties/nms_classes'], out['ties/nms_scores'], out['ties/nms_bboxes'] = c2, s2, b2
+    # (b) zero-area boxes: IoU = 0/0 = NaN -> "NaN < thr" is False -> suppressed when same class
+    classes = np.array([1, 1, 1, 2, 1], dtype=np.int64)
+    scores = np.array([.9, .8, .7, .6, .5], dtype=f)
+    boxes = np.array([[.3, .3, .3, .3], [.3, .3, .3, .3], [.2, .2, .6, .6], [.3, .3, .3, .3], [.2, .2, .6, .6]], dtype=f)
+    with np.errstate(all='ignore'):
+        c2, s2, b2 = npm.bboxes_nms(classes, scores, boxes, nms_threshold=0.45)
+    out['zero/in_classes'], out['zero/in_scores'], out['zero/in_bboxes'] = classes, scores, boxes
+    out['zero/nms_classes'], out['zero/nms_scores'], out['zero/nms_bboxes'] = c2, s2, b2
+    # (c) clip: boxes outside / inverted after clip (np version has no repair)
+    boxes = np.array([[-.2, -.1, .5, .6], [.4, .5, 1.3, 1.2], [1.1, 1.2, 1.5, 1.6], [-.5, -.5, -.1, -.2], [.2, .2, .8, .8]], dtype=f)
+    out['clip/in_bboxes'] = boxes
+    out['clip/out_bboxes'] = npm.bboxes_clip(np.array([0., 0., 1., 1.], dtype=f), boxes)
+    out['clip/ref2'] = np.array([.1, .2, .7, .9], dtype=f)
+    out['clip/out_bboxes2'] = npm.bboxes_clip(out['clip/ref2'], boxes)
+    out['resize/out_bboxes2'] = npm.bboxes_resize(out['clip/ref2'], out['clip/out_bboxes2'])
+    # (d) inverted boxes through nms (negative extents -> negative areas)
+    classes = np.array([4, 4, 4], dtype=np.int64)
+    scores = np.array([.9, .8, .7], dtype=f)
+    boxes = np.array([[.5, .5, .2, .2], [.5, .5, .2, .2], [.1, .1, .6, .6]], dtype=f)
+    with np.errstate(all='ignore'):
+        c2, s2, b2 = npm.bboxes_nms(classes, scores, boxes, nms_threshold=0.45)
+    out['inv/in_classes'], out['inv/in_scores'], out['inv/in_bboxes'] = classes, scores, boxes
+    out['inv/nms_classes'], out['inv/nms_scores'], out['inv/nms_bboxes'] = c2, s2, b2
+    # (e) IoU exactly at the threshold: [0,0,1,1] vs [0,0,1,.45] -> IoU = .45 (f32) ; "<" keeps only below
+    classes = np.array([9, 9, 9], dtype=np.int64)
+    scores = np.array([.9, .8, .7], dtype=f)
+    boxes = np.array([[0, 0, 1, 1], [0, 0, 1, .45], [0, 0, 1, .44]], dtype=f)
+    c2, s2, b2 = npm.bboxes_nms(classes, scores, boxes, nms_threshold=0.45)
+    out['thr/in_classes'], out['thr/in_scores'], out['thr/in_bboxes'] = classes, scores, boxes
+    out['thr/nms_classes'], out['thr/nms_scores'], out['thr/nms_bboxes'] = c2, s2, b2
+    out['thr/iou'] = npm.bboxes_jaccard(boxes[0], boxes[1:])
+    # (f) select at exactly the threshold (strict >) and 400/401 candidate cut
+    rs = np.random.RandomState(21)
+    pred = np.zeros((1, 1, 1, 500, 21), dtype=f)
+    sc = np.sort(rs.uniform(.02, .99, 401).astype(f))[::-1]
+    assert len(np.unique(sc)) == 401
+    order = rs.permutation(401)
+    pred[0, 0, 0, order, 1 + (order % 20)] = sc
+    pred[0, 0, 0, 450, 5] = f(0.01)          # exactly thr -> not selected
+    pred[0, 0, 0, 451, 5] = np.nextafter(f(0.01), f(1))  # just above -> selected (402 candidates)
+    loc = rs.uniform(0, 1, (1, 1, 1, 500, 4)).astype(f)
+    loc[..., 2:] += loc[..., :2]
+    c, s, b = npm.ssd_bboxes_select_layer(pred, loc, None, select_threshold=0.01, decode=False)
+    out['cut/pred'], out['cut/boxes'] = pred, loc
+    out['cut/sel_classes'], out['cut/sel_scores'], out['cut/sel_bboxes'] = c, s, b
+    c, s, b = npm.bboxes_sort(c, s, b, top_k=400)
+    out['cut/sorted_classes'], out['cut/sorted_scores'], out['cut/sorted_bboxes'] = c, s, b
+    np.savez_compressed(os.path.join(HERE, 'g4_edge.npz'), **out)
+
+
+def main():
+    npm = load_np_methods()
+    ron = load_ref_ron()
+    anchors = g1_anchors(ron)
+    g2_decode(npm, anchors)
+    g3_pipeline(npm, anchors)
+    g4_edge(npm)
+    for fn in sorted(os.listdir(HERE)):
+        if fn.endswith('.npz'):
+            print(fn, os.path.getsize(os.path.join(HERE, fn)), 'bytes')
+
+
+if __name__ == '__main__':
+    main()
