@@ -1,0 +1,247 @@
+/*
+ * ron_hip.h -- C ABI of libron_hip.so: the MI355X (gfx950) RON-320 inference hot path.
+ *
+ * The reference (HiKapok/RON_Tensorflow) is pure Python/TensorFlow-1 and has NO FFI of its
+ * own; every entry point below replaces the reference *Python* interface quoted next to it
+ * (file:line relative to the reference repository).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add to call them.
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, PODs.  No torch / TF types.  `stream` is a hipStream_t passed
+ *     as void* (NULL = default stream).  All device pointers are HIP device pointers.
+ *   - Every function returns 0 on success or a negative ron_status; the message is available
+ *     through ron_last_error() (per thread when no context is involved).
+ *   - Nothing here synchronises with the host unless stated; work is enqueued on `stream`.
+ *   - Ownership: the caller owns every input/output buffer; a ron_ctx owns its weights,
+ *     anchors and workspace.  One ron_ctx per device; calls on one ctx are not re-entrant.
+ *   - Tensor layout: NHWC, row-major, fp32 at the boundary.  Boxes are (ymin, xmin, ymax, xmax)
+ *     in normalised image coordinates.  Head tensors are ordered coarse -> fine
+ *     (block7 5x5, block6 10x10, block5 20x20, block4 40x40), RONParams.feat_layers,
+ *     nets/ron_vgg_320.py:101.
+ */
+#ifndef RON_HIP_H_
+#define RON_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RON_MAX_LAYERS 8
+#define RON_MAX_ANCHORS_PER_CELL 16
+#define RON_MAX_TOPK 512           /* rows a detection list can hold (np_methods top_k = 400) */
+
+typedef enum {
+  RON_OK = 0,
+  RON_ERR_INVALID = -1,      /* bad argument                                   */
+  RON_ERR_HIP = -2,          /* a HIP runtime call failed                      */
+  RON_ERR_STATE = -3,        /* call order (e.g. forward before finalize)      */
+  RON_ERR_UNKNOWN_NAME = -4, /* unknown variable / end-point / network name    */
+  RON_ERR_UNSUPPORTED = -5
+} ron_status;
+
+typedef enum { RON_VARIANT_REDUCEDFC = 0, RON_VARIANT_FULL = 1 } ron_variant;
+typedef enum { RON_DTYPE_F32 = 0, RON_DTYPE_BF16 = 1, RON_DTYPE_F16 = 2 } ron_dtype;
+
+const char* ron_last_error(void);
+/* ABI version of the library (bumped on any signature change). */
+int ron_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Anchors.  Replaces ron_anchor_one_layer / ron_anchors_all_layers / RONNet.anchors
+ * (nets/ron_vgg_320.py:285-333, :336-355, :162-171).  Pure host function, bit-exact with the
+ * reference's numpy float32 arithmetic.
+ *   y, x : [feat_h * feat_w]   (the reference returns them as [H, W, 1])
+ *   h, w : [n_sizes * n_ratios], anchor a = i_ratio * n_sizes + j_size
+ * ---------------------------------------------------------------------------------------- */
+int ron_anchor_one_layer(int img_h, int img_w, int feat_h, int feat_w,
+                         const double* sizes, int n_sizes,
+                         const double* ratios, int n_ratios,
+                         double step, double offset,
+                         float* y, float* x, float* h, float* w);
+
+/* ------------------------------------------------------------------------------------------
+ * Head tensors of one batch (device pointers, fp32).  This is what RONNet.net() returns as
+ * Python lists (nets/ron_vgg_320.py:136-154, :580) and what bboxes_decode / detected_bboxes /
+ * np_methods.ssd_bboxes_select consume.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t num_layers;
+  int32_t num_classes;                      /* C, background included (21)                  */
+  int32_t feat_h[RON_MAX_LAYERS];
+  int32_t feat_w[RON_MAX_LAYERS];
+  int32_t num_anchors[RON_MAX_LAYERS];      /* A per cell (10)                              */
+  const float* cls[RON_MAX_LAYERS];         /* [N,H,W,A,C]  logits or probabilities         */
+  const float* obj[RON_MAX_LAYERS];         /* [N,H,W,A,2] logits | [N,H,W,A,1] prob | NULL */
+  const float* loc[RON_MAX_LAYERS];         /* [N,H,W,A,4]  raw offsets or decoded boxes    */
+  /* anchors (device): y, x [H*W]; h, w [A].  Needed only when loc holds raw offsets. */
+  const float* anchor_y[RON_MAX_LAYERS];
+  const float* anchor_x[RON_MAX_LAYERS];
+  const float* anchor_h[RON_MAX_LAYERS];
+  const float* anchor_w[RON_MAX_LAYERS];
+} ron_heads;
+
+/* flags for ron_post_cfg.input_flags */
+#define RON_IN_CLS_IS_PROB 1u   /* cls holds softmax probabilities (RONNet.net()[0])          */
+#define RON_IN_OBJ_IS_PROB 2u   /* obj holds P(object) [N,H,W,A,1] (RONNet.net()[2])          */
+#define RON_IN_LOC_DECODED 4u   /* loc already holds decoded boxes (RONNet.bboxes_decode)     */
+
+typedef struct {
+  float objectness_thres;   /* eval_ron_network.py:66-67,227-229 (0.03); ignored if obj NULL */
+  float select_threshold;   /* np_methods.py:59 / eval_ron_network.py:64-65                  */
+  float nms_threshold;      /* np_methods.py:229                                             */
+  int32_t top_k;            /* np_methods.py:137 (400); <= RON_MAX_TOPK                      */
+  float bbox_img[4];        /* clip reference + resize box (notebook cell 8): [0,0,1,1]      */
+  float prior_scaling[4];   /* np_methods.py:25: [0.1,0.1,0.2,0.2]                           */
+  uint32_t input_flags;
+} ron_post_cfg;
+
+/* Fixed-capacity detection list per image; rows >= count[i] are zero. */
+typedef struct {
+  int32_t capacity;         /* rows per image, >= top_k                                      */
+  int32_t* classes;         /* [N, capacity]                                                 */
+  float* scores;            /* [N, capacity]                                                 */
+  float* bboxes;            /* [N, capacity, 4]                                              */
+  int32_t* anchor_index;    /* [N, capacity]  flat index into the concatenated anchor list   */
+  int32_t* count;           /* [N]                                                           */
+} ron_detections;
+
+/* Bytes of device scratch ron_post_np needs for a batch of n images. */
+int64_t ron_post_np_workspace_bytes(const ron_heads* heads, int n);
+
+/*
+ * np_methods pipeline on the device (one call per batch):
+ *   [softmax + objectness gate]  nets/ron_vgg_320.py:572-576, eval_ron_network.py:227-229
+ *   decode                        np_methods.py:23-53   (== ssd_common.py:448-474)
+ *   select (score > thr, c >= 1)  np_methods.py:56-131
+ *   clip to bbox_img              np_methods.py:153-164
+ *   sort, keep top_k              np_methods.py:137-150 (order: score desc, position asc)
+ *   greedy class-aware IoU NMS    np_methods.py:186-205, :229-242
+ *   resize by bbox_img            np_methods.py:167-183
+ * `out` receives the kept boxes; `sorted_out` (optional, may be NULL) the list after the
+ * top_k cut and before NMS; `n_candidates` (optional) [N] the select count per image.
+ */
+int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cfg,
+                void* workspace, int64_t workspace_bytes,
+                ron_detections* out, ron_detections* sorted_out, int32_t* n_candidates,
+                void* stream);
+
+/*
+ * The last three steps alone, on explicit candidate lists (np_methods.bboxes_sort ->
+ * bboxes_nms, np_methods.py:137-150, :229-242): classes [N, n_in] int32, scores [N, n_in],
+ * bboxes [N, n_in, 4]; n_valid [N] (or NULL = n_in everywhere).  No clip / resize.
+ */
+int ron_np_sort_nms(const int32_t* classes, const float* scores, const float* bboxes,
+                    const int32_t* n_valid, int n, int n_in, int top_k, float nms_threshold,
+                    void* workspace, int64_t workspace_bytes,
+                    ron_detections* out, ron_detections* sorted_out, void* stream);
+int64_t ron_np_sort_nms_workspace_bytes(int n, int n_in);
+
+/* RONNet.bboxes_decode (nets/ron_vgg_320.py:188-195 -> ssd_common.py:448-498): one layer,
+ * loc [N,H,W,A,4] raw -> out [N,H,W,A,4] (ymin,xmin,ymax,xmax). */
+int ron_bboxes_decode_layer(const float* loc, int n, int feat_h, int feat_w, int num_anchors,
+                            const float* anchor_y, const float* anchor_x,
+                            const float* anchor_h, const float* anchor_w,
+                            const float prior_scaling[4], float* out, void* stream);
+
+/* slim.softmax over the last axis (nets/ron_vgg_320.py:572,574): x [rows, c] -> y [rows, c].
+ * With pick >= 0 only channel `pick` is written: y [rows, 1] (objness_pred, :576). */
+int ron_softmax_last(const float* x, int64_t rows, int c, int pick, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TF evaluation variant of the post-processing (what eval_ron_network.py:226-236 runs):
+ *   tf_ssd_bboxes_select (ssd_common.py:504-589) -> tfe.bboxes_clip (bboxes.py:105-144)
+ *   -> RONNet.bboxes_filter_min (ron_vgg_320.py:196-233) -> tfe.bboxes_sort (bboxes.py:60-101)
+ *   -> tfe.bboxes_nms_batch (bboxes.py:173-234, :262-302).
+ * Output: per class c = 1..C-1, keep_top_k rows, zero padded (tfe.pad_axis, tensors.py:59-86):
+ *   scores [N, C-1, keep_top_k], bboxes [N, C-1, keep_top_k, 4].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  float objectness_thres;
+  float select_threshold;
+  float nms_threshold;
+  int32_t top_k;            /* select_top_k (200), <= RON_MAX_TOPK */
+  int32_t keep_top_k;       /* 100 */
+  int32_t nms_mode;         /* 0 = 'min' (bboxes.py:207-208), 1 = 'union' (:205-206) */
+  int32_t clip;             /* clipping_bbox given? */
+  float clipping_bbox[4];
+  float min_size;           /* bboxes_filter_min minsize (0.03); < 0 disables (SSD) */
+  float prior_scaling[4];
+  uint32_t input_flags;
+} ron_tfe_cfg;
+
+int64_t ron_post_tfe_workspace_bytes(const ron_heads* heads, int n);
+int ron_post_tfe(const ron_heads* heads, int n, const ron_tfe_cfg* cfg,
+                 void* workspace, int64_t workspace_bytes,
+                 float* scores, float* bboxes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conv stack.  Replaces RONNet.net / ron_net / ron_net_reducedfc
+ * (nets/ron_vgg_320.py:136-154, :434-508, :510-580) with slim semantics of ron_arg_scope
+ * (:595-629).  Weights enter by TF variable name (SURVEY.md 8b "weight contract").
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ron_ctx ron_ctx;
+
+typedef struct {
+  int32_t variant;          /* ron_variant: which body `net` builds                          */
+  int32_t dtype;            /* ron_dtype: arithmetic type of the conv stack                  */
+  int32_t img_h, img_w;     /* 320, 320                                                      */
+  int32_t num_classes;      /* 21                                                            */
+  int32_t max_batch;        /* workspace is sized for this many images per call              */
+  int32_t device;           /* HIP device ordinal                                            */
+  int32_t reserved;
+} ron_config;
+
+int ron_create(ron_ctx** out, const ron_config* cfg);
+int ron_destroy(ron_ctx* ctx);
+
+/* Number of variables the graph expects and the i-th name/shape ("ron_320_vgg/conv1/conv1_1/weights",
+ * HWIO for conv, [kh,kw,Cout,Cin] for deconv, as TF stores them). */
+int ron_num_variables(const ron_ctx* ctx);
+int ron_variable_info(const ron_ctx* ctx, int i, const char** name, int64_t shape[4], int* ndim);
+/* Host fp32 data for one variable (copied). */
+int ron_load_weight(ron_ctx* ctx, const char* tf_name, const float* host_ptr,
+                    const int64_t* shape, int ndim);
+/* Fold BatchNorm (eps 1e-5), fuse parallel branches, repack to the kernel layout, cast, upload. */
+int ron_finalize_weights(ron_ctx* ctx);
+
+/* Filled by ron_forward: device fp32 tensors owned by the CALLER (ron_heads.cls/obj/loc must
+ * point at writable buffers of the right size; anchor_* are filled in from the ctx). */
+int ron_heads_describe(const ron_ctx* ctx, ron_heads* heads);   /* shapes + ctx anchor pointers */
+int ron_forward(ron_ctx* ctx, const float* d_images, int n, ron_heads* d_out, void* stream);
+
+/* Copy an end_point (nets/ron_vgg_320.py:455-483: block1..block7, plus every internal
+ * activation by layer name) as dense fp32 NHWC into `d_out`; shape returned in nhwc. */
+int ron_end_point_shape(const ron_ctx* ctx, const char* name, int n, int64_t nhwc[4]);
+int ron_end_point_copy(ron_ctx* ctx, const char* name, int n, float* d_out, void* stream);
+
+/* Fused: forward + np_methods post-processing, the graded path (config 2/3 of BASELINE.json). */
+int ron_detect(ron_ctx* ctx, const float* d_images, int n, const ron_post_cfg* cfg,
+               ron_detections* out, void* stream);
+
+/* Algorithmic work of one image through the conv stack (2*MAC of conv + deconv). */
+double ron_flops_per_image(const ron_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Single operators (used by the parity tests to pin each kernel against the oracle).
+ * conv2d NHWC: x [n,h,w,cin] fp32, w HWIO fp32 [kh,kw,cin,cout], bias [cout] or NULL,
+ * residual [n,ho,wo,cout] or NULL: y = act(conv + bias) ; if residual: y = relu(y + residual).
+ * `dtype` selects the arithmetic (operands rounded to bf16/f16, fp32 accumulate).
+ * transpose != 0: slim.conv2d_transpose with kernel = stride (weights [kh,kw,cout,cin]).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n, h, w, cin, cout;
+  int32_t kh, kw, stride, dilation;
+  int32_t relu;
+  int32_t transpose;
+  int32_t dtype;            /* ron_dtype */
+} ron_conv_desc;
+int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const float* w, const float* bias,
+                    const float* residual, float* y, void* stream);
+int ron_maxpool2x2_nhwc(const float* x, int n, int h, int w, int c, int dtype, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RON_HIP_H_ */

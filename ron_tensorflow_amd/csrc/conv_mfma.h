@@ -1,0 +1,52 @@
+// Host-side description of one implicit-GEMM convolution launch (see conv_mfma.hip).
+#pragma once
+#include "common.h"
+
+namespace ron {
+
+// NHWC activation tensor in HBM.  Every activation carries a zero halo of `pad` pixels so the
+// 3x3 / 7x7 / dilated taps never need a bounds check: memory is [N][H+2pad][W+2pad][cstride],
+// element type = the ctx dtype (bf16 / f16 / f32).  A view may address a channel slice
+// [coff, coff + C) of a wider tensor.
+struct TensorView {
+  void* base = nullptr;      // start of the allocation (pixel (0,-pad,-pad), channel 0)
+  int64_t bytes = 0;         // size of the allocation
+  int N = 0, H = 0, W = 0, C = 0;
+  int pad = 0;
+  int cstride = 0;           // elements per pixel in memory
+  int coff = 0;              // first channel of the view
+  int Hp() const { return H + 2 * pad; }
+  int Wp() const { return W + 2 * pad; }
+};
+
+struct ConvLaunch {
+  int dtype = RON_DTYPE_BF16;
+  TensorView in, out;
+  const void* res = nullptr;     // residual with the geometry of `out` (same dtype), or null
+  const void* wgt = nullptr;     // packed [Npad][K] (K = kh*kw*Cin contiguous), dtype elements
+  int64_t wgt_bytes = 0;
+  const float* bias = nullptr;   // [Npad] fp32 (never null; zeros when the layer has none)
+  int Cout = 0;                  // GEMM N that is stored (<= Npad)
+  int Npad = 0;                  // rows of wgt, multiple of the N tile
+  int kh = 1, kw = 1, stride = 1, dil = 1, cpad = 0;
+  int relu = 0;
+  int out_f32 = 0;               // store fp32 (head logits) instead of dtype
+  // conv2d_transpose with kernel == stride == `up` (pixel shuffle epilogue); 0 = plain conv.
+  int up = 0;
+  int up_cout = 0;               // channels per tap of the transposed conv (Cout = up*up*up_cout)
+  int Ho = 0, Wo = 0;            // GEMM rows = N*Ho*Wo (input grid for a transposed conv)
+};
+
+int launch_conv(const ConvLaunch& c, hipStream_t stream);
+// Elements along K one staging step covers for this dtype (Cin must be a multiple of it).
+int conv_k_chunk(int dtype);
+int conv_n_tile(int cout);       // N tile (64 or 128) the launcher picks for this Cout
+size_t dtype_size(int dtype);
+
+// helpers (elementwise.hip)
+int launch_im2col_c3(const float* x, int n, int h, int w, int dtype, void* out, int kchunk, hipStream_t s);
+int launch_maxpool2x2(const TensorView& in, const TensorView& out, int dtype, hipStream_t s);
+int launch_pack_input(const float* x, const TensorView& out, int dtype, hipStream_t s);      // dense fp32 -> view
+int launch_unpack(const TensorView& in, int dtype, int in_is_f32, float* y, hipStream_t s);  // view -> dense fp32
+
+}  // namespace ron

@@ -1,0 +1,169 @@
+// Bandwidth-bound helpers around the conv stack: conv1_1 im2col, 2x2 max-pool, and the
+// fp32 <-> halo-tensor conversions at the boundary.  16 bytes per lane everywhere.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "conv_mfma.h"
+
+namespace ron {
+namespace {
+
+template <class T> struct Cvt;
+template <> struct Cvt<__hip_bfloat16> {
+  static __device__ __forceinline__ float to_f(__hip_bfloat16 v) { return __bfloat162float(v); }
+  static __device__ __forceinline__ __hip_bfloat16 from_f(float v) { return __float2bfloat16(v); }
+};
+template <> struct Cvt<_Float16> {
+  static __device__ __forceinline__ float to_f(_Float16 v) { return (float)v; }
+  static __device__ __forceinline__ _Float16 from_f(float v) { return (_Float16)v; }
+};
+template <> struct Cvt<float> {
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+
+template <class T, int V> struct alignas(sizeof(T) * V) Vec { T v[V]; };
+
+// conv1_1 (Cin = 3): x fp32 [N,H,W,3] -> out T [N,H,W,kc], out[.., (ky*3+kx)*3 + c] = x[y+ky-1, x+kx-1, c]
+// (zero outside the image, zero for k >= 27).  The 3x3 conv then runs as a 1x1 conv on the MFMA path.
+template <class T>
+__global__ void im2col_c3_kernel(const float* __restrict__ x, int n, int h, int w, int kc, T* __restrict__ out) {
+  constexpr int V = 16 / sizeof(T);
+  const int groups = kc / V;
+  const long long total = (long long)n * h * w * groups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const long long pix = i / groups;
+    const int px = (int)(pix % w);
+    const int py = (int)((pix / w) % h);
+    const long long img = pix / ((long long)w * h);
+    Vec<T, V> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int k = g * V + e;
+      float val = 0.f;
+      if (k < 27) {
+        const int tap = k / 3, c = k - tap * 3;
+        const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) val = x[((img * h + yy) * w + xx) * 3 + c];
+      }
+      o.v[e] = Cvt<T>::from_f(val);
+    }
+    reinterpret_cast<Vec<T, V>*>(out)[i] = o;
+  }
+}
+
+struct ViewDev {
+  char* base;
+  int N, H, W, C, pad, cstride, coff, Hp, Wp;
+};
+ViewDev to_dev(const TensorView& v) {
+  return ViewDev{(char*)v.base, v.N, v.H, v.W, v.C, v.pad, v.cstride, v.coff, v.Hp(), v.Wp()};
+}
+__device__ __forceinline__ long long view_off(const ViewDev& v, long long img, int y, int x) {
+  return ((img * v.Hp + y + v.pad) * v.Wp + x + v.pad) * v.cstride + v.coff;
+}
+
+// slim.max_pool2d [2,2] stride 2 (nets/ron_vgg_320.py:456..475); all RON maps are even so SAME == VALID.
+template <class T>
+__global__ void maxpool2x2_kernel(ViewDev in, ViewDev out) {
+  constexpr int V = 16 / sizeof(T);
+  const int groups = out.C / V;
+  const long long total = (long long)out.N * out.H * out.W * groups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const long long pix = i / groups;
+    const int ox = (int)(pix % out.W);
+    const int oy = (int)((pix / out.W) % out.H);
+    const long long img = pix / ((long long)out.W * out.H);
+    const T* ib = reinterpret_cast<const T*>(in.base);
+    const long long o00 = view_off(in, img, 2 * oy, 2 * ox) + g * V;
+    const long long rowstep = (long long)in.Wp * in.cstride;
+    const Vec<T, V> a = *reinterpret_cast<const Vec<T, V>*>(ib + o00);
+    const Vec<T, V> b = *reinterpret_cast<const Vec<T, V>*>(ib + o00 + in.cstride);
+    const Vec<T, V> c = *reinterpret_cast<const Vec<T, V>*>(ib + o00 + rowstep);
+    const Vec<T, V> d = *reinterpret_cast<const Vec<T, V>*>(ib + o00 + rowstep + in.cstride);
+    Vec<T, V> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float m = fmaxf(fmaxf(Cvt<T>::to_f(a.v[e]), Cvt<T>::to_f(b.v[e])), fmaxf(Cvt<T>::to_f(c.v[e]), Cvt<T>::to_f(d.v[e])));
+      o.v[e] = Cvt<T>::from_f(m);
+    }
+    T* ob = reinterpret_cast<T*>(out.base);
+    *reinterpret_cast<Vec<T, V>*>(ob + view_off(out, img, oy, ox) + g * V) = o;
+  }
+}
+
+template <class T>
+__global__ void pack_kernel(const float* __restrict__ x, ViewDev out) {
+  const long long total = (long long)out.N * out.H * out.W * out.C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % out.C);
+    const long long pix = i / out.C;
+    const int px = (int)(pix % out.W);
+    const int py = (int)((pix / out.W) % out.H);
+    const long long img = pix / ((long long)out.W * out.H);
+    reinterpret_cast<T*>(out.base)[view_off(out, img, py, px) + c] = Cvt<T>::from_f(x[i]);
+  }
+}
+
+template <class T>
+__global__ void unpack_kernel(ViewDev in, float* __restrict__ y) {
+  const long long total = (long long)in.N * in.H * in.W * in.C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % in.C);
+    const long long pix = i / in.C;
+    const int px = (int)(pix % in.W);
+    const int py = (int)((pix / in.W) % in.H);
+    const long long img = pix / ((long long)in.W * in.H);
+    y[i] = Cvt<T>::to_f(reinterpret_cast<const T*>(in.base)[view_off(in, img, py, px) + c]);
+  }
+}
+
+int grid_for(long long total) { return (int)std::min<long long>((total + 255) / 256, 256 * 8); }
+
+}  // namespace
+
+int launch_im2col_c3(const float* x, int n, int h, int w, int dtype, void* out, int kchunk, hipStream_t s) {
+  const long long total = (long long)n * h * w * (kchunk / (16 / (int)dtype_size(dtype)));
+  const int g = grid_for(total);
+  if (dtype == RON_DTYPE_BF16) hipLaunchKernelGGL(im2col_c3_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, s, x, n, h, w, kchunk, (__hip_bfloat16*)out);
+  else if (dtype == RON_DTYPE_F16) hipLaunchKernelGGL(im2col_c3_kernel<_Float16>, dim3(g), dim3(256), 0, s, x, n, h, w, kchunk, (_Float16*)out);
+  else hipLaunchKernelGGL(im2col_c3_kernel<float>, dim3(g), dim3(256), 0, s, x, n, h, w, kchunk, (float*)out);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+int launch_maxpool2x2(const TensorView& in, const TensorView& out, int dtype, hipStream_t s) {
+  const int V = 16 / (int)dtype_size(dtype);
+  RON_REQUIRE(in.H == 2 * out.H && in.W == 2 * out.W && in.C == out.C && in.N == out.N, "maxpool: shape mismatch");
+  RON_REQUIRE(out.C % V == 0 && in.cstride % V == 0 && out.cstride % V == 0 && in.coff % V == 0 && out.coff % V == 0,
+              "maxpool: channels must be a multiple of %d", V);
+  const long long total = (long long)out.N * out.H * out.W * (out.C / V);
+  const int g = grid_for(total);
+  if (dtype == RON_DTYPE_BF16) hipLaunchKernelGGL(maxpool2x2_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out));
+  else if (dtype == RON_DTYPE_F16) hipLaunchKernelGGL(maxpool2x2_kernel<_Float16>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out));
+  else hipLaunchKernelGGL(maxpool2x2_kernel<float>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out));
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+int launch_pack_input(const float* x, const TensorView& out, int dtype, hipStream_t s) {
+  const int g = grid_for((long long)out.N * out.H * out.W * out.C);
+  if (dtype == RON_DTYPE_BF16) hipLaunchKernelGGL(pack_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, s, x, to_dev(out));
+  else if (dtype == RON_DTYPE_F16) hipLaunchKernelGGL(pack_kernel<_Float16>, dim3(g), dim3(256), 0, s, x, to_dev(out));
+  else hipLaunchKernelGGL(pack_kernel<float>, dim3(g), dim3(256), 0, s, x, to_dev(out));
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+int launch_unpack(const TensorView& in, int dtype, int in_is_f32, float* y, hipStream_t s) {
+  const int g = grid_for((long long)in.N * in.H * in.W * in.C);
+  if (in_is_f32 || dtype == RON_DTYPE_F32) hipLaunchKernelGGL(unpack_kernel<float>, dim3(g), dim3(256), 0, s, to_dev(in), y);
+  else if (dtype == RON_DTYPE_BF16) hipLaunchKernelGGL(unpack_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, s, to_dev(in), y);
+  else hipLaunchKernelGGL(unpack_kernel<_Float16>, dim3(g), dim3(256), 0, s, to_dev(in), y);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+}  // namespace ron

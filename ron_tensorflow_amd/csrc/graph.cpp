@@ -1,0 +1,620 @@
+// ron_ctx: the RON-320 conv stack as a fixed launch plan over pre-allocated HBM tensors.
+//
+// Restates the graph of nets/ron_vgg_320.py (ron_net :434-508, ron_net_reducedfc :510-580,
+// reverse_connection_module_with_pred :418-432, pred_cls_module :378-404, reg_bbox_module
+// :406-415) with the slim layer semantics of ron_arg_scope (:595-629), re-planned for the
+// MFMA implicit-GEMM kernel:
+//   * inference BatchNorm (eps 1e-5) is folded into the preceding conv at load time;
+//   * per scale, the three 3x3 convs that read the reference map (objectness hidden layer,
+//     inception-1 = 3x3 || 1x1 concat, box hidden layer) run as ONE conv with 2048 output
+//     channels (the 1x1 branch sits in the centre tap), consumers read channel slices;
+//   * inception-2 (3x3 || 1x1 on 1024 channels) is one conv with 1024 outputs;
+//   * the 2x2 stride-2 transposed conv is a GEMM with a pixel-shuffle epilogue, and the
+//     reverse-connection sum relu(left + up) is the epilogue of the left conv;
+//   * head logits are written as fp32 straight into the caller's buffers.
+// Every activation lives in HBM as NHWC with a zero halo (conv_mfma.h); all buffers are
+// allocated once for max_batch images (activations of the full variant: ~150 MB / image).
+#include <math.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "pack.h"
+
+using namespace ron;
+
+namespace {
+
+constexpr float kBnEps = 1e-5f;
+const char* kScope = "ron_320_vgg";
+const char* kFeatLayers[4] = {"block7", "block6", "block5", "block4"};
+
+struct Var {
+  std::string name;
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool loaded = false;
+  int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct Tensor {
+  std::string name;
+  int H, W, C, pad;
+  void* d = nullptr;
+  int64_t bytes = 0;
+};
+
+struct PackedConv {
+  void* d_w = nullptr;
+  int64_t w_bytes = 0;
+  float* d_bias = nullptr;
+  int Npad = 0, Cout = 0;
+};
+
+enum OpKind { OP_IM2COL, OP_CONV, OP_POOL };
+
+struct Op {
+  OpKind kind;
+  std::string name;
+  int in = -1, out = -1, res = -1;      // tensor indices; out == -2: caller head buffer
+  int in_coff = 0, in_C = 0;            // channel slice of the input
+  int packed = -1;
+  int kh = 1, kw = 1, stride = 1, dil = 1, cpad = 0, relu = 0;
+  int up = 0, up_cout = 0;
+  int head_kind = -1, head_layer = -1;  // 0 cls, 1 obj, 2 loc
+  int Ho = 0, Wo = 0;
+};
+
+}  // namespace
+
+struct ron_ctx {
+  ron_config cfg;
+  int c6 = 0;                 // fc6 / fc7 channels
+  int num_anchors = 10;
+  int feat[4] = {0, 0, 0, 0};
+  std::vector<Var> vars;
+  std::map<std::string, int> var_index;
+  std::vector<Tensor> tensors;
+  std::map<std::string, int> tensor_index;
+  std::vector<PackedConv> packed;
+  std::vector<Op> ops;
+  bool finalized = false;
+  double flops_per_image = 0;
+  // anchors (device) + head buffers / workspace for ron_detect
+  float* d_anchor[4][4] = {};
+  float* d_head[3][4] = {};
+  void* d_post_ws = nullptr;
+  int64_t post_ws_bytes = 0;
+
+  int esz() const { return (int)dtype_size(cfg.dtype); }
+  int add_tensor(const std::string& name, int H, int W, int C, int pad) {
+    Tensor t;
+    t.name = name; t.H = H; t.W = W; t.C = C; t.pad = pad;
+    tensors.push_back(t);
+    tensor_index[name] = (int)tensors.size() - 1;
+    return (int)tensors.size() - 1;
+  }
+  void add_var(const std::string& rel, std::vector<int64_t> shape) {
+    Var v;
+    v.name = std::string(kScope) + "/" + rel;
+    v.shape = shape;
+    var_index[v.name] = (int)vars.size();
+    vars.push_back(v);
+  }
+  const Var& var(const std::string& rel) const { return vars[var_index.at(std::string(kScope) + "/" + rel)]; }
+  TensorView view(int t, int n, int coff = 0, int C = -1) const {
+    const Tensor& T = tensors[t];
+    TensorView v;
+    v.base = T.d; v.bytes = T.bytes; v.N = n; v.H = T.H; v.W = T.W; v.pad = T.pad; v.cstride = T.C;
+    v.coff = coff; v.C = C < 0 ? T.C : C;
+    return v;
+  }
+};
+
+namespace {
+
+void add_bn_vars(ron_ctx* c, const std::string& scope, int ch) {
+  for (const char* n : {"beta", "gamma", "moving_mean", "moving_variance"}) c->add_var(scope + "/BatchNorm/" + n, {ch});
+}
+
+// The variable list (names/shapes as TensorFlow stores them; SURVEY.md 8b weight contract).
+void declare_variables(ron_ctx* c) {
+  const int nc = c->cfg.num_classes, A = c->num_anchors, c6 = c->c6;
+  const int widths[5] = {64, 128, 256, 512, 512};
+  const int reps[5] = {2, 2, 3, 3, 3};
+  int cin = 3;
+  for (int b = 0; b < 5; ++b)
+    for (int r = 0; r < reps[b]; ++r) {
+      const std::string s = "conv" + std::to_string(b + 1) + "/conv" + std::to_string(b + 1) + "_" + std::to_string(r + 1);
+      c->add_var(s + "/weights", {3, 3, cin, widths[b]});
+      c->add_var(s + "/biases", {widths[b]});
+      cin = widths[b];
+    }
+  const int k6 = c->cfg.variant == RON_VARIANT_FULL ? 7 : 3;
+  c->add_var("fc6/weights", {k6, k6, 512, c6});
+  c->add_var("fc6/biases", {c6});
+  c->add_var("fc7/weights", {1, 1, c6, c6});
+  c->add_var("fc7/biases", {c6});
+  for (int i = 0; i < 4; ++i) {
+    const std::string L = std::string("reverse_module/") + kFeatLayers[i] + "_reverse";
+    const int left_c = i < 2 ? c6 : 512;
+    const int k = i == 0 ? 2 : 3;
+    c->add_var(L + "_conv_left/weights", {k, k, left_c, 512});
+    add_bn_vars(c, L + "_conv_left", 512);
+    if (i > 0) {
+      c->add_var(L + "_deconv_right/weights", {2, 2, 512, 512});
+      c->add_var(L + "_deconv_right/biases", {512});
+    }
+    c->add_var(L + "_objectness/weights", {3, 3, 512, 512});
+    add_bn_vars(c, L + "_objectness", 512);
+    c->add_var(L + "_objectness_score/weights", {3, 3, 512, 2 * A});
+    c->add_var(L + "_objectness_score/biases", {2 * A});
+    for (int blk = 1; blk <= 2; ++blk) {
+      const std::string I = L + "_inception" + std::to_string(blk);
+      const int ic = blk == 1 ? 512 : 1024;
+      c->add_var(I + "/Branch_0/Conv2d_3x3/weights", {3, 3, ic, 512});
+      c->add_var(I + "/Branch_0/Conv2d_3x3/biases", {512});
+      c->add_var(I + "/Branch_1/Conv2d_1x1/weights", {1, 1, ic, 512});
+      c->add_var(I + "/Branch_1/Conv2d_1x1/biases", {512});
+      add_bn_vars(c, I, 1024);
+    }
+    c->add_var(L + "_inception2/Conv2d_pred_3x3/weights", {3, 3, 1024, A * nc});
+    c->add_var(L + "_inception2/Conv2d_pred_3x3/biases", {A * nc});
+    c->add_var(L + "/Conv2d_0_3x3/weights", {3, 3, 512, 512});
+    add_bn_vars(c, L + "/Conv2d_0_3x3", 512);
+    c->add_var(L + "/Conv2d_1_3x3/weights", {3, 3, 512, 4 * A});
+    c->add_var(L + "/Conv2d_1_3x3/biases", {4 * A});
+  }
+}
+
+// ---- weight assembly: fp32 rows [npad][K] + bias [npad] -----------------------------------
+struct Rows {
+  int K = 0, npad = 0, kh = 0, kw = 0, cin = 0;
+  std::vector<float> w, b;
+  void init(int kh_, int kw_, int cin_, int n_real, int ntile) {
+    kh = kh_; kw = kw_; cin = cin_; K = kh * kw * cin; npad = round_up(n_real, ntile);
+    w.assign((size_t)npad * K, 0.f);
+    b.assign(npad, 0.f);
+  }
+  // place an HWIO filter (fh x fw, centred) at output rows [n_off, n_off + cout)
+  void place(const Var& wv, int n_off) {
+    const int fh = (int)wv.shape[0], fw = (int)wv.shape[1], ci = (int)wv.shape[2], co = (int)wv.shape[3];
+    const int oy = (kh - fh) / 2, ox = (kw - fw) / 2;
+    for (int y = 0; y < fh; ++y)
+      for (int x = 0; x < fw; ++x)
+        for (int c = 0; c < ci; ++c) {
+          const float* src = &wv.data[(((size_t)y * fw + x) * ci + c) * co];
+          const size_t k = ((size_t)(y + oy) * kw + (x + ox)) * cin + c;
+          for (int n = 0; n < co; ++n) w[(size_t)(n_off + n) * K + k] = src[n];
+        }
+  }
+  void add_bias(const Var& bv, int n_off) { for (size_t n = 0; n < bv.data.size(); ++n) b[n_off + n] += bv.data[n]; }
+  // y = gamma * (x - mean) / sqrt(var + eps) + beta  folded into rows [n_off, n_off + ch)
+  void fold_bn(const ron_ctx* c, const std::string& scope, int n_off, int ch) {
+    const Var& be = c->var(scope + "/BatchNorm/beta"); const Var& ga = c->var(scope + "/BatchNorm/gamma");
+    const Var& mu = c->var(scope + "/BatchNorm/moving_mean"); const Var& va = c->var(scope + "/BatchNorm/moving_variance");
+    for (int n = 0; n < ch; ++n) {
+      const float s = ga.data[n] / sqrtf(va.data[n] + kBnEps);
+      float* row = &w[(size_t)(n_off + n) * K];
+      for (int k = 0; k < K; ++k) row[k] *= s;
+      b[n_off + n] = (b[n_off + n] - mu.data[n]) * s + be.data[n];
+    }
+  }
+};
+
+int upload(ron_ctx* c, const Rows& r, int cout) {
+  PackedConv p;
+  std::vector<uint8_t> bytes = cast_rows(r.w, c->cfg.dtype);
+  p.w_bytes = (int64_t)bytes.size();
+  p.Npad = r.npad; p.Cout = cout;
+  RON_HIP_CHECK(hipMalloc(&p.d_w, bytes.size()));
+  RON_HIP_CHECK(hipMemcpy(p.d_w, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  RON_HIP_CHECK(hipMalloc((void**)&p.d_bias, r.b.size() * sizeof(float)));
+  RON_HIP_CHECK(hipMemcpy(p.d_bias, r.b.data(), r.b.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->packed.push_back(p);
+  return (int)c->packed.size() - 1;
+}
+
+// returns packed index (>= 0) or negative status
+int pack_plain(ron_ctx* c, const std::string& scope, bool bn) {
+  const Var& w = c->var(scope + "/weights");
+  const int cout = (int)w.shape[3];
+  Rows r;
+  r.init((int)w.shape[0], (int)w.shape[1], (int)w.shape[2], cout, conv_n_tile(cout));
+  r.place(w, 0);
+  if (bn) r.fold_bn(c, scope, 0, cout); else r.add_bias(c->var(scope + "/biases"), 0);
+  return upload(c, r, cout);
+}
+
+int pack_stem(ron_ctx* c, const std::string& scope) {
+  const Var& w = c->var(scope + "/weights");
+  const int cout = (int)w.shape[3], chunk = conv_k_chunk(c->cfg.dtype);
+  Rows r;
+  r.init(1, 1, chunk, cout, conv_n_tile(cout));
+  for (int k = 0; k < 27; ++k) for (int n = 0; n < cout; ++n) r.w[(size_t)n * chunk + k] = w.data[(size_t)k * cout + n];
+  r.add_bias(c->var(scope + "/biases"), 0);
+  return upload(c, r, cout);
+}
+
+int pack_deconv(ron_ctx* c, const std::string& scope) {
+  const Var& w = c->var(scope + "/weights");     // [kh, kw, Cout, Cin]
+  const Var& bv = c->var(scope + "/biases");
+  const int taps = (int)(w.shape[0] * w.shape[1]), co = (int)w.shape[2], ci = (int)w.shape[3];
+  Rows r;
+  r.init(1, 1, ci, taps * co, conv_n_tile(taps * co));
+  memcpy(r.w.data(), w.data.data(), w.data.size() * sizeof(float));
+  for (int t = 0; t < taps; ++t) for (int n = 0; n < co; ++n) r.b[t * co + n] = bv.data[n];
+  return upload(c, r, taps * co);
+}
+
+// rows 0..511 objectness hidden (conv+BN), 512..1535 inception1 (3x3 || 1x1, BN over the concat),
+// 1536..2047 box hidden (conv+BN)
+int pack_trio(ron_ctx* c, const std::string& L) {
+  Rows r;
+  r.init(3, 3, 512, 2048, 128);
+  r.place(c->var(L + "_objectness/weights"), 0);
+  r.fold_bn(c, L + "_objectness", 0, 512);
+  r.place(c->var(L + "_inception1/Branch_0/Conv2d_3x3/weights"), 512);
+  r.add_bias(c->var(L + "_inception1/Branch_0/Conv2d_3x3/biases"), 512);
+  r.place(c->var(L + "_inception1/Branch_1/Conv2d_1x1/weights"), 1024);
+  r.add_bias(c->var(L + "_inception1/Branch_1/Conv2d_1x1/biases"), 1024);
+  r.fold_bn(c, L + "_inception1", 512, 1024);
+  r.place(c->var(L + "/Conv2d_0_3x3/weights"), 1536);
+  r.fold_bn(c, L + "/Conv2d_0_3x3", 1536, 512);
+  return upload(c, r, 2048);
+}
+
+int pack_inception2(ron_ctx* c, const std::string& L) {
+  Rows r;
+  r.init(3, 3, 1024, 1024, 128);
+  r.place(c->var(L + "_inception2/Branch_0/Conv2d_3x3/weights"), 0);
+  r.add_bias(c->var(L + "_inception2/Branch_0/Conv2d_3x3/biases"), 0);
+  r.place(c->var(L + "_inception2/Branch_1/Conv2d_1x1/weights"), 512);
+  r.add_bias(c->var(L + "_inception2/Branch_1/Conv2d_1x1/biases"), 512);
+  r.fold_bn(c, L + "_inception2", 0, 1024);
+  return upload(c, r, 1024);
+}
+
+Op conv_op(const std::string& name, int in, int out, int packed, int k, int cpad, int relu, int Ho, int Wo) {
+  Op o;
+  o.kind = OP_CONV; o.name = name; o.in = in; o.out = out; o.packed = packed;
+  o.kh = o.kw = k; o.cpad = cpad; o.relu = relu; o.Ho = Ho; o.Wo = Wo;
+  return o;
+}
+
+double conv_flops(const Var& w, int out_pixels) { return 2.0 * (double)w.numel() * out_pixels; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
+  RON_REQUIRE(out && cfg, "NULL argument");
+  RON_REQUIRE(cfg->variant == RON_VARIANT_REDUCEDFC || cfg->variant == RON_VARIANT_FULL, "unknown variant %d", cfg->variant);
+  RON_REQUIRE(cfg->dtype >= 0 && cfg->dtype <= 2, "unknown dtype %d", cfg->dtype);
+  RON_REQUIRE(cfg->img_h > 0 && cfg->img_h % 64 == 0 && cfg->img_w > 0 && cfg->img_w % 64 == 0, "image size must be a multiple of 64");
+  RON_REQUIRE(cfg->num_classes >= 2 && cfg->num_classes <= 64, "num_classes out of range");
+  RON_REQUIRE(cfg->max_batch >= 1, "max_batch must be >= 1");
+  RON_HIP_CHECK(hipSetDevice(cfg->device));
+  std::unique_ptr<ron_ctx> c(new ron_ctx());
+  c->cfg = *cfg;
+  c->c6 = cfg->variant == RON_VARIANT_FULL ? 4096 : 1024;
+  declare_variables(c.get());
+
+  // ---- tensors ----
+  const int H = cfg->img_h, W = cfg->img_w;
+  const int chunk = conv_k_chunk(cfg->dtype);
+  c->add_tensor("im2col", H, W, chunk, 0);
+  const int widths[5] = {64, 128, 256, 512, 512};
+  const int reps[5] = {2, 2, 3, 3, 3};
+  int h = H, w = W;
+  for (int b = 0; b < 5; ++b) {
+    for (int r = 0; r < reps[b]; ++r) {
+      const bool last = r == reps[b] - 1;
+      // the block output feeds the pool (no halo needed); block4/block5 also feed a 3x3 left conv
+      const int pad = (!last || b >= 3) ? 1 : 0;
+      c->add_tensor("conv" + std::to_string(b + 1) + "_" + std::to_string(r + 1), h, w, widths[b], pad);
+    }
+    h /= 2; w /= 2;
+    c->add_tensor("pool" + std::to_string(b + 1), h, w, widths[b], b == 4 ? 3 : 1);
+  }
+  c->add_tensor("fc6", h, w, c->c6, 1);
+  c->add_tensor("fc7", h, w, c->c6, 0);
+  for (int i = 0; i < 4; ++i) {
+    const int s_h = (H / 64) << i, s_w = (W / 64) << i;
+    c->feat[i] = s_h;
+    const std::string L = kFeatLayers[i];
+    if (i > 0) c->add_tensor(L + "_up", s_h, s_w, 512, 1);
+    c->add_tensor(L + "_ref", s_h, s_w, 512, 1);
+    c->add_tensor(L + "_hcat", s_h, s_w, 2048, 1);
+    c->add_tensor(L + "_inc2", s_h, s_w, 1024, 1);
+  }
+  for (auto& t : c->tensors) {
+    t.bytes = (int64_t)cfg->max_batch * (t.H + 2 * t.pad) * (t.W + 2 * t.pad) * t.C * c->esz();
+    if (t.bytes >= ((int64_t)1 << 32)) {
+      ron::set_error("tensor %s needs %lld bytes for max_batch %d: above the 4 GiB buffer-addressing limit; lower max_batch",
+                     t.name.c_str(), (long long)t.bytes, cfg->max_batch);
+      for (auto& u : c->tensors) if (u.d) (void)hipFree(u.d);
+      return RON_ERR_INVALID;
+    }
+    RON_HIP_CHECK(hipMalloc(&t.d, (size_t)t.bytes));
+    RON_HIP_CHECK(hipMemset(t.d, 0, (size_t)t.bytes));     // halos stay zero forever: kernels write interiors only
+  }
+  // ---- anchors (RONNet.default_params, nets/ron_vgg_320.py:97-124) ----
+  const double sizes[4][2] = {{224., 256.}, {160., 192.}, {96., 128.}, {32., 64.}};
+  const double ratios[5] = {1., 2., 3., 1. / 2, 1. / 3};
+  const double steps[4] = {64, 32, 16, 8};
+  for (int i = 0; i < 4; ++i) {
+    const int fh = (H / 64) << i, fw = (W / 64) << i;
+    std::vector<float> y(fh * fw), x(fh * fw), hh(10), ww(10);
+    int rc = ron_anchor_one_layer(H, W, fh, fw, sizes[i], 2, ratios, 5, steps[i], 0.5, y.data(), x.data(), hh.data(), ww.data());
+    if (rc) return rc;
+    const std::vector<float>* src[4] = {&y, &x, &hh, &ww};
+    for (int k = 0; k < 4; ++k) {
+      RON_HIP_CHECK(hipMalloc((void**)&c->d_anchor[i][k], src[k]->size() * sizeof(float)));
+      RON_HIP_CHECK(hipMemcpy(c->d_anchor[i][k], src[k]->data(), src[k]->size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
+  *out = c.release();
+  return RON_OK;
+}
+
+extern "C" int ron_destroy(ron_ctx* c) {
+  if (!c) return RON_OK;
+  for (auto& t : c->tensors) if (t.d) (void)hipFree(t.d);
+  for (auto& p : c->packed) { if (p.d_w) (void)hipFree(p.d_w); if (p.d_bias) (void)hipFree(p.d_bias); }
+  for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) if (c->d_anchor[i][k]) (void)hipFree(c->d_anchor[i][k]);
+  for (int k = 0; k < 3; ++k) for (int i = 0; i < 4; ++i) if (c->d_head[k][i]) (void)hipFree(c->d_head[k][i]);
+  if (c->d_post_ws) (void)hipFree(c->d_post_ws);
+  delete c;
+  return RON_OK;
+}
+
+extern "C" int ron_num_variables(const ron_ctx* c) { return c ? (int)c->vars.size() : RON_ERR_INVALID; }
+
+extern "C" int ron_variable_info(const ron_ctx* c, int i, const char** name, int64_t shape[4], int* ndim) {
+  RON_REQUIRE(c && i >= 0 && i < (int)c->vars.size(), "variable index out of range");
+  if (name) *name = c->vars[i].name.c_str();
+  if (ndim) *ndim = (int)c->vars[i].shape.size();
+  if (shape) for (size_t k = 0; k < c->vars[i].shape.size(); ++k) shape[k] = c->vars[i].shape[k];
+  return RON_OK;
+}
+
+extern "C" int ron_load_weight(ron_ctx* c, const char* tf_name, const float* host_ptr, const int64_t* shape, int ndim) {
+  RON_REQUIRE(c && tf_name && host_ptr && shape, "NULL argument");
+  if (c->finalized) { ron::set_error("weights are already finalized"); return RON_ERR_STATE; }
+  auto it = c->var_index.find(tf_name);
+  if (it == c->var_index.end()) { ron::set_error("unknown variable '%s'", tf_name); return RON_ERR_UNKNOWN_NAME; }
+  Var& v = c->vars[it->second];
+  bool same = ndim == (int)v.shape.size();
+  for (int k = 0; same && k < ndim; ++k) same = shape[k] == v.shape[k];
+  if (!same) { ron::set_error("variable '%s': shape mismatch", tf_name); return RON_ERR_INVALID; }
+  v.data.assign(host_ptr, host_ptr + v.numel());
+  v.loaded = true;
+  return RON_OK;
+}
+
+extern "C" int ron_finalize_weights(ron_ctx* c) {
+  RON_REQUIRE(c, "NULL ctx");
+  if (c->finalized) { ron::set_error("weights are already finalized"); return RON_ERR_STATE; }
+  for (auto& v : c->vars)
+    if (!v.loaded) { ron::set_error("variable '%s' was not loaded", v.name.c_str()); return RON_ERR_STATE; }
+  RON_HIP_CHECK(hipSetDevice(c->cfg.device));
+  const int H = c->cfg.img_h, W = c->cfg.img_w;
+  auto T = [&](const std::string& n) { return c->tensor_index.at(n); };
+  double flops = 0;
+  int rc;
+#define PACK(expr) do { rc = (expr); if (rc < 0) return rc; } while (0)
+  // ---- VGG-16 body ----
+  {
+    Op o; o.kind = OP_IM2COL; o.name = "im2col"; o.out = T("im2col");
+    c->ops.push_back(o);
+  }
+  const int reps[5] = {2, 2, 3, 3, 3};
+  int h = H, w = W, prev = T("im2col");
+  for (int b = 0; b < 5; ++b) {
+    for (int r = 0; r < reps[b]; ++r) {
+      const std::string nm = "conv" + std::to_string(b + 1) + "_" + std::to_string(r + 1);
+      const std::string scope = "conv" + std::to_string(b + 1) + "/" + nm;
+      const bool stem = b == 0 && r == 0;
+      PACK(stem ? pack_stem(c, scope) : pack_plain(c, scope, false));
+      c->ops.push_back(conv_op(nm, prev, T(nm), rc, stem ? 1 : 3, stem ? 0 : 1, 1, h, w));
+      flops += conv_flops(c->var(scope + "/weights"), h * w);
+      prev = T(nm);
+    }
+    Op p; p.kind = OP_POOL; p.name = "pool" + std::to_string(b + 1); p.in = prev; p.out = T(p.name);
+    c->ops.push_back(p);
+    prev = p.out;
+    h /= 2; w /= 2;
+  }
+  // ---- fc6 / fc7 ----
+  PACK(pack_plain(c, "fc6", false));
+  {
+    Op o = c->cfg.variant == RON_VARIANT_FULL ? conv_op("fc6", prev, T("fc6"), rc, 7, 3, 1, h, w)
+                                               : conv_op("fc6", prev, T("fc6"), rc, 3, 3, 1, h, w);
+    if (c->cfg.variant != RON_VARIANT_FULL) o.dil = 3;
+    c->ops.push_back(o);
+    flops += conv_flops(c->var("fc6/weights"), h * w);
+  }
+  PACK(pack_plain(c, "fc7", false));
+  c->ops.push_back(conv_op("fc7", T("fc6"), T("fc7"), rc, 1, 0, 1, h, w));
+  flops += conv_flops(c->var("fc7/weights"), h * w);
+  // ---- reverse connections + heads, coarse -> fine ----
+  const char* left_src[4] = {"fc7", "fc6", "conv5_3", "conv4_3"};
+  for (int i = 0; i < 4; ++i) {
+    const std::string Ln = kFeatLayers[i];
+    const std::string L = "reverse_module/" + Ln + "_reverse";
+    const int sh = c->feat[i], sw = (W / 64) << i;
+    if (i == 0) {
+      PACK(pack_plain(c, L + "_conv_left", true));
+      Op o = conv_op(Ln + "_conv_left", T(left_src[i]), T(Ln + "_ref"), rc, 2, 0, 1, sh, sw);
+      o.stride = 2;
+      c->ops.push_back(o);
+    } else {
+      PACK(pack_deconv(c, L + "_deconv_right"));
+      Op d = conv_op(Ln + "_deconv_right", T(std::string(kFeatLayers[i - 1]) + "_ref"), T(Ln + "_up"), rc, 1, 0, 1, sh / 2, sw / 2);
+      d.up = 2; d.up_cout = 512;
+      c->ops.push_back(d);
+      flops += conv_flops(c->var(L + "_deconv_right/weights"), (sh / 2) * (sw / 2));
+      PACK(pack_plain(c, L + "_conv_left", true));
+      Op o = conv_op(Ln + "_conv_left", T(left_src[i]), T(Ln + "_ref"), rc, 3, 1, 1, sh, sw);
+      o.res = T(Ln + "_up");
+      c->ops.push_back(o);
+    }
+    flops += conv_flops(c->var(L + "_conv_left/weights"), sh * sw);
+    PACK(pack_trio(c, L));
+    c->ops.push_back(conv_op(Ln + "_trio", T(Ln + "_ref"), T(Ln + "_hcat"), rc, 3, 1, 1, sh, sw));
+    flops += conv_flops(c->var(L + "_objectness/weights"), sh * sw) + conv_flops(c->var(L + "/Conv2d_0_3x3/weights"), sh * sw) +
+             conv_flops(c->var(L + "_inception1/Branch_0/Conv2d_3x3/weights"), sh * sw) +
+             conv_flops(c->var(L + "_inception1/Branch_1/Conv2d_1x1/weights"), sh * sw);
+    PACK(pack_plain(c, L + "_objectness_score", false));
+    {
+      Op o = conv_op(Ln + "_objectness_score", T(Ln + "_hcat"), -2, rc, 3, 1, 0, sh, sw);
+      o.in_coff = 0; o.in_C = 512; o.head_kind = 1; o.head_layer = i;
+      c->ops.push_back(o);
+      flops += conv_flops(c->var(L + "_objectness_score/weights"), sh * sw);
+    }
+    PACK(pack_inception2(c, L));
+    {
+      Op o = conv_op(Ln + "_inception2", T(Ln + "_hcat"), T(Ln + "_inc2"), rc, 3, 1, 1, sh, sw);
+      o.in_coff = 512; o.in_C = 1024;
+      c->ops.push_back(o);
+      flops += conv_flops(c->var(L + "_inception2/Branch_0/Conv2d_3x3/weights"), sh * sw) +
+               conv_flops(c->var(L + "_inception2/Branch_1/Conv2d_1x1/weights"), sh * sw);
+    }
+    PACK(pack_plain(c, L + "_inception2/Conv2d_pred_3x3", false));
+    {
+      Op o = conv_op(Ln + "_cls_pred", T(Ln + "_inc2"), -2, rc, 3, 1, 0, sh, sw);
+      o.head_kind = 0; o.head_layer = i;
+      c->ops.push_back(o);
+      flops += conv_flops(c->var(L + "_inception2/Conv2d_pred_3x3/weights"), sh * sw);
+    }
+    PACK(pack_plain(c, L + "/Conv2d_1_3x3", false));
+    {
+      Op o = conv_op(Ln + "_loc_pred", T(Ln + "_hcat"), -2, rc, 3, 1, 0, sh, sw);
+      o.in_coff = 1536; o.in_C = 512; o.head_kind = 2; o.head_layer = i;
+      c->ops.push_back(o);
+      flops += conv_flops(c->var(L + "/Conv2d_1_3x3/weights"), sh * sw);
+    }
+  }
+#undef PACK
+  c->flops_per_image = flops;
+  for (auto& v : c->vars) { v.data.clear(); v.data.shrink_to_fit(); }
+  c->finalized = true;
+  return RON_OK;
+}
+
+extern "C" double ron_flops_per_image(const ron_ctx* c) { return c ? c->flops_per_image : -1.0; }
+
+extern "C" int ron_heads_describe(const ron_ctx* c, ron_heads* hd) {
+  RON_REQUIRE(c && hd, "NULL argument");
+  hd->num_layers = 4;
+  hd->num_classes = c->cfg.num_classes;
+  for (int i = 0; i < 4; ++i) {
+    hd->feat_h[i] = (c->cfg.img_h / 64) << i;
+    hd->feat_w[i] = (c->cfg.img_w / 64) << i;
+    hd->num_anchors[i] = c->num_anchors;
+    hd->anchor_y[i] = c->d_anchor[i][0]; hd->anchor_x[i] = c->d_anchor[i][1];
+    hd->anchor_h[i] = c->d_anchor[i][2]; hd->anchor_w[i] = c->d_anchor[i][3];
+  }
+  return RON_OK;
+}
+
+extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* out, void* stream) {
+  RON_REQUIRE(c && d_images && out, "NULL argument");
+  if (!c->finalized) { ron::set_error("ron_forward before ron_finalize_weights"); return RON_ERR_STATE; }
+  RON_REQUIRE(n >= 1 && n <= c->cfg.max_batch, "batch %d outside [1, max_batch=%d]", n, c->cfg.max_batch);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = ron_heads_describe(c, out);
+  if (rc) return rc;
+  const int A = c->num_anchors;
+  const int head_c[3] = {A * c->cfg.num_classes, 2 * A, 4 * A};
+  for (const Op& o : c->ops) {
+    if (o.kind == OP_IM2COL) {
+      const Tensor& t = c->tensors[o.out];
+      if ((rc = launch_im2col_c3(d_images, n, t.H, t.W, c->cfg.dtype, t.d, t.C, s))) return rc;
+    } else if (o.kind == OP_POOL) {
+      if ((rc = launch_maxpool2x2(c->view(o.in, n), c->view(o.out, n), c->cfg.dtype, s))) return rc;
+    } else {
+      const PackedConv& p = c->packed[o.packed];
+      ConvLaunch L;
+      L.dtype = c->cfg.dtype;
+      L.in = c->view(o.in, n, o.in_coff, o.in_C > 0 ? o.in_C : -1);
+      if (o.out == -2) {
+        const float* const* arr = o.head_kind == 0 ? out->cls : (o.head_kind == 1 ? out->obj : out->loc);
+        float* dst = const_cast<float*>(arr[o.head_layer]);
+        RON_REQUIRE(dst != nullptr, "ron_forward: head buffer (kind %d, layer %d) is NULL", o.head_kind, o.head_layer);
+        TensorView v;
+        v.base = dst; v.N = n; v.H = o.Ho; v.W = o.Wo; v.C = head_c[o.head_kind]; v.pad = 0; v.cstride = v.C; v.coff = 0;
+        v.bytes = (int64_t)n * v.H * v.W * v.C * 4;
+        L.out = v;
+        L.out_f32 = 1;
+      } else {
+        L.out = c->view(o.out, n);
+      }
+      L.res = o.res >= 0 ? c->tensors[o.res].d : nullptr;
+      L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.bias = p.d_bias; L.Cout = p.Cout; L.Npad = p.Npad;
+      L.kh = o.kh; L.kw = o.kw; L.stride = o.stride; L.dil = o.dil; L.cpad = o.cpad; L.relu = o.relu;
+      L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo;
+      if ((rc = launch_conv(L, s))) {
+        std::string msg = ron_last_error();
+        ron::set_error("%s: %s", o.name.c_str(), msg.c_str());
+        return rc;
+      }
+    }
+  }
+  return RON_OK;
+}
+
+extern "C" int ron_end_point_shape(const ron_ctx* c, const char* name, int n, int64_t nhwc[4]) {
+  RON_REQUIRE(c && name && nhwc, "NULL argument");
+  std::string key = name;
+  // end_points of the reference: block1..5 = last conv of the VGG block, block6 = fc6, block7 = fc7
+  static const std::map<std::string, std::string> alias = {{"block1", "conv1_2"}, {"block2", "conv2_2"}, {"block3", "conv3_3"},
+                                                           {"block4", "conv4_3"}, {"block5", "conv5_3"}, {"block6", "fc6"},
+                                                           {"block7", "fc7"}};
+  auto a = alias.find(key);
+  if (a != alias.end()) key = a->second;
+  auto it = c->tensor_index.find(key);
+  if (it == c->tensor_index.end()) { ron::set_error("unknown end point '%s'", name); return RON_ERR_UNKNOWN_NAME; }
+  const Tensor& t = c->tensors[it->second];
+  nhwc[0] = n; nhwc[1] = t.H; nhwc[2] = t.W; nhwc[3] = t.C;
+  return it->second + 1;     // > 0: tensor index + 1 (internal use), callers test for < 0
+}
+
+extern "C" int ron_end_point_copy(ron_ctx* c, const char* name, int n, float* d_out, void* stream) {
+  RON_REQUIRE(c && name && d_out, "NULL argument");
+  RON_REQUIRE(n >= 1 && n <= c->cfg.max_batch, "bad batch");
+  int64_t shp[4];
+  const int idx = ron_end_point_shape(c, name, n, shp);
+  if (idx < 0) return idx;
+  return launch_unpack(c->view(idx - 1, n), c->cfg.dtype, 0, d_out, (hipStream_t)stream);
+}
+
+extern "C" int ron_detect(ron_ctx* c, const float* d_images, int n, const ron_post_cfg* cfg, ron_detections* out, void* stream) {
+  RON_REQUIRE(c && cfg && out, "NULL argument");
+  RON_REQUIRE(n >= 1 && n <= c->cfg.max_batch, "batch %d outside [1, max_batch=%d]", n, c->cfg.max_batch);
+  const int A = c->num_anchors, mb = c->cfg.max_batch;
+  const int head_c[3] = {A * c->cfg.num_classes, 2 * A, 4 * A};
+  ron_heads hd;
+  memset(&hd, 0, sizeof(hd));
+  if (c->d_head[0][0] == nullptr) {          // first call: allocate ctx-owned head buffers + scratch
+    RON_HIP_CHECK(hipSetDevice(c->cfg.device));
+    for (int k = 0; k < 3; ++k)
+      for (int i = 0; i < 4; ++i) {
+        const int fh = (c->cfg.img_h / 64) << i, fw = (c->cfg.img_w / 64) << i;
+        RON_HIP_CHECK(hipMalloc((void**)&c->d_head[k][i], (size_t)mb * fh * fw * head_c[k] * sizeof(float)));
+      }
+  }
+  for (int i = 0; i < 4; ++i) { hd.cls[i] = c->d_head[0][i]; hd.obj[i] = c->d_head[1][i]; hd.loc[i] = c->d_head[2][i]; }
+  int rc = ron_forward(c, d_images, n, &hd, stream);
+  if (rc) return rc;
+  if (c->d_post_ws == nullptr) {
+    c->post_ws_bytes = ron_post_np_workspace_bytes(&hd, mb);
+    RON_HIP_CHECK(hipMalloc(&c->d_post_ws, (size_t)c->post_ws_bytes));
+  }
+  ron_post_cfg pc = *cfg;
+  pc.input_flags = 0;      // logits + raw offsets straight from the conv stack
+  return ron_post_np(&hd, n, &pc, c->d_post_ws, c->post_ws_bytes, out, nullptr, nullptr, stream);
+}

@@ -1,0 +1,137 @@
+// Single-operator entry points (ron_conv2d_nhwc, ron_maxpool2x2_nhwc): the same kernels the
+// graph launches, wrapped with dense-fp32 <-> halo-tensor conversion so that the parity tests
+// can pin each kernel against the oracle.  They allocate scratch and synchronise: test/tool use.
+#include <vector>
+
+#include "pack.h"
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(int64_t bytes, bool zero) {
+    RON_HIP_CHECK(hipMalloc(&p, (size_t)bytes));
+    if (zero) RON_HIP_CHECK(hipMemset(p, 0, (size_t)bytes));
+    return RON_OK;
+  }
+};
+
+ron::TensorView make_view(void* base, int n, int h, int w, int c, int pad, int esz) {
+  ron::TensorView v;
+  v.base = base; v.N = n; v.H = h; v.W = w; v.C = c; v.pad = pad; v.cstride = c; v.coff = 0;
+  v.bytes = (int64_t)n * (h + 2 * pad) * (w + 2 * pad) * c * esz;
+  return v;
+}
+
+}  // namespace
+
+extern "C" int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const float* w, const float* bias,
+                               const float* residual, float* y, void* stream) {
+  using namespace ron;
+  RON_REQUIRE(d && x && w && y, "NULL argument");
+  RON_REQUIRE(d->dtype >= 0 && d->dtype <= 2, "bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  const int esz = (int)dtype_size(d->dtype);
+  const int chunk = conv_k_chunk(d->dtype);
+  const bool is_c3 = (!d->transpose && d->cin == 3 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1);
+  RON_REQUIRE(is_c3 || d->cin % chunk == 0, "cin %d must be a multiple of %d (or the 3-channel 3x3 stem)", d->cin, chunk);
+  int ho, wo, cpad = 0;
+  ConvLaunch c;
+  c.dtype = d->dtype;
+  std::vector<float> rows;
+  std::vector<float> bias_pad;
+  int cout_gemm;
+  if (d->transpose) {
+    RON_REQUIRE(d->kh == d->kw && d->kh == d->stride && d->dilation == 1, "transposed conv needs kernel == stride");
+    ho = d->h * d->stride; wo = d->w * d->stride;
+    cout_gemm = d->kh * d->kw * d->cout;
+    const int BN = conv_n_tile(cout_gemm);
+    RON_REQUIRE(d->cout % BN == 0, "transposed conv: cout %d must be a multiple of %d", d->cout, BN);
+    c.Npad = cout_gemm;
+    // TF layout [kh,kw,cout,cin] -> rows[(t*cout + co)][ci]
+    rows.assign((size_t)cout_gemm * d->cin, 0.f);
+    memcpy(rows.data(), w, rows.size() * sizeof(float));
+    bias_pad.assign(cout_gemm, 0.f);
+    if (bias) for (int t = 0; t < d->kh * d->kw; ++t) for (int co = 0; co < d->cout; ++co) bias_pad[t * d->cout + co] = bias[co];
+    c.up = d->stride; c.up_cout = d->cout;
+    c.kh = c.kw = 1; c.stride = 1; c.dil = 1; c.cpad = 0;
+    c.Ho = d->h; c.Wo = d->w;
+  } else {
+    RON_REQUIRE(d->stride == 1 || (d->h % d->stride == 0 && d->w % d->stride == 0 && d->kh == d->stride),
+                "strided conv: only kernel == stride on divisible maps");
+    cpad = d->stride == 1 ? ((d->kh - 1) * d->dilation) / 2 : 0;   // SAME
+    ho = d->h / d->stride; wo = d->w / d->stride;
+    cout_gemm = d->cout;
+    const int BN = conv_n_tile(cout_gemm);
+    c.Npad = round_up(cout_gemm, BN);
+    if (is_c3) {
+      rows.assign((size_t)c.Npad * chunk, 0.f);
+      for (int k = 0; k < 27; ++k) for (int n = 0; n < d->cout; ++n) rows[(size_t)n * chunk + k] = w[(size_t)k * d->cout + n];
+      c.kh = c.kw = 1; c.cpad = 0;
+    } else {
+      hwio_to_rows(w, d->kh, d->kw, d->cin, d->cout, c.Npad, &rows);
+      c.kh = d->kh; c.kw = d->kw; c.cpad = cpad;
+    }
+    bias_pad.assign(c.Npad, 0.f);
+    if (bias) for (int n = 0; n < d->cout; ++n) bias_pad[n] = bias[n];
+    c.stride = d->stride; c.dil = d->dilation;
+    c.Ho = ho; c.Wo = wo;
+  }
+  c.Cout = cout_gemm;
+  c.relu = d->relu;
+  std::vector<uint8_t> wbytes = cast_rows(rows, d->dtype);
+
+  DevBuf d_w, d_b, d_in, d_out, d_res;
+  int rc;
+  if ((rc = d_w.alloc((int64_t)wbytes.size(), false))) return rc;
+  if ((rc = d_b.alloc((int64_t)bias_pad.size() * 4, false))) return rc;
+  RON_HIP_CHECK(hipMemcpy(d_w.p, wbytes.data(), wbytes.size(), hipMemcpyHostToDevice));
+  RON_HIP_CHECK(hipMemcpy(d_b.p, bias_pad.data(), bias_pad.size() * 4, hipMemcpyHostToDevice));
+  c.wgt = d_w.p; c.wgt_bytes = (int64_t)wbytes.size(); c.bias = (const float*)d_b.p;
+
+  if (is_c3) {
+    c.in = make_view(nullptr, d->n, d->h, d->w, chunk, 0, esz);
+    if ((rc = d_in.alloc(c.in.bytes, false))) return rc;
+    c.in.base = d_in.p;
+    if ((rc = launch_im2col_c3(x, d->n, d->h, d->w, d->dtype, d_in.p, chunk, s))) return rc;
+  } else {
+    c.in = make_view(nullptr, d->n, d->h, d->w, d->cin, cpad, esz);
+    if ((rc = d_in.alloc(c.in.bytes, true))) return rc;
+    c.in.base = d_in.p;
+    if ((rc = launch_pack_input(x, c.in, d->dtype, s))) return rc;
+  }
+  c.out = make_view(nullptr, d->n, ho, wo, d->cout, 1, esz);   // halo 1: exercises padded stores
+  if ((rc = d_out.alloc(c.out.bytes, true))) return rc;
+  c.out.base = d_out.p;
+  if (residual) {
+    TensorView rv = c.out;
+    if ((rc = d_res.alloc(rv.bytes, true))) return rc;
+    rv.base = d_res.p;
+    if ((rc = launch_pack_input(residual, rv, d->dtype, s))) return rc;
+    c.res = d_res.p;
+  }
+  if ((rc = launch_conv(c, s))) return rc;
+  if ((rc = launch_unpack(c.out, d->dtype, 0, y, s))) return rc;
+  RON_HIP_CHECK(hipStreamSynchronize(s));
+  return RON_OK;
+}
+
+extern "C" int ron_maxpool2x2_nhwc(const float* x, int n, int h, int w, int c, int dtype, float* y, void* stream) {
+  using namespace ron;
+  RON_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && h % 2 == 0 && w % 2 == 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int esz = (int)dtype_size(dtype);
+  TensorView vin = make_view(nullptr, n, h, w, c, 1, esz);
+  TensorView vout = make_view(nullptr, n, h / 2, w / 2, c, 3, esz);
+  DevBuf d_in, d_out;
+  int rc;
+  if ((rc = d_in.alloc(vin.bytes, true))) return rc;
+  if ((rc = d_out.alloc(vout.bytes, true))) return rc;
+  vin.base = d_in.p; vout.base = d_out.p;
+  if ((rc = launch_pack_input(x, vin, dtype, s))) return rc;
+  if ((rc = launch_maxpool2x2(vin, vout, dtype, s))) return rc;
+  if ((rc = launch_unpack(vout, dtype, 0, y, s))) return rc;
+  RON_HIP_CHECK(hipStreamSynchronize(s));
+  return RON_OK;
+}

@@ -1,0 +1,608 @@
+// Post-processing of the RON heads on gfx950: softmax + objectness gate + decode + select,
+// top-k, class-aware greedy NMS.  One pass over the head tensors (HBM-bound: 2.3 MB/image
+// read), then one workgroup per image for the order-dependent part (LDS sort, ballot-free
+// bitmask NMS).  Arithmetic that decides an index (IoU, decode, clip) is float32 with one
+// rounding per operation (-ffp-contract=off), i.e. what numpy computes for np_methods.py.
+//
+// Candidate identity: p = anchor_global * (C-1) + (class-1).  p grows exactly in the order
+// np.where() enumerates candidates in the reference (layers coarse->fine, anchor-major,
+// class-minor; np_methods.py:91-95,117-131), so the 64-bit key
+//        key = (float_bits(score) << 32) | (0xFFFFFFFF - p)
+// sorted descending reproduces "score descending, position ascending".
+#include "common.h"
+
+namespace {
+
+constexpr int kSelectThreads = 256;
+constexpr int kSortCap = 4096;     // keys sorted in LDS by one workgroup
+constexpr int kMaxTopK = RON_MAX_TOPK;
+constexpr int kTopkThreads = 1024;
+constexpr int kMaskWords = kMaxTopK / 64;
+
+typedef unsigned long long u64;
+
+struct HeadsDev {
+  int num_layers;
+  int num_classes;
+  int cells[RON_MAX_LAYERS];        // H*W
+  int num_anchors[RON_MAX_LAYERS];  // A
+  int anchor_base[RON_MAX_LAYERS + 1];   // prefix sum of cells*A
+  int block_base[RON_MAX_LAYERS + 1];    // prefix sum of ceil(cells*A / kSelectThreads)
+  const float* cls[RON_MAX_LAYERS];
+  const float* obj[RON_MAX_LAYERS];
+  const float* loc[RON_MAX_LAYERS];
+  const float* ay[RON_MAX_LAYERS];
+  const float* ax[RON_MAX_LAYERS];
+  const float* ah[RON_MAX_LAYERS];
+  const float* aw[RON_MAX_LAYERS];
+};
+
+struct PostDev {
+  float obj_thr, sel_thr, nms_thr;
+  int top_k;
+  float ref[4];
+  float ps[4];
+  unsigned flags;
+};
+
+struct DetDev {
+  int capacity;
+  int* classes;
+  float* scores;
+  float* bboxes;
+  int* anchor_index;
+  int* count;
+};
+
+__device__ __forceinline__ u64 make_key(float score, unsigned p) {
+  return ((u64)__float_as_uint(score) << 32) | (u64)(0xFFFFFFFFu - p);
+}
+
+// ------------------------------------------------------------------------------------------
+// K-select: one thread per anchor.  The block's class tensor chunk (256 anchors x C floats,
+// contiguous) is staged through LDS with coalesced loads; each thread then reads its C values
+// at stride C (C odd -> conflict free).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSelectThreads) void select_kernel(HeadsDev hd, PostDev pc, u64* keys,
+                                                                int* counts, int cap) {
+  extern __shared__ __attribute__((aligned(16))) float stage[];
+  const int img = blockIdx.y;
+  const int tid = threadIdx.x;
+  int layer = 0;
+#pragma unroll
+  for (int l = 1; l < RON_MAX_LAYERS; ++l)
+    if (l < hd.num_layers && (int)blockIdx.x >= hd.block_base[l]) layer = l;
+  const int C = hd.num_classes;
+  const int n_anchor_layer = hd.cells[layer] * hd.num_anchors[layer];
+  const int first = ((int)blockIdx.x - hd.block_base[layer]) * kSelectThreads;
+  const int n_here = min(kSelectThreads, n_anchor_layer - first);
+
+  const float* cls = hd.cls[layer] + ((size_t)img * n_anchor_layer + first) * C;
+  for (int i = tid; i < n_here * C; i += kSelectThreads) stage[i] = cls[i];
+  __syncthreads();
+
+  const bool active = tid < n_here;
+  const int local = first + tid;
+  bool gate = active;
+  if (active && hd.obj[layer] != nullptr) {
+    float objp;
+    if (pc.flags & RON_IN_OBJ_IS_PROB) {
+      objp = hd.obj[layer][(size_t)img * n_anchor_layer + local];
+    } else {
+      const float2 o = *reinterpret_cast<const float2*>(hd.obj[layer] + ((size_t)img * n_anchor_layer + local) * 2);
+      const float m = fmaxf(o.x, o.y);
+      const float e0 = expf(o.x - m), e1 = expf(o.y - m);
+      objp = e1 / (e0 + e1);
+    }
+    gate = objp > pc.obj_thr;   // eval_ron_network.py:227-229
+  }
+
+  // scores of this anchor (registers)
+  float inv_sum = 1.f, mx = 0.f;
+  const float* row = stage + tid * C;
+  const bool is_prob = (pc.flags & RON_IN_CLS_IS_PROB) != 0;
+  if (gate && !is_prob) {
+    mx = row[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(row[c] - mx);
+    inv_sum = s;
+  }
+  int n_sel = 0;
+  if (gate) {
+    for (int c = 1; c < C; ++c) {
+      const float sc = is_prob ? row[c] : expf(row[c] - mx) / inv_sum;
+      n_sel += (sc > pc.sel_thr) ? 1 : 0;
+    }
+  }
+  // wave-aggregated reservation of output slots
+  const int lane = tid & 63;
+  int incl = n_sel;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  const int wave_total = __shfl(incl, 63, 64);
+  int base = 0;
+  if (lane == 63 && wave_total > 0) base = atomicAdd(&counts[img], wave_total);
+  base = __shfl(base, 63, 64);
+  if (n_sel > 0) {
+    int pos = base + incl - n_sel;
+    const unsigned p0 = (unsigned)(hd.anchor_base[layer] + local) * (unsigned)(C - 1);
+    u64* out = keys + (size_t)img * cap;
+    for (int c = 1; c < C; ++c) {
+      const float sc = is_prob ? row[c] : expf(row[c] - mx) / inv_sum;
+      if (sc > pc.sel_thr) {
+        if (pos < cap) out[pos] = make_key(sc, p0 + (unsigned)(c - 1));
+        ++pos;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Shared pieces of the per-image workgroup.
+// ------------------------------------------------------------------------------------------
+struct ImageLds {
+  u64 sort[kSortCap];              // keys; reused as the NMS suppression bit matrix
+  float box[kMaxTopK][4];
+  float score[kMaxTopK];
+  int cls[kMaxTopK];
+  int anchor[kMaxTopK];
+  unsigned hist[256];
+  int scalars[8];
+};
+
+__device__ void bitonic_sort_desc(u64* s, int n2, int tid, int nthreads) {
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n2; i += nthreads) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const u64 a = s[i], b = s[ixj];
+          const bool desc_block = (i & k) == 0;
+          if (desc_block ? (a < b) : (a > b)) {
+            s[i] = b;
+            s[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Puts the top_k largest keys of keys[0..m) (unique keys) sorted descending at lds.sort[0..).
+// Returns number of valid keys (min(m, top_k)).
+__device__ int topk_keys(const u64* __restrict__ keys, int m, int top_k, ImageLds& lds) {
+  const int tid = threadIdx.x;
+  const int nth = blockDim.x;
+  int n_sel;
+  if (m <= kSortCap) {
+    for (int i = tid; i < m; i += nth) lds.sort[i] = keys[i];
+    n_sel = m;
+    __syncthreads();
+  } else {
+    // radix select from the most significant byte down until the survivors fit in LDS
+    u64 prefix = 0, mask = 0;
+    int need = top_k, above_total = 0;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      for (int i = tid; i < 256; i += nth) lds.hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < m; i += nth) {
+        const u64 k = keys[i];
+        if ((k & mask) == prefix) atomicAdd(&lds.hist[(unsigned)(k >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int cum = 0, bin = 0;
+        for (int b = 255; b >= 0; --b) {
+          const int c = (int)lds.hist[b];
+          if (cum + c >= need) { bin = b; break; }
+          cum += c;
+        }
+        lds.scalars[0] = bin;
+        lds.scalars[1] = cum;
+        lds.scalars[2] = (int)lds.hist[bin];
+      }
+      __syncthreads();
+      const int bin = lds.scalars[0], cum = lds.scalars[1], bin_count = lds.scalars[2];
+      __syncthreads();
+      above_total += cum;
+      need -= cum;
+      prefix |= (u64)bin << shift;
+      mask |= (u64)0xFF << shift;
+      if (above_total + bin_count <= kSortCap) break;
+    }
+    if (tid == 0) lds.scalars[3] = 0;
+    __syncthreads();
+    for (int i = tid; i < m; i += nth) {
+      const u64 k = keys[i];
+      if ((k & mask) >= prefix) {
+        const int pos = atomicAdd(&lds.scalars[3], 1);
+        if (pos < kSortCap) lds.sort[pos] = k;
+      }
+    }
+    __syncthreads();
+    n_sel = min(lds.scalars[3], kSortCap);
+  }
+  int n2 = 64;
+  while (n2 < n_sel) n2 <<= 1;
+  for (int i = n_sel + tid; i < n2; i += nth) lds.sort[i] = 0;
+  __syncthreads();
+  bitonic_sort_desc(lds.sort, n2, tid, nth);
+  return min(n_sel, top_k);
+}
+
+__device__ __forceinline__ bool nms_suppresses(const float* bi, const float* bj, float thr) {
+  // np_methods.py:186-205 (bboxes_jaccard), float32, one rounding per operation
+  const float ih = fmaxf(fminf(bi[2], bj[2]) - fmaxf(bi[0], bj[0]), 0.f);
+  const float iw = fmaxf(fminf(bi[3], bj[3]) - fmaxf(bi[1], bj[1]), 0.f);
+  const float inter = ih * iw;
+  const float vol1 = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+  const float vol2 = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+  const float iou = inter / (vol1 + vol2 - inter);
+  return !(iou < thr);   // NaN suppresses, as logical_or(overlap < thr, ...) does
+}
+
+// Greedy scan over the n sorted boxes in lds (np_methods.py:229-242).  Writes kept rows,
+// compacted, to `out` (image `img`), after the resize by `ref` when do_resize.
+__device__ void nms_and_store(ImageLds& lds, int n, float nms_thr, const float* ref, bool do_resize,
+                              const DetDev& out, int img) {
+  const int tid = threadIdx.x;
+  const int nth = blockDim.x;
+  const int words = (n + 63) >> 6;
+  u64* mask = lds.sort;    // [n][kMaskWords]
+  for (int idx = tid; idx < n * words; idx += nth) {
+    const int i = idx / words, w = idx - i * words;
+    u64 bits = 0;
+    const int j0 = w << 6;
+    const int j1 = min(n, j0 + 64);
+    const int ci = lds.cls[i];
+    for (int j = max(j0, i + 1); j < j1; ++j) {
+      if (lds.cls[j] == ci && nms_suppresses(lds.box[i], lds.box[j], nms_thr)) bits |= 1ull << (j - j0);
+    }
+    mask[i * kMaskWords + w] = bits;
+  }
+  __syncthreads();
+  // serial part: one wave, lane w owns word w of the "removed" set
+  if (tid < 64) {
+    const int lane = tid;
+    u64 removed = 0;
+    u64 keep_bits = 0;     // lane w: kept rows of word w
+    for (int i = 0; i < n; ++i) {
+      const int wi = i >> 6;
+      const u64 rw = __shfl(removed, wi, 64);
+      const bool kept = ((rw >> (i & 63)) & 1ull) == 0;
+      if (kept) {
+        if (lane < words) removed |= mask[i * kMaskWords + lane];
+        if (lane == wi) keep_bits |= 1ull << (i & 63);
+      }
+    }
+    // exclusive prefix of kept counts per word
+    int cnt = (lane < words) ? __popcll(keep_bits) : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    if (lane < kMaskWords) {
+      // stash keep bits + exclusive offsets behind the mask rows actually used
+      lds.hist[lane] = (unsigned)(keep_bits & 0xFFFFFFFFull);
+      lds.hist[16 + lane] = (unsigned)(keep_bits >> 32);
+      lds.hist[32 + lane] = (unsigned)(incl - cnt);
+    }
+    if (lane == 63) lds.scalars[4] = incl;
+  }
+  __syncthreads();
+  const int total = lds.scalars[4];
+  const float sy = ref[2] - ref[0], sx = ref[3] - ref[1];
+  for (int i = tid; i < out.capacity; i += nth) {
+    // zero rows at and after `total` (records are fixed-capacity, zero padded)
+    if (i >= total) {
+      const size_t o = (size_t)img * out.capacity + i;
+      out.classes[o] = 0;
+      out.scores[o] = 0.f;
+      out.anchor_index[o] = 0;
+      out.bboxes[o * 4 + 0] = 0.f; out.bboxes[o * 4 + 1] = 0.f;
+      out.bboxes[o * 4 + 2] = 0.f; out.bboxes[o * 4 + 3] = 0.f;
+    }
+  }
+  for (int i = tid; i < n; i += nth) {
+    const int w = i >> 6, b = i & 63;
+    const u64 kb = ((u64)lds.hist[16 + w] << 32) | (u64)lds.hist[w];
+    if ((kb >> b) & 1ull) {
+      const int pos = (int)lds.hist[32 + w] + __popcll(kb & ((1ull << b) - 1ull));
+      if (pos < out.capacity) {
+        const size_t o = (size_t)img * out.capacity + pos;
+        out.classes[o] = lds.cls[i];
+        out.scores[o] = lds.score[i];
+        out.anchor_index[o] = lds.anchor[i];
+        float b0 = lds.box[i][0], b1 = lds.box[i][1], b2 = lds.box[i][2], b3 = lds.box[i][3];
+        if (do_resize) {   // np_methods.py:167-183
+          b0 = (b0 - ref[0]) / sy; b1 = (b1 - ref[1]) / sx;
+          b2 = (b2 - ref[0]) / sy; b3 = (b3 - ref[1]) / sx;
+        }
+        out.bboxes[o * 4 + 0] = b0; out.bboxes[o * 4 + 1] = b1;
+        out.bboxes[o * 4 + 2] = b2; out.bboxes[o * 4 + 3] = b3;
+      }
+    }
+  }
+  if (tid == 0) out.count[img] = min(total, out.capacity);
+}
+
+__device__ void store_sorted(const ImageLds& lds, int n, const DetDev& out, int img) {
+  for (int i = threadIdx.x; i < out.capacity; i += blockDim.x) {
+    const size_t o = (size_t)img * out.capacity + i;
+    const bool v = i < n;
+    out.classes[o] = v ? lds.cls[i] : 0;
+    out.scores[o] = v ? lds.score[i] : 0.f;
+    out.anchor_index[o] = v ? lds.anchor[i] : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out.bboxes[o * 4 + k] = v ? lds.box[i][k] : 0.f;
+  }
+  if (threadIdx.x == 0) out.count[img] = min(n, out.capacity);
+}
+
+__device__ __forceinline__ void decode_box(const float* l, float ya, float xa, float ha, float wa,
+                                           const float* ps, float* box) {
+  // np_methods.py:41-50 (== ssd_common.py:464-472)
+  const float cx = l[0] * wa * ps[0] + xa;
+  const float cy = l[1] * ha * ps[1] + ya;
+  const float w = wa * expf(l[2] * ps[2]);
+  const float h = ha * expf(l[3] * ps[3]);
+  box[0] = cy - h / 2.f;
+  box[1] = cx - w / 2.f;
+  box[2] = cy + h / 2.f;
+  box[3] = cx + w / 2.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// K-topk-nms: one workgroup per image.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTopkThreads) void topk_nms_kernel(HeadsDev hd, PostDev pc, const u64* keys,
+                                                                const int* counts, int cap, DetDev out,
+                                                                DetDev sorted_out, int* n_candidates) {
+  __shared__ ImageLds lds;
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int m_raw = counts[img];
+  if (tid == 0 && n_candidates != nullptr) n_candidates[img] = m_raw;
+  const int m = min(m_raw, cap);
+  const int n = topk_keys(keys + (size_t)img * cap, m, pc.top_k, lds);
+  // keys -> records.  Each thread keeps its key in a register before the LDS region is reused.
+  const int C1 = hd.num_classes - 1;
+  for (int r = tid; r < n; r += blockDim.x) {
+    const u64 k = lds.sort[r];
+    const float score = __uint_as_float((unsigned)(k >> 32));
+    const unsigned p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+    const int anchor = (int)(p / (unsigned)C1);
+    const int cls = (int)(p - (unsigned)anchor * (unsigned)C1) + 1;
+    int layer = 0;
+#pragma unroll
+    for (int l = 1; l < RON_MAX_LAYERS; ++l)
+      if (l < hd.num_layers && anchor >= hd.anchor_base[l]) layer = l;
+    const int local = anchor - hd.anchor_base[layer];
+    const int A = hd.num_anchors[layer];
+    const int cell = local / A, a = local - cell * A;
+    const size_t n_anchor_layer = (size_t)hd.cells[layer] * A;
+    const float* l4 = hd.loc[layer] + ((size_t)img * n_anchor_layer + local) * 4;
+    float box[4];
+    if (pc.flags & RON_IN_LOC_DECODED) {
+      box[0] = l4[0]; box[1] = l4[1]; box[2] = l4[2]; box[3] = l4[3];
+    } else {
+      decode_box(l4, hd.ay[layer][cell], hd.ax[layer][cell], hd.ah[layer][a], hd.aw[layer][a], pc.ps, box);
+    }
+    // np_methods.py:153-164 (clip: no ymin<=ymax repair)
+    lds.box[r][0] = fmaxf(box[0], pc.ref[0]);
+    lds.box[r][1] = fmaxf(box[1], pc.ref[1]);
+    lds.box[r][2] = fminf(box[2], pc.ref[2]);
+    lds.box[r][3] = fminf(box[3], pc.ref[3]);
+    lds.score[r] = score;
+    lds.cls[r] = cls;
+    lds.anchor[r] = anchor;
+  }
+  __syncthreads();
+  if (sorted_out.classes != nullptr) store_sorted(lds, n, sorted_out, img);
+  nms_and_store(lds, n, pc.nms_thr, pc.ref, true, out, img);
+}
+
+// Explicit lists (np_methods.bboxes_sort -> bboxes_nms), one workgroup per image.
+__global__ __launch_bounds__(kTopkThreads) void list_sort_nms_kernel(const int* classes, const float* scores,
+                                                                     const float* bboxes, const int* n_valid,
+                                                                     int n_in, int top_k, float nms_thr,
+                                                                     u64* keys, DetDev out, DetDev sorted_out) {
+  __shared__ ImageLds lds;
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int m = n_valid ? min(n_valid[img], n_in) : n_in;
+  u64* my_keys = keys + (size_t)img * n_in;
+  for (int i = tid; i < m; i += blockDim.x) my_keys[i] = make_key(scores[(size_t)img * n_in + i], (unsigned)i);
+  __threadfence_block();
+  __syncthreads();
+  const int n = topk_keys(my_keys, m, top_k, lds);
+  for (int r = tid; r < n; r += blockDim.x) {
+    const u64 k = lds.sort[r];
+    const unsigned p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+    const size_t src = (size_t)img * n_in + p;
+    lds.score[r] = scores[src];
+    lds.cls[r] = classes[src];
+    lds.anchor[r] = (int)p;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lds.box[r][q] = bboxes[src * 4 + q];
+  }
+  __syncthreads();
+  if (sorted_out.classes != nullptr) store_sorted(lds, n, sorted_out, img);
+  const float ref[4] = {0.f, 0.f, 1.f, 1.f};
+  nms_and_store(lds, n, nms_thr, ref, false, out, img);
+}
+
+__global__ void decode_layer_kernel(const float* loc, int n, int cells, int A, const float* ay, const float* ax,
+                                    const float* ah, const float* aw, float ps0, float ps1, float ps2, float ps3,
+                                    float* out) {
+  const size_t total = (size_t)n * cells * A;
+  const float ps[4] = {ps0, ps1, ps2, ps3};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int a = (int)(i % A);
+    const int cell = (int)((i / A) % cells);
+    const float4 l = reinterpret_cast<const float4*>(loc)[i];
+    const float l4[4] = {l.x, l.y, l.z, l.w};
+    float box[4];
+    decode_box(l4, ay[cell], ax[cell], ah[a], aw[a], ps, box);
+    reinterpret_cast<float4*>(out)[i] = make_float4(box[0], box[1], box[2], box[3]);
+  }
+}
+
+__global__ void softmax_last_kernel(const float* x, long long rows, int c, int pick, float* y) {
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows;
+       r += (long long)gridDim.x * blockDim.x) {
+    const float* in = x + r * c;
+    float m = in[0];
+    for (int i = 1; i < c; ++i) m = fmaxf(m, in[i]);
+    float s = 0.f;
+    for (int i = 0; i < c; ++i) s += expf(in[i] - m);
+    if (pick >= 0) {
+      y[r] = expf(in[pick] - m) / s;
+    } else {
+      for (int i = 0; i < c; ++i) y[r * c + i] = expf(in[i] - m) / s;
+    }
+  }
+}
+
+int build_heads_dev(const ron_heads* h, HeadsDev* d, bool need_anchors) {
+  RON_REQUIRE(h != nullptr, "heads is NULL");
+  RON_REQUIRE(h->num_layers >= 1 && h->num_layers <= RON_MAX_LAYERS, "num_layers %d out of range", h->num_layers);
+  RON_REQUIRE(h->num_classes >= 2 && h->num_classes <= 64, "num_classes %d out of range", h->num_classes);
+  d->num_layers = h->num_layers;
+  d->num_classes = h->num_classes;
+  d->anchor_base[0] = 0;
+  d->block_base[0] = 0;
+  for (int l = 0; l < RON_MAX_LAYERS; ++l) {
+    if (l < h->num_layers) {
+      RON_REQUIRE(h->feat_h[l] > 0 && h->feat_w[l] > 0 && h->num_anchors[l] > 0 &&
+                      h->num_anchors[l] <= RON_MAX_ANCHORS_PER_CELL,
+                  "layer %d: bad shape", l);
+      RON_REQUIRE(h->cls[l] != nullptr && h->loc[l] != nullptr, "layer %d: cls/loc pointer is NULL", l);
+      if (need_anchors)
+        RON_REQUIRE(h->anchor_y[l] && h->anchor_x[l] && h->anchor_h[l] && h->anchor_w[l],
+                    "layer %d: anchors are required when loc holds raw offsets", l);
+      d->cells[l] = h->feat_h[l] * h->feat_w[l];
+      d->num_anchors[l] = h->num_anchors[l];
+      const int na = d->cells[l] * d->num_anchors[l];
+      d->anchor_base[l + 1] = d->anchor_base[l] + na;
+      d->block_base[l + 1] = d->block_base[l] + (na + kSelectThreads - 1) / kSelectThreads;
+      d->cls[l] = h->cls[l]; d->obj[l] = h->obj[l]; d->loc[l] = h->loc[l];
+      d->ay[l] = h->anchor_y[l]; d->ax[l] = h->anchor_x[l]; d->ah[l] = h->anchor_h[l]; d->aw[l] = h->anchor_w[l];
+    } else {
+      d->cells[l] = 0; d->num_anchors[l] = 0;
+      d->anchor_base[l + 1] = d->anchor_base[l];
+      d->block_base[l + 1] = d->block_base[l];
+      d->cls[l] = d->obj[l] = d->loc[l] = d->ay[l] = d->ax[l] = d->ah[l] = d->aw[l] = nullptr;
+    }
+  }
+  return RON_OK;
+}
+
+int to_det_dev(const ron_detections* d, DetDev* out, int top_k, const char* what, bool optional) {
+  if (d == nullptr || d->classes == nullptr) {
+    if (!optional) { ron::set_error("%s is NULL", what); return RON_ERR_INVALID; }
+    *out = DetDev{0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return RON_OK;
+  }
+  RON_REQUIRE(d->capacity >= top_k, "%s: capacity %d < top_k %d", what, d->capacity, top_k);
+  RON_REQUIRE(d->scores && d->bboxes && d->anchor_index && d->count, "%s: NULL member", what);
+  *out = DetDev{d->capacity, d->classes, d->scores, d->bboxes, d->anchor_index, d->count};
+  return RON_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t ron_post_np_workspace_bytes(const ron_heads* heads, int n) {
+  HeadsDev hd;
+  if (build_heads_dev(heads, &hd, false) != RON_OK || n <= 0) return -1;
+  const int64_t cap = (int64_t)hd.anchor_base[RON_MAX_LAYERS] * (heads->num_classes - 1);
+  return ron::align_up((int64_t)n * 4, 256) + (int64_t)n * cap * 8;
+}
+
+extern "C" int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cfg, void* workspace,
+                           int64_t workspace_bytes, ron_detections* out, ron_detections* sorted_out,
+                           int32_t* n_candidates, void* stream) {
+  RON_REQUIRE(cfg != nullptr && n > 0, "bad cfg / n");
+  RON_REQUIRE(cfg->top_k >= 1 && cfg->top_k <= kMaxTopK, "top_k %d not in [1, %d]", cfg->top_k, kMaxTopK);
+  RON_REQUIRE(cfg->select_threshold > 0.f,
+              "select_threshold must be > 0 (the argmax branch of np_methods.py:82-89 is not on this path)");
+  HeadsDev hd;
+  int rc = build_heads_dev(heads, &hd, (cfg->input_flags & RON_IN_LOC_DECODED) == 0);
+  if (rc != RON_OK) return rc;
+  const int64_t need = ron_post_np_workspace_bytes(heads, n);
+  RON_REQUIRE(workspace != nullptr && workspace_bytes >= need, "workspace too small: %lld < %lld",
+              (long long)workspace_bytes, (long long)need);
+  DetDev d_out, d_sorted;
+  if ((rc = to_det_dev(out, &d_out, cfg->top_k, "out", false)) != RON_OK) return rc;
+  if ((rc = to_det_dev(sorted_out, &d_sorted, cfg->top_k, "sorted_out", true)) != RON_OK) return rc;
+  PostDev pc;
+  pc.obj_thr = cfg->objectness_thres; pc.sel_thr = cfg->select_threshold; pc.nms_thr = cfg->nms_threshold;
+  pc.top_k = cfg->top_k; pc.flags = cfg->input_flags;
+  for (int i = 0; i < 4; ++i) { pc.ref[i] = cfg->bbox_img[i]; pc.ps[i] = cfg->prior_scaling[i]; }
+  hipStream_t s = (hipStream_t)stream;
+  int* counts = (int*)workspace;
+  u64* keys = (u64*)((char*)workspace + ron::align_up((int64_t)n * 4, 256));
+  const int cap = hd.anchor_base[RON_MAX_LAYERS] * (hd.num_classes - 1);
+  RON_HIP_CHECK(hipMemsetAsync(counts, 0, ron::align_up((int64_t)n * 4, 256), s));
+  dim3 grid(hd.block_base[RON_MAX_LAYERS], n);
+  const size_t lds = (size_t)kSelectThreads * hd.num_classes * sizeof(float);
+  hipLaunchKernelGGL(select_kernel, grid, dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
+  hipLaunchKernelGGL(topk_nms_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, d_out,
+                     d_sorted, n_candidates);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+extern "C" int64_t ron_np_sort_nms_workspace_bytes(int n, int n_in) {
+  if (n <= 0 || n_in < 0) return -1;
+  return (int64_t)n * (n_in > 0 ? n_in : 1) * 8;
+}
+
+extern "C" int ron_np_sort_nms(const int32_t* classes, const float* scores, const float* bboxes,
+                               const int32_t* n_valid, int n, int n_in, int top_k, float nms_threshold,
+                               void* workspace, int64_t workspace_bytes, ron_detections* out,
+                               ron_detections* sorted_out, void* stream) {
+  RON_REQUIRE(n > 0 && n_in >= 0, "bad n / n_in");
+  RON_REQUIRE(top_k >= 1 && top_k <= kMaxTopK, "top_k %d not in [1, %d]", top_k, kMaxTopK);
+  RON_REQUIRE(n_in == 0 || (classes && scores && bboxes), "NULL input list");
+  RON_REQUIRE(workspace != nullptr && workspace_bytes >= ron_np_sort_nms_workspace_bytes(n, n_in), "workspace too small");
+  DetDev d_out, d_sorted;
+  int rc;
+  if ((rc = to_det_dev(out, &d_out, top_k, "out", false)) != RON_OK) return rc;
+  if ((rc = to_det_dev(sorted_out, &d_sorted, top_k, "sorted_out", true)) != RON_OK) return rc;
+  hipLaunchKernelGGL(list_sort_nms_kernel, dim3(n), dim3(kTopkThreads), 0, (hipStream_t)stream, classes, scores,
+                     bboxes, n_valid, n_in, top_k, nms_threshold, (u64*)workspace, d_out, d_sorted);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+extern "C" int ron_bboxes_decode_layer(const float* loc, int n, int feat_h, int feat_w, int num_anchors,
+                                       const float* anchor_y, const float* anchor_x, const float* anchor_h,
+                                       const float* anchor_w, const float prior_scaling[4], float* out,
+                                       void* stream) {
+  RON_REQUIRE(loc && out && anchor_y && anchor_x && anchor_h && anchor_w && prior_scaling, "NULL argument");
+  RON_REQUIRE(n > 0 && feat_h > 0 && feat_w > 0 && num_anchors > 0, "bad shape");
+  const size_t total = (size_t)n * feat_h * feat_w * num_anchors;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(decode_layer_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, loc, n, feat_h * feat_w,
+                     num_anchors, anchor_y, anchor_x, anchor_h, anchor_w, prior_scaling[0], prior_scaling[1],
+                     prior_scaling[2], prior_scaling[3], out);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+extern "C" int ron_softmax_last(const float* x, int64_t rows, int c, int pick, float* y, void* stream) {
+  RON_REQUIRE(x && y && rows > 0 && c > 0 && pick < c, "bad argument");
+  const int blocks = (int)std::min<int64_t>((rows + 255) / 256, 4096);
+  hipLaunchKernelGGL(softmax_last_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, c,
+                     pick, y);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}

@@ -1,0 +1,116 @@
+"""GPU parity: implicit-GEMM conv / transposed conv / max-pool kernels vs the oracle's numpy ops.
+
+fp32 mode: exact-fp32 MFMA, tolerance 2e-5 relative to the output scale.  bf16/f16 modes: the oracle
+gets the same operand rounding (inputs and weights rounded to the storage type, fp32 accumulate) and
+the comparison allows one storage-type rounding of the output."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import ron_forward as orf  # noqa: E402
+
+ROUND = {'fp32': lambda a: np.asarray(a, np.float32), 'bf16': orf.round_bf16, 'fp16': orf.round_f16}
+OUT_EPS = {'fp32': 2e-5, 'bf16': 2 ** -7, 'fp16': 2 ** -10}
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from ron_tensorflow_amd import ops as _ops
+    return _ops
+
+
+def _check(got, ref, dtype):
+    scale = float(np.abs(ref).max()) + 1e-6
+    err = np.abs(got - ref).max() / scale
+    assert err <= OUT_EPS[dtype] * 1.5, 'max err / scale = %g' % err
+
+
+CONV_SHAPES = [
+    # n, h, w, cin, cout, k, stride, rate
+    (2, 12, 10, 64, 64, 3, 1, 1),       # N tile 64
+    (1, 9, 7, 128, 128, 3, 1, 1),       # N tile 128, ragged M
+    (3, 10, 10, 64, 20, 3, 1, 1),       # objectness_score-like: Cout 20 -> padded rows masked
+    (1, 10, 10, 128, 210, 3, 1, 1),     # cls pred
+    (2, 10, 10, 192, 256, 1, 1, 1),     # 1x1
+    (2, 10, 10, 64, 128, 3, 1, 3),      # fc6 reduced: rate 3
+    (1, 10, 10, 64, 128, 7, 1, 1),      # fc6 full: 7x7
+    (2, 10, 10, 128, 128, 2, 2, 1),     # block7 conv_left: 2x2 stride 2
+    (1, 40, 40, 64, 64, 3, 1, 1),       # many tiles
+]
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('shape', CONV_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_conv2d(ops, dev, shape, dtype):
+    n, h, w, cin, cout, k, stride, rate = shape
+    rs = np.random.RandomState(hash(shape) % 1000)
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    b = (rs.randn(cout) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt), stride, rate) + b, 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, stride=stride, dilation=rate, relu=True,
+                          dtype=dtype).cpu().numpy()
+    assert got.shape == ref.shape
+    _check(got, ref, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_conv2d_no_relu_no_bias_and_residual(ops, dev, dtype):
+    rs = np.random.RandomState(5)
+    x = rs.randn(2, 10, 10, 128).astype(np.float32)
+    wt = (rs.randn(3, 3, 128, 128) * 0.03).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = orf.conv2d_np(rnd(x), rnd(wt))
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, None, relu=False, dtype=dtype).cpu().numpy()
+    assert (got < 0).any()
+    _check(got, ref, dtype)
+    # reverse-connection sum: relu(relu(conv + b) + residual)   (nets/ron_vgg_320.py:422-425)
+    res = np.maximum(rs.randn(2, 10, 10, 128), 0).astype(np.float32)
+    b = (rs.randn(128) * 0.1).astype(np.float32)
+    ref = np.maximum(np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0) + rnd(res), 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, residual=torch.from_numpy(res).to(dev), relu=True,
+                          dtype=dtype).cpu().numpy()
+    _check(got, ref, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
+def test_conv2d_transpose_2x2(ops, dev, dtype):
+    rs = np.random.RandomState(6)
+    x = rs.randn(2, 5, 5, 128).astype(np.float32)
+    wt = (rs.randn(2, 2, 128, 128) * 0.08).astype(np.float32)       # [kh, kw, Cout, Cin]
+    b = (rs.randn(128) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(orf.conv2d_transpose_np(rnd(x), rnd(wt), 2) + b, 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, stride=2, relu=True, transpose=True,
+                          dtype=dtype).cpu().numpy()
+    assert got.shape == (2, 10, 10, 128)
+    _check(got, ref, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_conv_stem_3_channels(ops, dev, dtype):
+    rs = np.random.RandomState(7)
+    x = (rs.uniform(0, 255, (2, 16, 20, 3)) - np.array([123., 117., 104.])).astype(np.float32)
+    wt = (rs.randn(3, 3, 3, 64) * np.sqrt(2.0 / 27)).astype(np.float32)
+    b = (rs.randn(64) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype).cpu().numpy()
+    _check(got, ref, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
+def test_maxpool(ops, dev, dtype):
+    rs = np.random.RandomState(8)
+    x = ROUND[dtype](rs.randn(2, 8, 12, 64).astype(np.float32))
+    got = ops.maxpool2x2_nhwc(torch.from_numpy(x).to(dev), dtype=dtype).cpu().numpy()
+    assert np.array_equal(got, orf.max_pool2x2_np(x))
