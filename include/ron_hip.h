@@ -223,10 +223,23 @@ int ron_detect(ron_ctx* ctx, const float* d_images, int n, const ron_post_cfg* c
 /* Algorithmic work of one image through the conv stack (2*MAC of conv + deconv). */
 double ron_flops_per_image(const ron_ctx* ctx);
 
+/* Per-launch timing with HIP events on the caller's stream (what bench.py's roofline uses; the reference's
+ * only timing is wall-clock prints, eval_ron_network.py:353,363-366).  While enabled, ron_forward /
+ * ron_detect bracket every launch with an event; ron_profile_get synchronises on the recorded events and
+ * returns, for launch i (the last index is the post-processing stage of ron_detect), its name, whether it is
+ * the implicit-GEMM conv kernel, its algorithmic FLOPs per image, the accumulated time and launch count. */
+int ron_profile_enable(ron_ctx* ctx, int enable);
+int ron_profile_num_ops(const ron_ctx* ctx);
+int ron_profile_get(ron_ctx* ctx, int i, const char** name, int* is_conv, double* flops_per_image,
+                    double* total_ms, int* launches);
+int ron_profile_reset(ron_ctx* ctx);
+
 /* ------------------------------------------------------------------------------------------
  * Single operators (used by the parity tests to pin each kernel against the oracle).
- * conv2d NHWC: x [n,h,w,cin] fp32, w HWIO fp32 [kh,kw,cin,cout], bias [cout] or NULL,
- * residual [n,ho,wo,cout] or NULL: y = act(conv + bias) ; if residual: y = relu(y + residual).
+ * conv2d NHWC: x [n,h,w,cin] fp32 (device), w HWIO fp32 [kh,kw,cin,cout] and bias [cout] or NULL (HOST
+ * pointers: they are packed on the host like ron_finalize_weights does), residual [n,ho,wo,cout] (device)
+ * or NULL: y = act(conv + bias) ; if residual: y = relu(y + residual).  These two calls allocate scratch
+ * and synchronise the stream (test / tooling use, not for graph capture).
  * `dtype` selects the arithmetic (operands rounded to bf16/f16, fp32 accumulate).
  * transpose != 0: slim.conv2d_transpose with kernel = stride (weights [kh,kw,cout,cin]).
  * ---------------------------------------------------------------------------------------- */

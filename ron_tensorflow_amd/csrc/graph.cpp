@@ -65,6 +65,12 @@ struct Op {
   int up = 0, up_cout = 0;
   int head_kind = -1, head_layer = -1;  // 0 cls, 1 obj, 2 loc
   int Ho = 0, Wo = 0;
+  double flops = 0;                     // algorithmic 2*MAC per image of this launch
+};
+
+struct OpTiming {
+  double ms = 0;
+  int launches = 0;
 };
 
 }  // namespace
@@ -87,6 +93,11 @@ struct ron_ctx {
   float* d_head[3][4] = {};
   void* d_post_ws = nullptr;
   int64_t post_ws_bytes = 0;
+  // optional per-launch timing (ron_profile_*): event pairs recorded on the caller's stream
+  bool profiling = false;
+  std::vector<OpTiming> timing;                       // ops.size() + 1 (last = post-processing)
+  std::vector<std::vector<hipEvent_t>> pending;       // per recorded call: 2 events per op (+2 for post)
+  std::vector<hipEvent_t> event_pool;
 
   int esz() const { return (int)dtype_size(cfg.dtype); }
   int add_tensor(const std::string& name, int H, int W, int C, int pad) {
@@ -366,6 +377,8 @@ extern "C" int ron_destroy(ron_ctx* c) {
   for (auto& p : c->packed) { if (p.d_w) (void)hipFree(p.d_w); if (p.d_bias) (void)hipFree(p.d_bias); }
   for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) if (c->d_anchor[i][k]) (void)hipFree(c->d_anchor[i][k]);
   for (int k = 0; k < 3; ++k) for (int i = 0; i < 4; ++i) if (c->d_head[k][i]) (void)hipFree(c->d_head[k][i]);
+  for (auto& call : c->pending) for (hipEvent_t e : call) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->d_post_ws) (void)hipFree(c->d_post_ws);
   delete c;
   return RON_OK;
@@ -403,8 +416,9 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
   RON_HIP_CHECK(hipSetDevice(c->cfg.device));
   const int H = c->cfg.img_h, W = c->cfg.img_w;
   auto T = [&](const std::string& n) { return c->tensor_index.at(n); };
-  double flops = 0;
+  double flops = 0, mark = 0;
   int rc;
+#define ATTR() do { c->ops.back().flops += flops - mark; mark = flops; } while (0)
 #define PACK(expr) do { rc = (expr); if (rc < 0) return rc; } while (0)
   // ---- VGG-16 body ----
   {
@@ -420,7 +434,7 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       const bool stem = b == 0 && r == 0;
       PACK(stem ? pack_stem(c, scope) : pack_plain(c, scope, false));
       c->ops.push_back(conv_op(nm, prev, T(nm), rc, stem ? 1 : 3, stem ? 0 : 1, 1, h, w));
-      flops += conv_flops(c->var(scope + "/weights"), h * w);
+      flops += conv_flops(c->var(scope + "/weights"), h * w); ATTR();
       prev = T(nm);
     }
     Op p; p.kind = OP_POOL; p.name = "pool" + std::to_string(b + 1); p.in = prev; p.out = T(p.name);
@@ -435,11 +449,11 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
                                                : conv_op("fc6", prev, T("fc6"), rc, 3, 3, 1, h, w);
     if (c->cfg.variant != RON_VARIANT_FULL) o.dil = 3;
     c->ops.push_back(o);
-    flops += conv_flops(c->var("fc6/weights"), h * w);
+    flops += conv_flops(c->var("fc6/weights"), h * w); ATTR();
   }
   PACK(pack_plain(c, "fc7", false));
   c->ops.push_back(conv_op("fc7", T("fc6"), T("fc7"), rc, 1, 0, 1, h, w));
-  flops += conv_flops(c->var("fc7/weights"), h * w);
+  flops += conv_flops(c->var("fc7/weights"), h * w); ATTR();
   // ---- reverse connections + heads, coarse -> fine ----
   const char* left_src[4] = {"fc7", "fc6", "conv5_3", "conv4_3"};
   for (int i = 0; i < 4; ++i) {
@@ -456,24 +470,24 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       Op d = conv_op(Ln + "_deconv_right", T(std::string(kFeatLayers[i - 1]) + "_ref"), T(Ln + "_up"), rc, 1, 0, 1, sh / 2, sw / 2);
       d.up = 2; d.up_cout = 512;
       c->ops.push_back(d);
-      flops += conv_flops(c->var(L + "_deconv_right/weights"), (sh / 2) * (sw / 2));
+      flops += conv_flops(c->var(L + "_deconv_right/weights"), (sh / 2) * (sw / 2)); ATTR();
       PACK(pack_plain(c, L + "_conv_left", true));
       Op o = conv_op(Ln + "_conv_left", T(left_src[i]), T(Ln + "_ref"), rc, 3, 1, 1, sh, sw);
       o.res = T(Ln + "_up");
       c->ops.push_back(o);
     }
-    flops += conv_flops(c->var(L + "_conv_left/weights"), sh * sw);
+    flops += conv_flops(c->var(L + "_conv_left/weights"), sh * sw); ATTR();
     PACK(pack_trio(c, L));
     c->ops.push_back(conv_op(Ln + "_trio", T(Ln + "_ref"), T(Ln + "_hcat"), rc, 3, 1, 1, sh, sw));
     flops += conv_flops(c->var(L + "_objectness/weights"), sh * sw) + conv_flops(c->var(L + "/Conv2d_0_3x3/weights"), sh * sw) +
              conv_flops(c->var(L + "_inception1/Branch_0/Conv2d_3x3/weights"), sh * sw) +
-             conv_flops(c->var(L + "_inception1/Branch_1/Conv2d_1x1/weights"), sh * sw);
+             conv_flops(c->var(L + "_inception1/Branch_1/Conv2d_1x1/weights"), sh * sw); ATTR();
     PACK(pack_plain(c, L + "_objectness_score", false));
     {
       Op o = conv_op(Ln + "_objectness_score", T(Ln + "_hcat"), -2, rc, 3, 1, 0, sh, sw);
       o.in_coff = 0; o.in_C = 512; o.head_kind = 1; o.head_layer = i;
       c->ops.push_back(o);
-      flops += conv_flops(c->var(L + "_objectness_score/weights"), sh * sw);
+      flops += conv_flops(c->var(L + "_objectness_score/weights"), sh * sw); ATTR();
     }
     PACK(pack_inception2(c, L));
     {
@@ -481,25 +495,27 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       o.in_coff = 512; o.in_C = 1024;
       c->ops.push_back(o);
       flops += conv_flops(c->var(L + "_inception2/Branch_0/Conv2d_3x3/weights"), sh * sw) +
-               conv_flops(c->var(L + "_inception2/Branch_1/Conv2d_1x1/weights"), sh * sw);
+               conv_flops(c->var(L + "_inception2/Branch_1/Conv2d_1x1/weights"), sh * sw); ATTR();
     }
     PACK(pack_plain(c, L + "_inception2/Conv2d_pred_3x3", false));
     {
       Op o = conv_op(Ln + "_cls_pred", T(Ln + "_inc2"), -2, rc, 3, 1, 0, sh, sw);
       o.head_kind = 0; o.head_layer = i;
       c->ops.push_back(o);
-      flops += conv_flops(c->var(L + "_inception2/Conv2d_pred_3x3/weights"), sh * sw);
+      flops += conv_flops(c->var(L + "_inception2/Conv2d_pred_3x3/weights"), sh * sw); ATTR();
     }
     PACK(pack_plain(c, L + "/Conv2d_1_3x3", false));
     {
       Op o = conv_op(Ln + "_loc_pred", T(Ln + "_hcat"), -2, rc, 3, 1, 0, sh, sw);
       o.in_coff = 1536; o.in_C = 512; o.head_kind = 2; o.head_layer = i;
       c->ops.push_back(o);
-      flops += conv_flops(c->var(L + "/Conv2d_1_3x3/weights"), sh * sw);
+      flops += conv_flops(c->var(L + "/Conv2d_1_3x3/weights"), sh * sw); ATTR();
     }
   }
 #undef PACK
+#undef ATTR
   c->flops_per_image = flops;
+  c->timing.assign(c->ops.size() + 1, OpTiming());
   for (auto& v : c->vars) { v.data.clear(); v.data.shrink_to_fit(); }
   c->finalized = true;
   return RON_OK;
@@ -530,7 +546,22 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
   if (rc) return rc;
   const int A = c->num_anchors;
   const int head_c[3] = {A * c->cfg.num_classes, 2 * A, 4 * A};
+  std::vector<hipEvent_t>* ev = nullptr;
+  if (c->profiling && c->pending.size() < 256) {
+    c->pending.emplace_back();
+    ev = &c->pending.back();
+  }
+  auto stamp = [&]() -> int {
+    if (!ev) return RON_OK;
+    hipEvent_t e;
+    if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+    else RON_HIP_CHECK(hipEventCreate(&e));
+    RON_HIP_CHECK(hipEventRecord(e, s));
+    ev->push_back(e);
+    return RON_OK;
+  };
   for (const Op& o : c->ops) {
+    if ((rc = stamp())) return rc;
     if (o.kind == OP_IM2COL) {
       const Tensor& t = c->tensors[o.out];
       if ((rc = launch_im2col_c3(d_images, n, t.H, t.W, c->cfg.dtype, t.d, t.C, s))) return rc;
@@ -564,6 +595,55 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
       }
     }
   }
+  if ((rc = stamp())) return rc;      // closes the last op
+  return RON_OK;
+}
+
+// ---- per-launch timing -----------------------------------------------------------------------
+extern "C" int ron_profile_enable(ron_ctx* c, int enable) {
+  RON_REQUIRE(c, "NULL ctx");
+  c->profiling = enable != 0;
+  return RON_OK;
+}
+
+static int profile_collect(ron_ctx* c) {
+  for (auto& call : c->pending) {
+    if (call.empty()) continue;
+    RON_HIP_CHECK(hipEventSynchronize(call.back()));
+    for (size_t i = 0; i + 1 < call.size(); ++i) {
+      float ms = 0.f;
+      RON_HIP_CHECK(hipEventElapsedTime(&ms, call[i], call[i + 1]));
+      const size_t slot = i < c->ops.size() ? i : c->ops.size();
+      c->timing[slot].ms += ms;
+      c->timing[slot].launches += 1;
+    }
+    for (hipEvent_t e : call) c->event_pool.push_back(e);
+  }
+  c->pending.clear();
+  return RON_OK;
+}
+
+extern "C" int ron_profile_num_ops(const ron_ctx* c) { return c ? (int)c->ops.size() + 1 : RON_ERR_INVALID; }
+
+extern "C" int ron_profile_get(ron_ctx* c, int i, const char** name, int* is_conv, double* flops_per_image,
+                               double* total_ms, int* launches) {
+  RON_REQUIRE(c && i >= 0 && i <= (int)c->ops.size(), "op index out of range");
+  int rc = profile_collect(c);
+  if (rc) return rc;
+  const bool post = i == (int)c->ops.size();
+  if (name) *name = post ? "post_np" : c->ops[i].name.c_str();
+  if (is_conv) *is_conv = !post && c->ops[i].kind == OP_CONV;
+  if (flops_per_image) *flops_per_image = post ? 0.0 : c->ops[i].flops;
+  if (total_ms) *total_ms = c->timing[i].ms;
+  if (launches) *launches = c->timing[i].launches;
+  return RON_OK;
+}
+
+extern "C" int ron_profile_reset(ron_ctx* c) {
+  RON_REQUIRE(c, "NULL ctx");
+  int rc = profile_collect(c);
+  if (rc) return rc;
+  for (auto& t : c->timing) t = OpTiming();
   return RON_OK;
 }
 
@@ -616,5 +696,13 @@ extern "C" int ron_detect(ron_ctx* c, const float* d_images, int n, const ron_po
   }
   ron_post_cfg pc = *cfg;
   pc.input_flags = 0;      // logits + raw offsets straight from the conv stack
-  return ron_post_np(&hd, n, &pc, c->d_post_ws, c->post_ws_bytes, out, nullptr, nullptr, stream);
+  rc = ron_post_np(&hd, n, &pc, c->d_post_ws, c->post_ws_bytes, out, nullptr, nullptr, stream);
+  if (rc == RON_OK && c->profiling && !c->pending.empty() && c->pending.back().size() == c->ops.size() + 1) {
+    hipEvent_t e;
+    if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+    else RON_HIP_CHECK(hipEventCreate(&e));
+    RON_HIP_CHECK(hipEventRecord(e, (hipStream_t)stream));
+    c->pending.back().push_back(e);          // [ops.size()] .. [ops.size()+1] = post-processing
+  }
+  return rc;
 }

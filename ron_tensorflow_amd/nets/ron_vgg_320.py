@@ -1,0 +1,194 @@
+"""RON-320 (VGG-16) network object with the interface of the reference's ``nets/ron_vgg_320.py``.
+
+``RONNet`` keeps the names, argument names, defaults and return arity/order of the reference class
+(nets/ron_vgg_320.py:86-279) so that an ``eval_ron_network.py``-style driver works unchanged, but every
+tensor op runs as HIP kernels through libron_hip.so; tensors are torch CUDA tensors (device containers).
+
+Additions: ``variant`` ('reducedfc' = what the reference's RONNet.net builds, :144; 'full' = ron_net,
+reachable in the reference through nets_factory.get_network_fn), ``dtype`` ('bf16' | 'fp16' | 'fp32'),
+``load_weights`` (dict keyed by TF variable names) and the fused ``detect``.
+"""
+import contextlib
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from .._lib import check, current_stream, lib, ptr
+
+# same field names as the reference namedtuple (nets/ron_vgg_320.py:72-83)
+RONParams = namedtuple('SSDParameters', ['img_shape', 'num_classes', 'no_annotation_label', 'feat_layers',
+                                         'feat_shapes', 'allowed_borders', 'anchor_sizes', 'anchor_ratios',
+                                         'anchor_steps', 'anchor_offset', 'prior_scaling'])
+
+
+class RONNet(object):
+    """RON VGG-based 320 network: conv4 -> 40x40, conv5 -> 20x20, fc6 -> 10x10, fc7 -> 5x5."""
+    default_params = RONParams(
+        img_shape=(320, 320),
+        num_classes=21,
+        no_annotation_label=21,
+        feat_layers=['block7', 'block6', 'block5', 'block4'],
+        feat_shapes=[(5, 5), (10, 10), (20, 20), (40, 40)],
+        allowed_borders=[32, 16, 8, 4],
+        anchor_sizes=[(224., 256.), (160., 192.), (96., 128.), (32., 64.)],
+        anchor_ratios=[[1, 2, 3, 1. / 2, 1. / 3]] * 4,
+        anchor_steps=[64, 32, 16, 8],
+        anchor_offset=0.5,
+        prior_scaling=[0.1, 0.1, 0.2, 0.2])
+
+    def __init__(self, params=None, variant='reducedfc', dtype='bf16', max_batch=32, device=None):
+        self.params = params if isinstance(params, RONParams) else RONNet.default_params
+        if variant not in _lib.VARIANTS:
+            raise ValueError('Unknown RON variant %s' % variant)
+        if dtype not in _lib.DTYPES:
+            raise ValueError('Unknown dtype %s' % dtype)
+        self.variant, self.dtype, self.max_batch = variant, dtype, max_batch
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self._ctx = None
+        self._anchors_dev = None
+
+    # ------------------------------------------------------------------ context / weights
+    def _context(self):
+        if self._ctx is None:
+            cfg = _lib.Config(_lib.VARIANTS[self.variant], _lib.DTYPES[self.dtype], self.params.img_shape[0],
+                              self.params.img_shape[1], self.params.num_classes, self.max_batch,
+                              self.device.index or 0, 0)
+            h = C.c_void_p()
+            check(lib().ron_create(C.byref(h), C.byref(cfg)))
+            self._ctx = h
+        return self._ctx
+
+    def variables(self):
+        """[(tf_name, shape)] the graph expects (ron_variable_info)."""
+        ctx = self._context()
+        out = []
+        for i in range(lib().ron_num_variables(ctx)):
+            name = C.c_char_p()
+            shape = (C.c_int64 * 4)()
+            nd = C.c_int()
+            check(lib().ron_variable_info(ctx, i, C.byref(name), shape, C.byref(nd)))
+            out.append((name.value.decode(), tuple(shape[k] for k in range(nd.value))))
+        return out
+
+    def load_weights(self, weights):
+        """weights: dict {tf variable name: ndarray} (HWIO convs, [kh,kw,Cout,Cin] transposed convs)."""
+        ctx = self._context()
+        for name, shape in self.variables():
+            if name not in weights:
+                raise KeyError('missing variable %s' % name)
+            a = np.ascontiguousarray(weights[name], dtype=np.float32)
+            shp = (C.c_int64 * 4)(*a.shape)
+            check(lib().ron_load_weight(ctx, name.encode(), ptr(a), shp, a.ndim))
+        check(lib().ron_finalize_weights(ctx))
+        return self
+
+    def flops_per_image(self):
+        return lib().ron_flops_per_image(self._context())
+
+    def close(self):
+        if self._ctx is not None:
+            lib().ron_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference interface
+    def _head_buffers(self, n):
+        A, nc = len(self.params.anchor_sizes[0]) * len(self.params.anchor_ratios[0]), self.params.num_classes
+        cls, obj, loc = [], [], []
+        for (fh, fw) in self.params.feat_shapes:
+            cls.append(torch.empty((n, fh, fw, A, nc), dtype=torch.float32, device=self.device))
+            obj.append(torch.empty((n, fh, fw, A, 2), dtype=torch.float32, device=self.device))
+            loc.append(torch.empty((n, fh, fw, A, 4), dtype=torch.float32, device=self.device))
+        return cls, obj, loc
+
+    def forward_heads(self, inputs):
+        """Conv stack only: (logits, objness_logits, localisations) as lists of fp32 GPU tensors."""
+        inputs = inputs.to(self.device, torch.float32).contiguous()
+        n = inputs.shape[0]
+        assert tuple(inputs.shape[1:]) == tuple(self.params.img_shape) + (3,), 'inputs must be [N,%d,%d,3] NHWC' % self.params.img_shape
+        cls, obj, loc = self._head_buffers(n)
+        hd = _lib.Heads()
+        for i in range(4):
+            hd.cls[i], hd.obj[i], hd.loc[i] = cls[i].data_ptr(), obj[i].data_ptr(), loc[i].data_ptr()
+        check(lib().ron_forward(self._context(), ptr(inputs), n, C.byref(hd), current_stream()))
+        return cls, obj, loc
+
+    def net(self, inputs, is_training=True, dropout_keep_prob=0.5, prediction_fn=None, reuse=None,
+            scope='ron_320_vgg', end_points=('block1', 'block2', 'block3', 'block4', 'block5', 'block6', 'block7')):
+        """RON network (nets/ron_vgg_320.py:136-154).  Inference only: `is_training` / `dropout_keep_prob` /
+        `reuse` / `scope` are accepted for signature compatibility (the reference's dropout is commented out,
+        :480, and BatchNorm runs on its moving statistics).  Returns the reference's 6-tuple
+        (predictions, logits, objness_pred, objness_logits, localisations, end_points)."""
+        logits, objness_logits, localisations = self.forward_heads(inputs)
+        fn = prediction_fn if prediction_fn is not None else ops.softmax_last
+        predictions = [fn(l) for l in logits]
+        objness_pred = [ops.softmax_last(o, pick=1) if prediction_fn is None else fn(o)[..., 1:2] for o in objness_logits]
+        eps = {name: self.end_point(name, inputs.shape[0]) for name in (end_points or ())}
+        return predictions, logits, objness_pred, objness_logits, localisations, eps
+
+    def end_point(self, name, n):
+        shp = (C.c_int64 * 4)()
+        rc = lib().ron_end_point_shape(self._context(), name.encode(), n, shp)
+        if rc < 0:
+            check(rc)
+        out = torch.empty(tuple(shp), dtype=torch.float32, device=self.device)
+        check(lib().ron_end_point_copy(self._context(), name.encode(), n, ptr(out), current_stream()))
+        return out
+
+    def arg_scope(self, weight_decay=0.0005, is_training=True, data_format='NHWC'):
+        """Network arg_scope (nets/ron_vgg_320.py:156-159).  Layer defaults are baked into the HIP graph;
+        returned object is a no-op context manager so `with slim.arg_scope(net.arg_scope(...))`-style code runs."""
+        if data_format != 'NHWC':
+            raise ValueError('only NHWC is supported')
+        return contextlib.nullcontext()
+
+    def anchors(self, img_shape, dtype=np.float32):
+        """Default anchor boxes (nets/ron_vgg_320.py:162-171): list of (y, x, h, w) per layer."""
+        p = self.params
+        return [ops.anchor_one_layer(img_shape, s, p.anchor_sizes[i], p.anchor_ratios[i], p.anchor_steps[i],
+                                     offset=p.anchor_offset, dtype=dtype) for i, s in enumerate(p.feat_shapes)]
+
+    def _anchors_device(self):
+        if self._anchors_dev is None:
+            self._anchors_dev = ops.anchors_to_device(self.anchors(self.params.img_shape), self.device)
+        return self._anchors_dev
+
+    def bboxes_decode(self, feat_localizations, anchors, scope='ssd_bboxes_decode'):
+        """nets/ron_vgg_320.py:188-195 -> ssd_common.tf_ssd_bboxes_decode."""
+        adev = ops.anchors_to_device(anchors, self.device)
+        return [ops.bboxes_decode_layer(l, a, tuple(self.params.prior_scaling)) for l, a in zip(feat_localizations, adev)]
+
+    def detected_bboxes(self, predictions, localisations, select_threshold=None, nms_threshold=0.5,
+                        clipping_bbox=None, top_k=400, keep_top_k=200, nms_mode='min'):
+        """nets/ron_vgg_320.py:234-256: per-class select -> clip -> filter_min -> sort -> NMS (TF semantics).
+        Returns (dict_scores, dict_bboxes): class -> [N, keep_top_k] / [N, keep_top_k, 4], zero padded."""
+        from .. import tfe
+        return tfe.detected_bboxes(predictions, localisations, num_classes=self.params.num_classes,
+                                   select_threshold=select_threshold, nms_threshold=nms_threshold,
+                                   clipping_bbox=clipping_bbox, top_k=top_k, keep_top_k=keep_top_k,
+                                   nms_mode=nms_mode, min_size=0.03)
+
+    # ------------------------------------------------------------------ fused graded path
+    def detect(self, inputs, objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45, top_k=400,
+               bbox_img=(0., 0., 1., 1.)):
+        """forward + np_methods post-processing in one enqueue (ron_detect).  Returns DetectionBuffers."""
+        inputs = inputs.to(self.device, torch.float32).contiguous()
+        n = inputs.shape[0]
+        cfg = _lib.PostCfg()
+        cfg.objectness_thres, cfg.select_threshold, cfg.nms_threshold, cfg.top_k = \
+            objectness_thres, select_threshold, nms_threshold, top_k
+        for i in range(4):
+            cfg.bbox_img[i] = bbox_img[i]
+            cfg.prior_scaling[i] = self.params.prior_scaling[i]
+        out = ops.DetectionBuffers(n, top_k, self.device)
+        oc = out.c_struct()
+        check(lib().ron_detect(self._context(), ptr(inputs), n, C.byref(cfg), C.byref(oc), current_stream()))
+        return out

@@ -1,0 +1,170 @@
+"""GPU parity: the conv stack (ron_forward through RONNet) vs the oracle forward, and the fused detect path.
+
+fp32 mode is the parity mode (exact-fp32 MFMA): head tensors within 1e-4 of the logit scale.  bf16/fp16
+modes are compared with an oracle that applies the same operand rounding, with a tolerance of a few
+storage-type ulps; their detections are graded on identical head tensors ("parity vs precision")."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import anchors as oanchors  # noqa: E402
+from oracle import np_post  # noqa: E402
+from oracle import ron_forward as orf  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    import ron_tensorflow_amd.weights as W
+    from ron_tensorflow_amd.nets import nets_factory, ron_vgg_320
+    return dict(W=W, factory=nets_factory, ron=ron_vgg_320)
+
+
+@pytest.fixture(scope='module')
+def weights_reduced(pkg):
+    return pkg['W'].synthetic_weights('reducedfc', seed=1)
+
+
+@pytest.fixture(scope='module')
+def weights_full(pkg):
+    return pkg['W'].synthetic_weights('full', seed=2)
+
+
+@pytest.fixture(scope='module')
+def images(pkg):
+    return pkg['W'].synthetic_images(2, seed=0)
+
+
+@pytest.fixture(scope='module')
+def oracle_reduced(weights_reduced, images):
+    col = {}
+    out = orf.ron_forward(images, weights_reduced, 'reducedfc', backend='numpy', collect=col)
+    return out, col
+
+
+def _rel_err(got, ref):
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+
+
+def test_factory_interface(pkg):
+    f = pkg['factory']
+    cls = f.get_network('ron_320_vgg')
+    assert cls is pkg['ron'].RONNet
+    params = cls.default_params._replace(num_classes=21)
+    assert params.img_shape == (320, 320) and params.feat_shapes[0] == (5, 5)
+    with pytest.raises(ValueError):
+        f.get_network_fn('no_such_net', 21)
+    with pytest.raises(KeyError):
+        f.get_network('no_such_net')
+
+
+def test_variable_contract_and_flops(pkg, dev):
+    for variant, gflop in (('reducedfc', 138.26), ('full', 164.16)):
+        net = pkg['ron'].RONNet(variant=variant, dtype='fp32', max_batch=1)
+        assert net.variables() == [(n, tuple(s)) for n, s in pkg['W'].variable_shapes(variant)]
+        net.close()
+    # FLOPs are known after finalize (needs weights): checked in the forward tests below
+
+
+def test_forward_fp32_reducedfc(pkg, dev, weights_reduced, images, oracle_reduced):
+    (pred, logits, objp, objl, loc, eps), col = oracle_reduced
+    net = pkg['ron'].RONNet(variant='reducedfc', dtype='fp32', max_batch=2).load_weights(weights_reduced)
+    assert abs(net.flops_per_image() / 1e9 - 138.26) < 0.5
+    x = torch.from_numpy(images).to(dev)
+    g_pred, g_logits, g_objp, g_objl, g_loc, g_eps = net.net(x, is_training=False)
+    for i in range(4):
+        assert tuple(g_logits[i].shape) == logits[i].shape and tuple(g_pred[i].shape) == pred[i].shape
+        assert tuple(g_objp[i].shape) == objp[i].shape and tuple(g_loc[i].shape) == loc[i].shape
+        assert _rel_err(g_logits[i].cpu().numpy(), logits[i]) < 1e-4, i
+        assert _rel_err(g_objl[i].cpu().numpy(), objl[i]) < 1e-4, i
+        assert _rel_err(g_loc[i].cpu().numpy(), loc[i]) < 1e-4, i
+        np.testing.assert_allclose(g_pred[i].cpu().numpy(), pred[i], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(g_objp[i].cpu().numpy(), objp[i], rtol=0, atol=1e-4)
+    for name in ('block1', 'block4', 'block5', 'block6', 'block7'):
+        assert _rel_err(g_eps[name].cpu().numpy(), eps[name]) < 1e-4, name
+    for name in ('block7_ref', 'block4_ref', 'pool5'):
+        assert _rel_err(net.end_point(name, 2).cpu().numpy(), col[name]) < 1e-4, name
+
+    # fused detect == post-processing of the heads the same context produced (identical head tensors)
+    anchors = oanchors.anchors_all_layers()
+    det = net.detect(x).to_lists()
+    ref = np_post.detect_from_predictions([p.cpu().numpy() for p in g_pred], [l.cpu().numpy() for l in g_loc], anchors,
+                                          objness_pred=[o.cpu().numpy() for o in g_objp])
+    for b in range(2):
+        assert np.array_equal(det[b]['classes'], ref[b]['classes'])
+        assert np.array_equal(det[b]['anchor_index'], ref[b]['anchor_index'])
+        assert np.array_equal(det[b]['scores'], ref[b]['scores'])
+        np.testing.assert_allclose(det[b]['bboxes'], ref[b]['bboxes'], rtol=0, atol=1e-5)
+    # fully independent oracle (own conv stack): detections agree except where a score / IoU sits within
+    # float rounding of a threshold; require >= 98 % of the reference detections reproduced, floats to 1e-4
+    ind = np_post.detect_from_predictions(pred, loc, anchors, objness_pred=objp)
+    for b in range(2):
+        ref_keys = {(int(c), int(a)): k for k, (c, a) in enumerate(zip(ind[b]['classes'], ind[b]['anchor_index']))}
+        hit = [(k, ref_keys[(int(c), int(a))]) for k, (c, a) in enumerate(zip(det[b]['classes'], det[b]['anchor_index']))
+               if (int(c), int(a)) in ref_keys]
+        assert len(hit) >= 0.98 * len(ref_keys) and len(hit) >= 0.98 * len(det[b]['classes'])
+        gi, ri = np.array([h[0] for h in hit]), np.array([h[1] for h in hit])
+        np.testing.assert_allclose(det[b]['scores'][gi], ind[b]['scores'][ri], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(det[b]['bboxes'][gi], ind[b]['bboxes'][ri], rtol=0, atol=1e-4)
+    net.close()
+
+
+def test_forward_fp32_full(pkg, dev, weights_full, images):
+    ref = orf.ron_forward(images[:1], weights_full, 'full', backend='numpy')
+    net = pkg['ron'].RONNet(variant='full', dtype='fp32', max_batch=1).load_weights(weights_full)
+    assert abs(net.flops_per_image() / 1e9 - 164.16) < 0.5
+    cls, obj, loc = net.forward_heads(torch.from_numpy(images[:1]).to(dev))
+    for i in range(4):
+        assert _rel_err(cls[i].cpu().numpy(), ref[1][i]) < 1e-4, i
+        assert _rel_err(obj[i].cpu().numpy(), ref[3][i]) < 1e-4, i
+        assert _rel_err(loc[i].cpu().numpy(), ref[4][i]) < 1e-4, i
+    net.close()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_forward_reduced_precision(pkg, dev, weights_reduced, images, oracle_reduced, dtype):
+    rnd = {'bf16': orf.round_bf16, 'fp16': orf.round_f16}[dtype]
+    tol = {'bf16': 0.04, 'fp16': 0.006}[dtype]
+    ref = orf.ron_forward(images[:1], weights_reduced, 'reducedfc', backend='numpy', round_fn=rnd)
+    net = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=2).load_weights(weights_reduced)
+    x = torch.from_numpy(images).to(dev)
+    cls, obj, loc = net.forward_heads(x)
+    for i in range(4):
+        g = cls[i][:1].cpu().numpy()
+        assert _rel_err(g, ref[1][i]) < tol, (i, _rel_err(g, ref[1][i]))
+        assert float(np.abs(g - ref[1][i]).mean() / np.abs(ref[1][i]).max()) < tol / 8
+        assert _rel_err(loc[i][:1].cpu().numpy(), ref[4][i]) < tol * 2
+    # detections of the reduced-precision stack are graded on its own head tensors (bit-exact post-processing)
+    from ron_tensorflow_amd import ops
+    anchors = oanchors.anchors_all_layers()
+    pred = [ops.softmax_last(c) for c in cls]
+    objp = [ops.softmax_last(o, pick=1) for o in obj]
+    want = np_post.detect_from_predictions([p.cpu().numpy() for p in pred], [l.cpu().numpy() for l in loc], anchors,
+                                           objness_pred=[o.cpu().numpy() for o in objp])
+    det = net.detect(x).to_lists()
+    for b in range(2):
+        assert np.array_equal(det[b]['classes'], want[b]['classes'])
+        assert np.array_equal(det[b]['anchor_index'], want[b]['anchor_index'])
+        assert np.array_equal(det[b]['scores'], want[b]['scores'])
+        np.testing.assert_allclose(det[b]['bboxes'], want[b]['bboxes'], rtol=0, atol=1e-5)
+    # batch independence: image 1 alone == image 1 in the batch
+    one = net.forward_heads(x[1:2])
+    for i in range(4):
+        assert torch.equal(one[0][i][0], cls[i][1])
+    net.close()
+
+
+def test_network_fn_uses_full_variant(pkg, dev, weights_full, images):
+    fn = pkg['factory'].get_network_fn('ron_320_vgg', 21, is_training=False, weights=weights_full, dtype='bf16', max_batch=1)
+    assert fn.default_image_size == 320
+    out = fn(torch.from_numpy(images[:1]).to(dev), end_points=('block6',))
+    assert len(out) == 6
+    assert tuple(out[5]['block6'].shape) == (1, 10, 10, 4096)       # ron_net: fc6 7x7 -> 4096 (nets/ron_vgg_320.py:478)
+    assert tuple(out[0][3].shape) == (1, 40, 40, 10, 21)
