@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of RON-VGG16-320 inference on N MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic pre-whitened 320x320x3 images that are
+already resident in HBM: conv stack (ron_net, full VGG-16 fc6/fc7, bf16 MFMA) -> softmax + objectness gate ->
+decode -> select -> top-k -> class-aware NMS (np_methods semantics), i.e. one ron_detect() call; with N > 1
+every rank processes its own shard of images (weak scaling) and the fixed-size detection records are
+all-gathered over RCCL (the only exchange the path has).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (dominant kernel = the
+implicit-GEMM conv kernel, MFMA-bound; achieved = algorithmic conv FLOPs per launch / HIP-event duration of
+those launches inside the timed region) and, at N = 1, `cpu_baseline` (the oracle port timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F16_TFLOPS = 2500.0
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step (BASELINE config 2: 32)')
+    ap.add_argument('--variant', default='full', choices=['full', 'reducedfc'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=4, help='images in the bounded CPU-baseline sample')
+    ap.add_argument('--layers', default='', help='write the per-launch timing table to this file')
+    return ap.parse_args()
+
+
+def cpu_baseline(variant, weights, n_images):
+    """The oracle port (numpy conv stack + numpy np_methods post-processing) on the host cores."""
+    from oracle import anchors as oanchors
+    from oracle import np_post
+    from oracle import ron_forward as orf
+    from ron_tensorflow_amd.weights import synthetic_images
+    anchors = oanchors.anchors_all_layers()
+    x = synthetic_images(n_images + 1, seed=10)
+
+    def run(batch):
+        pred, _, objp, _, loc, _ = orf.ron_forward(batch, weights, variant, backend='numpy')
+        return np_post.detect_from_predictions(pred, loc, anchors, objness_pred=objp)
+
+    run(x[:1])                                   # warm-up (BLAS threads, page faults)
+    t0 = time.perf_counter()
+    for i in range(n_images):
+        run(x[i + 1:i + 2])
+    dt = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return {'value': n_images / dt, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d images, batch 1, %s, fp32 numpy conv stack (BLAS threads = host cores) + numpy np_methods '
+                      'post-processing; %.1f s' % (n_images, variant, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world and world > 1:
+        raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('for --gpus > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                         '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from ron_tensorflow_amd import _lib
+    from ron_tensorflow_amd.nets import nets_factory
+    from ron_tensorflow_amd.weights import synthetic_images, synthetic_weights
+    import ctypes as C
+
+    # ---- the reference's call pattern (eval_ron_network.py:148-152): factory -> class -> params -> net
+    ron_class = nets_factory.get_network('ron_320_vgg')
+    ron_params = ron_class.default_params._replace(num_classes=21)
+    weights = synthetic_weights(args.variant, seed=1)     # seed 1: ~4.8 k candidates, ~230 detections per image (full)
+    net = ron_class(ron_params, variant=args.variant, dtype=args.dtype, max_batch=args.batch, device=dev)
+    net.load_weights(weights)
+    images = torch.from_numpy(synthetic_images(args.batch, seed=3 + rank)).to(dev)      # resident in HBM
+    top_k = 400
+
+    gathered = None
+    if world > 1:
+        rec_w = 1 + 1 + 4 + 1          # class, score, box, anchor index  (+ count row)
+        gathered = torch.empty((world, args.batch, top_k + 1, rec_w), dtype=torch.float32, device=dev)
+
+    def step():
+        det = net.detect(images, objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45, top_k=top_k)
+        if world > 1:
+            rec = torch.empty((args.batch, top_k + 1, 7), dtype=torch.float32, device=dev)
+            rec[:, :top_k, 0] = det.classes
+            rec[:, :top_k, 1] = det.scores
+            rec[:, :top_k, 2:6] = det.bboxes
+            rec[:, :top_k, 6] = det.anchor_index
+            rec[:, top_k, :] = det.count[:, None]
+            dist.all_gather_into_tensor(gathered, rec)
+        return det
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib = _lib.lib()
+    _lib.check(lib.ron_profile_reset(net._context()))
+    _lib.check(lib.ron_profile_enable(net._context(), 1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        det = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.check(lib.ron_profile_enable(net._context(), 0))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-launch timing of the timed region (HIP events on the launch stream, inside libron_hip)
+    rows = []
+    nops = lib.ron_profile_num_ops(net._context())
+    for i in range(nops):
+        name, is_conv, fl, ms, ln = C.c_char_p(), C.c_int(), C.c_double(), C.c_double(), C.c_int()
+        _lib.check(lib.ron_profile_get(net._context(), i, C.byref(name), C.byref(is_conv), C.byref(fl), C.byref(ms), C.byref(ln)))
+        rows.append(dict(name=name.value.decode(), is_conv=bool(is_conv.value), gflop_per_image=fl.value / 1e9,
+                         total_ms=ms.value, launches=ln.value))
+    conv = [r for r in rows if r['is_conv'] and r['launches'] > 0]
+    conv_ms = sum(r['total_ms'] for r in conv)
+    conv_launches = sum(r['launches'] for r in conv)
+    conv_flop = sum(r['gflop_per_image'] * 1e9 * args.batch * r['launches'] for r in conv)
+    achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = {'bf16': PEAK_BF16_TFLOPS, 'fp16': PEAK_F16_TFLOPS, 'fp32': PEAK_F32_TFLOPS}[args.dtype]
+
+    if rank == 0:
+        total_images = world * args.batch * args.steps
+        out = {
+            'metric': 'images/sec RON-VGG16-320 inference',
+            'value': total_images / dt,
+            'unit': 'images/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': args.dtype,
+            'data': 'synthetic',
+            'config': {'workload': 'RON-320 %s (%s) batch=%d per GPU, synthetic 320x320x3 inputs resident in HBM, '
+                                   'forward + np_methods decode/select/top-400/NMS%s'
+                                   % ('VGG16 ron_net' if args.variant == 'full' else 'reducedfc', args.dtype, args.batch,
+                                      ', RCCL all-gather of detection records' if world > 1 else ''),
+                       'images_per_step': world * args.batch,
+                       'gflop_per_image': net.flops_per_image() / 1e9,
+                       'conv_stack_tflops_per_gpu': net.flops_per_image() * args.batch * args.steps / dt / 1e12,
+                       'mean_detections_per_image': float(det.count.float().mean().item())},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel', 'achieved': achieved, 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                         'avg_launch_us': conv_ms / max(conv_launches, 1) * 1e3,
+                         'launches_per_step': conv_launches // max(args.steps, 1),
+                         'kernel_time_share': conv_ms / (dt * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.variant, weights, args.cpu_images)
+        if args.layers:
+            with open(args.layers, 'w') as f:
+                f.write('# per-launch timing, %s %s batch %d, %d steps (HIP events)\n' % (args.variant, args.dtype, args.batch, args.steps))
+                f.write('%-28s %9s %10s %9s %9s\n' % ('launch', 'GFLOP/img', 'avg_us', 'TFLOP/s', 'share_%'))
+                tot = sum(r['total_ms'] for r in rows) or 1.0
+                for r in rows:
+                    if r['launches'] == 0:
+                        continue
+                    us = r['total_ms'] / r['launches'] * 1e3
+                    tf = r['gflop_per_image'] * args.batch / (us * 1e-6) / 1e3 if us > 0 else 0
+                    f.write('%-28s %9.3f %10.1f %9.1f %9.2f\n' % (r['name'], r['gflop_per_image'], us, tf, 100 * r['total_ms'] / tot))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
