@@ -102,21 +102,16 @@ def main():
     images = torch.from_numpy(synthetic_images(args.batch, seed=3 + rank)).to(dev)      # resident in HBM
     top_k = 400
 
+    from ron_tensorflow_amd import parallel
     gathered = None
     if world > 1:
-        rec_w = 1 + 1 + 4 + 1          # class, score, box, anchor index  (+ count row)
-        gathered = torch.empty((world, args.batch, top_k + 1, rec_w), dtype=torch.float32, device=dev)
+        gathered = torch.empty((world, args.batch, top_k + 1, parallel.RECORD_WIDTH), dtype=torch.float32, device=dev)
 
     def step():
         det = net.detect(images, objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45, top_k=top_k)
         if world > 1:
-            rec = torch.empty((args.batch, top_k + 1, 7), dtype=torch.float32, device=dev)
-            rec[:, :top_k, 0] = det.classes
-            rec[:, :top_k, 1] = det.scores
-            rec[:, :top_k, 2:6] = det.bboxes
-            rec[:, :top_k, 6] = det.anchor_index
-            rec[:, top_k, :] = det.count[:, None]
-            dist.all_gather_into_tensor(gathered, rec)
+            rec = parallel.pack_records(det.classes, det.scores, det.bboxes, det.anchor_index, det.count)
+            parallel.gather_detections(rec, out=gathered)
         return det
 
     for _ in range(args.warmup):
