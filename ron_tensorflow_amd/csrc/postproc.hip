@@ -246,10 +246,22 @@ __device__ __forceinline__ bool nms_suppresses(const float* bi, const float* bj,
   return !(iou < thr);   // NaN suppresses, as logical_or(overlap < thr, ...) does
 }
 
-// Greedy scan over the n sorted boxes in lds (np_methods.py:229-242).  Writes kept rows,
-// compacted, to `out` (image `img`), after the resize by `ref` when do_resize.
-__device__ void nms_and_store(ImageLds& lds, int n, float nms_thr, const float* ref, bool do_resize,
-                              const DetDev& out, int img) {
+// tf_extended/bboxes.py:195-211 + :226: kept box i against a later box j; mode 1 = 'min', 2 = 'union'
+__device__ __forceinline__ bool tfe_suppresses(const float* bi, const float* bj, float thr, int mode) {
+  const float ih = fmaxf(fminf(bj[2], bi[2]) - fmaxf(bj[0], bi[0]), 0.f);
+  const float iw = fmaxf(fminf(bj[3], bi[3]) - fmaxf(bj[1], bi[1]), 0.f);
+  const float inner = ih * iw;
+  const float this_vol = (bi[2] - bi[0]) * (bi[3] - bi[1]);
+  const float vol = (bj[3] - bj[1]) * (bj[2] - bj[0]);
+  const float den = mode == 2 ? (vol - inner + this_vol) : fminf(vol, this_vol);
+  const float sc = den > 0.f ? inner / den : 0.f;      // safe_divide, bboxes.py:192-193
+  return !(sc < thr);
+}
+
+// Suppression bit matrix of the n sorted boxes in lds (row i: which later rows box i removes), then the
+// greedy scan by one wave.  Leaves in lds.hist: [0..7] low / [16..23] high halves of the keep bits per
+// 64-row word, [32..39] exclusive kept counts per word; lds.scalars[4] = number kept (<= max_keep).
+__device__ void nms_scan(ImageLds& lds, int n, float nms_thr, int mode, int max_keep) {
   const int tid = threadIdx.x;
   const int nth = blockDim.x;
   const int words = (n + 63) >> 6;
@@ -261,7 +273,9 @@ __device__ void nms_and_store(ImageLds& lds, int n, float nms_thr, const float* 
     const int j1 = min(n, j0 + 64);
     const int ci = lds.cls[i];
     for (int j = max(j0, i + 1); j < j1; ++j) {
-      if (lds.cls[j] == ci && nms_suppresses(lds.box[i], lds.box[j], nms_thr)) bits |= 1ull << (j - j0);
+      const bool sup = mode == 0 ? (lds.cls[j] == ci && nms_suppresses(lds.box[i], lds.box[j], nms_thr))
+                                 : tfe_suppresses(lds.box[i], lds.box[j], nms_thr, mode);
+      if (sup) bits |= 1ull << (j - j0);
     }
     mask[i * kMaskWords + w] = bits;
   }
@@ -271,13 +285,15 @@ __device__ void nms_and_store(ImageLds& lds, int n, float nms_thr, const float* 
     const int lane = tid;
     u64 removed = 0;
     u64 keep_bits = 0;     // lane w: kept rows of word w
-    for (int i = 0; i < n; ++i) {
+    int n_kept = 0;
+    for (int i = 0; i < n && n_kept < max_keep; ++i) {
       const int wi = i >> 6;
       const u64 rw = __shfl(removed, wi, 64);
       const bool kept = ((rw >> (i & 63)) & 1ull) == 0;
       if (kept) {
         if (lane < words) removed |= mask[i * kMaskWords + lane];
         if (lane == wi) keep_bits |= 1ull << (i & 63);
+        ++n_kept;
       }
     }
     // exclusive prefix of kept counts per word
@@ -289,7 +305,6 @@ __device__ void nms_and_store(ImageLds& lds, int n, float nms_thr, const float* 
       if (lane >= d) incl += v;
     }
     if (lane < kMaskWords) {
-      // stash keep bits + exclusive offsets behind the mask rows actually used
       lds.hist[lane] = (unsigned)(keep_bits & 0xFFFFFFFFull);
       lds.hist[16 + lane] = (unsigned)(keep_bits >> 32);
       lds.hist[32 + lane] = (unsigned)(incl - cnt);
@@ -297,6 +312,23 @@ __device__ void nms_and_store(ImageLds& lds, int n, float nms_thr, const float* 
     if (lane == 63) lds.scalars[4] = incl;
   }
   __syncthreads();
+}
+
+// output slot of sorted row i after the scan, or -1 when it was suppressed
+__device__ __forceinline__ int nms_slot(const ImageLds& lds, int i) {
+  const int w = i >> 6, b = i & 63;
+  const u64 kb = ((u64)lds.hist[16 + w] << 32) | (u64)lds.hist[w];
+  if (!((kb >> b) & 1ull)) return -1;
+  return (int)lds.hist[32 + w] + __popcll(kb & ((1ull << b) - 1ull));
+}
+
+// Greedy scan over the n sorted boxes in lds (np_methods.py:229-242).  Writes kept rows,
+// compacted, to `out` (image `img`), after the resize by `ref` when do_resize.
+__device__ void nms_and_store(ImageLds& lds, int n, float nms_thr, const float* ref, bool do_resize,
+                              const DetDev& out, int img) {
+  const int tid = threadIdx.x;
+  const int nth = blockDim.x;
+  nms_scan(lds, n, nms_thr, 0, n);
   const int total = lds.scalars[4];
   const float sy = ref[2] - ref[0], sx = ref[3] - ref[1];
   for (int i = tid; i < out.capacity; i += nth) {
@@ -311,23 +343,19 @@ __device__ void nms_and_store(ImageLds& lds, int n, float nms_thr, const float* 
     }
   }
   for (int i = tid; i < n; i += nth) {
-    const int w = i >> 6, b = i & 63;
-    const u64 kb = ((u64)lds.hist[16 + w] << 32) | (u64)lds.hist[w];
-    if ((kb >> b) & 1ull) {
-      const int pos = (int)lds.hist[32 + w] + __popcll(kb & ((1ull << b) - 1ull));
-      if (pos < out.capacity) {
-        const size_t o = (size_t)img * out.capacity + pos;
-        out.classes[o] = lds.cls[i];
-        out.scores[o] = lds.score[i];
-        out.anchor_index[o] = lds.anchor[i];
-        float b0 = lds.box[i][0], b1 = lds.box[i][1], b2 = lds.box[i][2], b3 = lds.box[i][3];
-        if (do_resize) {   // np_methods.py:167-183
-          b0 = (b0 - ref[0]) / sy; b1 = (b1 - ref[1]) / sx;
-          b2 = (b2 - ref[0]) / sy; b3 = (b3 - ref[1]) / sx;
-        }
-        out.bboxes[o * 4 + 0] = b0; out.bboxes[o * 4 + 1] = b1;
-        out.bboxes[o * 4 + 2] = b2; out.bboxes[o * 4 + 3] = b3;
+    const int pos = nms_slot(lds, i);
+    if (pos >= 0 && pos < out.capacity) {
+      const size_t o = (size_t)img * out.capacity + pos;
+      out.classes[o] = lds.cls[i];
+      out.scores[o] = lds.score[i];
+      out.anchor_index[o] = lds.anchor[i];
+      float b0 = lds.box[i][0], b1 = lds.box[i][1], b2 = lds.box[i][2], b3 = lds.box[i][3];
+      if (do_resize) {   // np_methods.py:167-183
+        b0 = (b0 - ref[0]) / sy; b1 = (b1 - ref[1]) / sx;
+        b2 = (b2 - ref[0]) / sy; b3 = (b3 - ref[1]) / sx;
       }
+      out.bboxes[o * 4 + 0] = b0; out.bboxes[o * 4 + 1] = b1;
+      out.bboxes[o * 4 + 2] = b2; out.bboxes[o * 4 + 3] = b3;
     }
   }
   if (tid == 0) out.count[img] = min(total, out.capacity);
@@ -603,6 +631,186 @@ extern "C" int ron_softmax_last(const float* x, int64_t rows, int c, int pick, f
   const int blocks = (int)std::min<int64_t>((rows + 255) / 256, 4096);
   hipLaunchKernelGGL(softmax_last_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, c,
                      pick, y);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+// ==========================================================================================
+// TF-evaluation variant (what eval_ron_network.py:226-236 runs through RONNet.detected_bboxes,
+// nets/ron_vgg_320.py:234-256): per class select (ssd_common.py:504-589) -> clip with repair
+// (tf_extended/bboxes.py:105-144) -> bboxes_filter_min (ron_vgg_320.py:196-233) -> top_k sort
+// (bboxes.py:60-101) -> greedy NMS, mode 'min' | 'union', at most keep_top_k (bboxes.py:173-234)
+// -> zero padding (tensors.py:59-86).  The dense zeroed rows of the TF graph are never
+// materialised: rows with score <= thr are zero rows there, which neither suppress nor survive
+// the size filter, so only the selected candidates are listed (per image AND class).
+// ==========================================================================================
+namespace {
+
+struct TfeDev {
+  float obj_thr, sel_thr, nms_thr;
+  int top_k, keep_top_k, nms_mode, clip;
+  float ref[4];
+  float min_size;
+  float ps[4];
+  unsigned flags;
+};
+
+__device__ __forceinline__ void tfe_box(const HeadsDev& hd, const TfeDev& pc, int img, int layer, int local, float* box) {
+  const int A = hd.num_anchors[layer];
+  const int cell = local / A, a = local - cell * A;
+  const size_t n_anchor_layer = (size_t)hd.cells[layer] * A;
+  const float* l4 = hd.loc[layer] + ((size_t)img * n_anchor_layer + local) * 4;
+  if (pc.flags & RON_IN_LOC_DECODED) {
+    box[0] = l4[0]; box[1] = l4[1]; box[2] = l4[2]; box[3] = l4[3];
+  } else {
+    decode_box(l4, hd.ay[layer][cell], hd.ax[layer][cell], hd.ah[layer][a], hd.aw[layer][a], pc.ps, box);
+  }
+  if (pc.clip) {   // tf_extended/bboxes.py:130-142
+    box[0] = fmaxf(box[0], pc.ref[0]); box[1] = fmaxf(box[1], pc.ref[1]);
+    box[2] = fminf(box[2], pc.ref[2]); box[3] = fminf(box[3], pc.ref[3]);
+    box[0] = fminf(box[0], box[2]);    box[1] = fminf(box[1], box[3]);
+  }
+}
+
+// one thread per anchor; candidates go to per-(image, class) lists keyed by (score, anchor index)
+__global__ __launch_bounds__(kSelectThreads) void tfe_select_kernel(HeadsDev hd, TfeDev pc, u64* keys, int* counts,
+                                                                    int cap) {
+  extern __shared__ __attribute__((aligned(16))) float stage[];
+  const int img = blockIdx.y;
+  const int tid = threadIdx.x;
+  int layer = 0;
+#pragma unroll
+  for (int l = 1; l < RON_MAX_LAYERS; ++l)
+    if (l < hd.num_layers && (int)blockIdx.x >= hd.block_base[l]) layer = l;
+  const int C = hd.num_classes;
+  const int n_anchor_layer = hd.cells[layer] * hd.num_anchors[layer];
+  const int first = ((int)blockIdx.x - hd.block_base[layer]) * kSelectThreads;
+  const int n_here = min(kSelectThreads, n_anchor_layer - first);
+  const float* cls = hd.cls[layer] + ((size_t)img * n_anchor_layer + first) * C;
+  for (int i = tid; i < n_here * C; i += kSelectThreads) stage[i] = cls[i];
+  __syncthreads();
+  if (tid >= n_here) return;
+  const int local = first + tid;
+  if (hd.obj[layer] != nullptr) {
+    float objp;
+    if (pc.flags & RON_IN_OBJ_IS_PROB) {
+      objp = hd.obj[layer][(size_t)img * n_anchor_layer + local];
+    } else {
+      const float2 o = *reinterpret_cast<const float2*>(hd.obj[layer] + ((size_t)img * n_anchor_layer + local) * 2);
+      const float m = fmaxf(o.x, o.y);
+      const float e0 = expf(o.x - m), e1 = expf(o.y - m);
+      objp = e1 / (e0 + e1);
+    }
+    if (!(objp > pc.obj_thr)) return;
+  }
+  const float* row = stage + tid * C;
+  const bool is_prob = (pc.flags & RON_IN_CLS_IS_PROB) != 0;
+  float sum = 1.f, mx = 0.f;
+  if (!is_prob) {
+    mx = row[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(row[c] - mx);
+    sum = s;
+  }
+  bool have_box = false, size_ok = true;
+  for (int c = 1; c < C; ++c) {
+    const float sc = is_prob ? row[c] : expf(row[c] - mx) / sum;
+    if (!(sc > pc.sel_thr)) continue;
+    if (!have_box) {
+      float box[4];
+      tfe_box(hd, pc, img, layer, local, box);
+      if (pc.min_size >= 0.f) {   // ron_vgg_320.py:222-225
+        const float h = box[2] - box[0], w = box[3] - box[1];
+        size_ok = (w > pc.min_size) && (h > pc.min_size);
+      }
+      have_box = true;
+    }
+    if (!size_ok) break;
+    const size_t list = (size_t)img * (C - 1) + (c - 1);
+    const int pos = atomicAdd(&counts[list], 1);
+    if (pos < cap) keys[list * cap + pos] = make_key(sc, (unsigned)(hd.anchor_base[layer] + local));
+  }
+}
+
+__global__ __launch_bounds__(kTopkThreads) void tfe_topk_nms_kernel(HeadsDev hd, TfeDev pc, const u64* keys,
+                                                                    const int* counts, int cap, float* out_scores,
+                                                                    float* out_boxes) {
+  __shared__ ImageLds lds;
+  const int c1 = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+  const int C1 = hd.num_classes - 1;
+  const size_t list = (size_t)img * C1 + c1;
+  const int m = min(counts[list], cap);
+  const int n = topk_keys(keys + list * cap, m, pc.top_k, lds);
+  for (int r = tid; r < n; r += blockDim.x) {
+    const u64 k = lds.sort[r];
+    const int anchor = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+    int layer = 0;
+#pragma unroll
+    for (int l = 1; l < RON_MAX_LAYERS; ++l)
+      if (l < hd.num_layers && anchor >= hd.anchor_base[l]) layer = l;
+    float box[4];
+    tfe_box(hd, pc, img, layer, anchor - hd.anchor_base[layer], box);
+    lds.box[r][0] = box[0]; lds.box[r][1] = box[1]; lds.box[r][2] = box[2]; lds.box[r][3] = box[3];
+    lds.score[r] = __uint_as_float((unsigned)(k >> 32));
+    lds.cls[r] = c1 + 1;
+    lds.anchor[r] = anchor;
+  }
+  __syncthreads();
+  nms_scan(lds, n, pc.nms_thr, pc.nms_mode == 1 ? 2 : 1, pc.keep_top_k);
+  float* os = out_scores + list * pc.keep_top_k;
+  float* ob = out_boxes + list * pc.keep_top_k * 4;
+  const int total = lds.scalars[4];
+  for (int i = tid; i < pc.keep_top_k; i += blockDim.x)
+    if (i >= total) { os[i] = 0.f; ob[i * 4 + 0] = 0.f; ob[i * 4 + 1] = 0.f; ob[i * 4 + 2] = 0.f; ob[i * 4 + 3] = 0.f; }
+  for (int i = tid; i < n; i += blockDim.x) {
+    const int pos = nms_slot(lds, i);
+    if (pos >= 0 && pos < pc.keep_top_k) {
+      os[pos] = lds.score[i];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ob[pos * 4 + q] = lds.box[i][q];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t ron_post_tfe_workspace_bytes(const ron_heads* heads, int n) {
+  HeadsDev hd;
+  if (build_heads_dev(heads, &hd, false) != RON_OK || n <= 0) return -1;
+  const int64_t lists = (int64_t)n * (heads->num_classes - 1);
+  return ron::align_up(lists * 4, 256) + lists * hd.anchor_base[RON_MAX_LAYERS] * 8;
+}
+
+extern "C" int ron_post_tfe(const ron_heads* heads, int n, const ron_tfe_cfg* cfg, void* workspace,
+                            int64_t workspace_bytes, float* scores, float* bboxes, void* stream) {
+  RON_REQUIRE(cfg != nullptr && n > 0 && scores != nullptr && bboxes != nullptr, "bad argument");
+  RON_REQUIRE(cfg->top_k >= 1 && cfg->top_k <= kMaxTopK, "top_k %d not in [1, %d]", cfg->top_k, kMaxTopK);
+  RON_REQUIRE(cfg->keep_top_k >= 1 && cfg->keep_top_k <= cfg->top_k, "keep_top_k %d not in [1, top_k]", cfg->keep_top_k);
+  RON_REQUIRE(cfg->nms_mode == 0 || cfg->nms_mode == 1, "unknown mode to use for nms.");
+  RON_REQUIRE(cfg->select_threshold >= 0.f, "select_threshold must be >= 0");
+  HeadsDev hd;
+  int rc = build_heads_dev(heads, &hd, (cfg->input_flags & RON_IN_LOC_DECODED) == 0);
+  if (rc != RON_OK) return rc;
+  const int64_t need = ron_post_tfe_workspace_bytes(heads, n);
+  RON_REQUIRE(workspace != nullptr && workspace_bytes >= need, "workspace too small: %lld < %lld",
+              (long long)workspace_bytes, (long long)need);
+  TfeDev pc;
+  pc.obj_thr = cfg->objectness_thres; pc.sel_thr = cfg->select_threshold; pc.nms_thr = cfg->nms_threshold;
+  pc.top_k = cfg->top_k; pc.keep_top_k = cfg->keep_top_k; pc.nms_mode = cfg->nms_mode; pc.clip = cfg->clip;
+  pc.min_size = cfg->min_size; pc.flags = cfg->input_flags;
+  for (int i = 0; i < 4; ++i) { pc.ref[i] = cfg->clipping_bbox[i]; pc.ps[i] = cfg->prior_scaling[i]; }
+  hipStream_t s = (hipStream_t)stream;
+  const int C1 = hd.num_classes - 1;
+  const int64_t lists = (int64_t)n * C1;
+  int* counts = (int*)workspace;
+  u64* keys = (u64*)((char*)workspace + ron::align_up(lists * 4, 256));
+  const int cap = hd.anchor_base[RON_MAX_LAYERS];
+  RON_HIP_CHECK(hipMemsetAsync(counts, 0, ron::align_up(lists * 4, 256), s));
+  const size_t lds = (size_t)kSelectThreads * hd.num_classes * sizeof(float);
+  hipLaunchKernelGGL(tfe_select_kernel, dim3(hd.block_base[RON_MAX_LAYERS], n), dim3(kSelectThreads), lds, s, hd, pc, keys,
+                     counts, cap);
+  hipLaunchKernelGGL(tfe_topk_nms_kernel, dim3(C1, n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, scores, bboxes);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
