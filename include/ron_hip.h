@@ -249,10 +249,16 @@ typedef struct {
   int32_t relu;
   int32_t transpose;
   int32_t dtype;            /* ron_dtype */
+  int32_t tile_cfg;         /* tile configuration of the conv kernel (csrc/conv_mfma.hip kCfgs); -1 = by shape */
+  int32_t in_cstride;       /* tooling: input laid out as a channel slice: elements per pixel (0 = cin) ...   */
+  int32_t in_coff;          /* ... and first channel of the slice                                              */
 } ron_conv_desc;
 int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const float* w, const float* bias,
                     const float* residual, float* y, void* stream);
 int ron_maxpool2x2_nhwc(const float* x, int n, int h, int w, int c, int dtype, float* y, void* stream);
+/* Tooling: time the conv kernel alone on random data (ms per launch, HIP events, default stream, synchronises). */
+int ron_conv2d_bench(const ron_conv_desc* d, int warmup, int iters, float* ms_per_launch);
+int ron_conv_num_tile_cfgs(void);
 
 #ifdef __cplusplus
 }

@@ -60,7 +60,8 @@ class Config(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cin', C.c_int32), ('cout', C.c_int32),
                 ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('dilation', C.c_int32),
-                ('relu', C.c_int32), ('transpose', C.c_int32), ('dtype', C.c_int32)]
+                ('relu', C.c_int32), ('transpose', C.c_int32), ('dtype', C.c_int32), ('tile_cfg', C.c_int32),
+                ('in_cstride', C.c_int32), ('in_coff', C.c_int32)]
 
 
 # every symbol include/ron_hip.h declares: (restype, argtypes)
@@ -100,6 +101,8 @@ SIGNATURES = {
     'ron_profile_reset': (C.c_int, [_P]),
     'ron_conv2d_nhwc': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'ron_maxpool2x2_nhwc': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    'ron_conv2d_bench': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    'ron_conv_num_tile_cfgs': (C.c_int, []),
 }
 
 _lib = None

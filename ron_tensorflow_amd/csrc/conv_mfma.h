@@ -35,18 +35,22 @@ struct ConvLaunch {
   int up = 0;
   int up_cout = 0;               // channels per tap of the transposed conv (Cout = up*up*up_cout)
   int Ho = 0, Wo = 0;            // GEMM rows = N*Ho*Wo (input grid for a transposed conv)
+  int cfg = -1;                  // tile configuration index (conv_mfma.hip kCfgs); -1 = pick by shape
 };
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream);
 // Elements along K one staging step covers for this dtype (Cin must be a multiple of it).
 int conv_k_chunk(int dtype);
-int conv_n_tile(int cout);       // N tile (64 or 128) the launcher picks for this Cout
+int conv_n_tile(int cout);       // granularity Cout is padded to (64 or 128)
+int conv_num_cfgs();
+int conv_pick_cfg(int M, int Npad, int K);
 size_t dtype_size(int dtype);
 
 // helpers (elementwise.hip)
 int launch_im2col_c3(const float* x, int n, int h, int w, int dtype, void* out, int kchunk, hipStream_t s);
 int launch_maxpool2x2(const TensorView& in, const TensorView& out, int dtype, hipStream_t s);
 int launch_pack_input(const float* x, const TensorView& out, int dtype, hipStream_t s);      // dense fp32 -> view
+int launch_fill_random(const TensorView& out, int dtype, unsigned seed, hipStream_t s);       // interior <- U[-1,1)
 int launch_unpack(const TensorView& in, int dtype, int in_is_f32, float* y, hipStream_t s);  // view -> dense fp32
 
 }  // namespace ron

@@ -31,6 +31,15 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+template <int N> struct alignas(4 * N) F32Vec { float v[N]; };
+template <int N> __device__ __forceinline__ void store_f32_vec(float* p, const float* v) {
+  F32Vec<N> t;
+#pragma unroll
+  for (int j = 0; j < N; ++j) t.v[j] = v[j];
+  *reinterpret_cast<F32Vec<N>*>(p) = t;
+}
+template <class E, int N> struct alignas(sizeof(E) * N) EVec { E v[N]; };
+
 struct ConvArgs {
   const void* in;
   unsigned in_bytes;
@@ -55,6 +64,7 @@ struct ConvArgs {
 struct TraitsBF16 {
   typedef __hip_bfloat16 elem;
   static constexpr int kEsz = 2;
+  static constexpr int kMfmaPerMma = 1;
   static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
   }
@@ -64,10 +74,22 @@ struct TraitsBF16 {
   static __device__ __forceinline__ void store(void* p, int i, float v) {
     reinterpret_cast<__hip_bfloat16*>(p)[i] = __float2bfloat16(v);
   }
+  template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
+    EVec<__hip_bfloat16, N> t;
+#pragma unroll
+    for (int j = 0; j < N; ++j) t.v[j] = __float2bfloat16(v[j]);
+    *reinterpret_cast<EVec<__hip_bfloat16, N>*>(reinterpret_cast<__hip_bfloat16*>(p) + i) = t;
+  }
+  template <int N> static __device__ __forceinline__ void load_vec(const void* p, int i, float* v) {
+    const EVec<__hip_bfloat16, N> t = *reinterpret_cast<const EVec<__hip_bfloat16, N>*>(reinterpret_cast<const __hip_bfloat16*>(p) + i);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = __bfloat162float(t.v[j]);
+  }
 };
 struct TraitsF16 {
   typedef _Float16 elem;
   static constexpr int kEsz = 2;
+  static constexpr int kMfmaPerMma = 1;
   static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
   }
@@ -77,10 +99,22 @@ struct TraitsF16 {
   static __device__ __forceinline__ void store(void* p, int i, float v) {
     reinterpret_cast<_Float16*>(p)[i] = (_Float16)v;
   }
+  template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
+    EVec<_Float16, N> t;
+#pragma unroll
+    for (int j = 0; j < N; ++j) t.v[j] = (_Float16)v[j];
+    *reinterpret_cast<EVec<_Float16, N>*>(reinterpret_cast<_Float16*>(p) + i) = t;
+  }
+  template <int N> static __device__ __forceinline__ void load_vec(const void* p, int i, float* v) {
+    const EVec<_Float16, N> t = *reinterpret_cast<const EVec<_Float16, N>*>(reinterpret_cast<const _Float16*>(p) + i);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = (float)t.v[j];
+  }
 };
 struct TraitsF32 {
   typedef float elem;
   static constexpr int kEsz = 4;
+  static constexpr int kMfmaPerMma = 4;
   static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
     // lane half h holds k = 4*(2s+h) + q, q = 0..3, for both operands: four exact-f32 MFMAs
     const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
@@ -91,29 +125,51 @@ struct TraitsF32 {
   }
   static __device__ __forceinline__ float load(const void* p, int i) { return reinterpret_cast<const float*>(p)[i]; }
   static __device__ __forceinline__ void store(void* p, int i, float v) { reinterpret_cast<float*>(p)[i] = v; }
+  template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
+    store_f32_vec<N>(reinterpret_cast<float*>(p) + i, v);
+  }
+  template <int N> static __device__ __forceinline__ void load_vec(const void* p, int i, float* v) {
+    const F32Vec<N> t = *reinterpret_cast<const F32Vec<N>*>(reinterpret_cast<const float*>(p) + i);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = t.v[j];
+  }
 };
 
-constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;   // one LDS row = one K chunk of one tile row
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <class Tr, int BM, int BN>
-__global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvArgs p) {
-  constexpr int MR = BM / 64, NR = BN / 64;          // 32x32 accumulators per wave: MR x NR
-  constexpr int A_IT = BM / 32, B_IT = BN / 32;      // LDS-DMA wave-instructions per thread and K step
+// all of this wave's LDS reads retired (the stage about to be refilled is no longer being read) and all but
+// its N youngest LDS-DMA transfers landed
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+// Tile configuration: BM x BN block tile, WM x WN waves (each wave owns (BM/WM) x (BN/WN)), S LDS stages.
+// The K loop keeps S-1 tiles in flight: one counted vmcnt + one raw s_barrier per K step, the LDS-DMA of
+// tile kt+S-1 is issued right after the barrier into the stage whose reads finished before it.
+// ABL (diagnostic builds only, outputs are wrong): 1 = no LDS-DMA (compute structure alone), 2 = no LDS reads / MFMA
+// (data movement alone).
+template <class Tr, int BM, int BN, int WM, int WN, int S, bool SPREAD, int ABL = 0>
+__global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
+  constexpr int kThreads = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
+  constexpr int MR = TM / 32, NR = TN / 32;          // 32x32 accumulators per wave: MR x NR
+  constexpr int kRowsPerIt = kThreads / 8;           // tile rows one LDS-DMA pass of the block covers
+  constexpr int A_IT = BM / kRowsPerIt, B_IT = BN / kRowsPerIt;
+  constexpr int LPT = A_IT + B_IT;                   // LDS-DMA instructions per thread and K step
   constexpr int kABytes = BM * kRowBytes, kBBytes = BN * kRowBytes;
   constexpr int kStage = kABytes + kBBytes;
   constexpr int kChunkElems = kRowBytes / Tr::kEsz;
+  static_assert(BM % kRowsPerIt == 0 && BN % kRowsPerIt == 0 && kRowsPerIt % 16 == 0, "tile / thread-count mismatch");
+  static_assert(TM % 32 == 0 && TN % 32 == 0 && S >= 2 && S <= 4, "bad wave tile / stage count");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // layout: [stage0: A | B][stage1: A | B][in_off: BM ints][out_off: BM ints]
-  int* s_in_off = reinterpret_cast<int*>(smem + 2 * kStage);
+  // layout: [stage 0 .. S-1: A | B][in_off: BM ints][out_off: BM ints]
+  int* s_in_off = reinterpret_cast<int*>(smem + S * kStage);
   int* s_out_off = s_in_off + BM;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   // XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) take consecutive tiles,
   // so the N-tiles that re-read one A tile hit the same L2.
@@ -126,8 +182,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // per-row addressing, once per tile
-  if (tid < BM) {
-    int m = m0 + tid;
+  for (int r = tid; r < BM; r += kThreads) {
+    int m = m0 + r;
     const bool valid = m < p.M;
     m = valid ? m : p.M - 1;
     const int hw = p.Ho * p.Wo;
@@ -136,15 +192,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvArgs p) {
     const int oy = rem / p.Wo;
     const int ox = rem - oy * p.Wo;
     const int iy = oy * p.stride + p.in_org, ix = ox * p.stride + p.in_org;
-    s_in_off[tid] = (((img * p.in_Hp + iy) * p.in_Wp + ix) * p.in_cstride + p.in_coff) * Tr::kEsz;
+    s_in_off[r] = (int)((((unsigned)(img * p.in_Hp + iy) * p.in_Wp + ix) * p.in_cstride + p.in_coff) * Tr::kEsz);
     const int os = p.up > 0 ? p.up : 1;
     const int off = ((img * p.out_Hp + oy * os + p.out_pad) * p.out_Wp + ox * os + p.out_pad) * p.out_cstride +
                     p.out_coff;
-    s_out_off[tid] = valid ? off : -1;
+    s_out_off[r] = valid ? off : -1;
   }
   __syncthreads();
 
-  // LDS-DMA source offsets (bytes): thread -> (row = it*32 + tid/8, slot = tid%8), source chunk = slot ^ key(row)
+  // LDS-DMA source offsets (bytes): thread -> (row = it*kRowsPerIt + tid/8, slot = tid%8), source chunk = slot ^ key(row)
   const int ld_row = tid >> 3;
   const int ld_chunk = (tid & 7) ^ ((tid >> 4) & 7);
   // fixed-size arrays on purpose: with a template-dependent bound the LDS-DMA builtin's voffset becomes a
@@ -152,32 +208,50 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvArgs p) {
   int a_voff[8], b_voff[8];
   static_assert(A_IT <= 8 && B_IT <= 8, "tile too large");
 #pragma unroll
-  for (int it = 0; it < A_IT; ++it) a_voff[it] = s_in_off[it * 32 + ld_row] + ld_chunk * 16;
+  for (int it = 0; it < A_IT; ++it) a_voff[it] = s_in_off[it * kRowsPerIt + ld_row] + ld_chunk * 16;
+  // B rows are permuted on the way in: LDS row (j*32 + r) of a wave's TN-wide group holds weight row (r*NR + j), so
+  // that MFMA column r of the wave's j-th 32-column tile is output channel r*NR + j: a lane's NR accumulators are NR
+  // adjacent channels and the epilogue stores them as one contiguous NR-element vector (full 128-B lines per row).
 #pragma unroll
-  for (int it = 0; it < B_IT; ++it) b_voff[it] = (n0 + it * 32 + ld_row) * p.K * Tr::kEsz + ld_chunk * 16;
+  for (int it = 0; it < B_IT; ++it) {
+    const int lrow = it * kRowsPerIt + ld_row;
+    const int grp = lrow / TN, loc = lrow % TN;
+    const int nrow = grp * TN + (loc & 31) * NR + (loc >> 5);
+    b_voff[it] = (n0 + nrow) * p.K * Tr::kEsz + ld_chunk * 16;
+  }
 
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
-
-  // K-step bookkeeping (wave-uniform): tap (ky, kx) and channel chunk cc
+  // K-step bookkeeping (wave-uniform): tap (ky, kx) and channel chunk cc of the NEXT tile to stage
   int ky = 0, kx = 0, cc = 0;
-#define RON_STAGE_LOAD(stage_, kt_)                                                                                  \
-  do {                                                                                                               \
+  // One tile = LPT LDS-DMA pieces per thread (A pieces first).  RON_STAGE_BEGIN computes the wave-uniform
+  // part once per tile, RON_STAGE_PIECE issues piece i (compile-time), RON_STAGE_END advances the tap.
+#define RON_STAGE_BEGIN(kt_)                                                                                         \
+    /* past the last tile: zero-record descriptors, the DMA moves nothing but keeps the vmcnt bookkeeping uniform */  \
+    const bool live_ = (kt_) < p.KT;                                                                                 \
+    const __amdgpu_buffer_rsrc_t rs_a =                                                                              \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, live_ ? p.in_bytes : 0u, 0x00020000);          \
+    const __amdgpu_buffer_rsrc_t rs_b =                                                                              \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, live_ ? p.wgt_bytes : 0u, 0x00020000);        \
     const int a_soff = ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz;                         \
     const int b_soff = (kt_) * kRowBytes;                                                                            \
-    char* dst = smem + (stage_) * kStage + wave * (8 * kRowBytes);                                                   \
-    _Pragma("unroll") for (int it = 0; it < A_IT; ++it)                                                              \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst + it * 32 * kRowBytes), 16, a_voff[it],      \
-                                                 a_soff, 0, 0);                                                      \
-    _Pragma("unroll") for (int it = 0; it < B_IT; ++it)                                                              \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(dst + kABytes + it * 32 * kRowBytes), 16,         \
-                                                 b_voff[it], b_soff, 0, 0);                                          \
-    cc += kChunkElems;                                                                                               \
-    if (cc >= p.Cin) {                                                                                               \
-      cc = 0;                                                                                                        \
-      if (++kx == p.kw) { kx = 0; ++ky; }                                                                            \
-    }                                                                                                                \
-  } while (0)
+    char* dst = smem + ((kt_) % S) * kStage + wave * (8 * kRowBytes);
+#define RON_STAGE_PIECE(i_)                                                                                          \
+    do {                                                                                                             \
+      if (ABL == 1) break;                                                                                           \
+      if ((i_) < A_IT)                                                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst + (i_) * kRowsPerIt * kRowBytes), 16,         \
+                                                 a_voff[(i_) < A_IT ? (i_) : 0], a_soff, 0, 0);                      \
+      else                                                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(dst + kABytes + ((i_) - A_IT) * kRowsPerIt * kRowBytes), 16, \
+                                                 b_voff[(i_) >= A_IT ? (i_) - A_IT : 0], b_soff, 0, 0);              \
+    } while (0)
+#define RON_STAGE_END()                                                                                              \
+    do {                                                                                                             \
+      cc += kChunkElems;                                                                                             \
+      if (cc >= p.Cin) {                                                                                             \
+        cc = 0;                                                                                                      \
+        if (++kx == p.kw) { kx = 0; ++ky; }                                                                          \
+      }                                                                                                              \
+    } while (0)
 
   f32x16 acc[MR][NR];
 #pragma unroll
@@ -192,31 +266,94 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvArgs p) {
   int rd_off[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) rd_off[s] = fr * kRowBytes + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
-  const int a_base = wm * (BM / 2) * kRowBytes;
-  const int b_base = kABytes + wn * (BN / 2) * kRowBytes;
+  const int a_base = wm * TM * kRowBytes;
+  const int b_base = kABytes + wn * TN * kRowBytes;
 
-  RON_STAGE_LOAD(0, 0);
-  __syncthreads();
+  // prologue: S-1 tiles in flight
+#pragma unroll
+  for (int t = 0; t < S - 1; ++t) {
+    RON_STAGE_BEGIN(t)
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) RON_STAGE_PIECE(i);
+    RON_STAGE_END();
+  }
+
   for (int kt = 0; kt < p.KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < p.KT) RON_STAGE_LOAD(cur ^ 1, kt + 1);
-    const char* sbuf = smem + cur * kStage;
+    wait_vmcnt<(S - 2) * LPT>();            // this wave's share of tile kt has landed
+    __builtin_amdgcn_s_barrier();           // ... everyone's has, and everyone is done reading tile kt-1
+    // refill the stage tile kt-1 occupied; the LPT pieces are spread over the four k-steps below so that
+    // their issue slots fall into the MFMA shadow instead of ahead of it (SPREAD) or are issued up front
+    RON_STAGE_BEGIN(kt + S - 1)
+    if (!SPREAD) {
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) RON_STAGE_PIECE(i);
+    }
+    const char* sbuf = smem + (kt % S) * kStage;
+    // fragments of k-step s+1 are read while the MFMAs of k-step s run (two register sets)
+    u32x4 fa[2][MR], fb[2][NR];
+    if (ABL == 2) {
+      if (SPREAD) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) RON_STAGE_PIECE(i);
+      }
+      RON_STAGE_END();
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < MR; ++i) fa[0][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * 32 * kRowBytes + rd_off[0]);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * 32 * kRowBytes + rd_off[0]);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      u32x4 fa[MR], fb[NR];
+      if (s < 3) {
 #pragma unroll
-      for (int i = 0; i < MR; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * 32 * kRowBytes + rd_off[s]);
+        for (int i = 0; i < MR; ++i)
+          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * 32 * kRowBytes + rd_off[(s + 1) & 3]);
 #pragma unroll
-      for (int j = 0; j < NR; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * 32 * kRowBytes + rd_off[s]);
+        for (int j = 0; j < NR; ++j)
+          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * 32 * kRowBytes + rd_off[(s + 1) & 3]);
+      }
+      if (SPREAD) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+          if ((i * 4) / LPT == s) RON_STAGE_PIECE(i);
+      }
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
-        for (int j = 0; j < NR; ++j) Tr::mma(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < NR; ++j) Tr::mma(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
     }
-    __syncthreads();
+    // Pin the issue order (hipcc otherwise sinks the next k-step's fragment reads below the MFMAs to save
+    // registers): R0 | (MFMA, read)* of k-steps 0..2 with the LDS-DMA pieces in the MFMA shadow | MFMAs of step 3.
+    {
+      constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma, PAIR = RD < MM ? RD : MM;
+      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        constexpr int kAll = SPREAD ? 0 : LPT;
+        const int pieces = SPREAD ? ((s + 1) * LPT + 3) / 4 - (s * LPT + 3) / 4 : (s == 0 ? kAll : 0);
+        (void)pieces;
+        if (s < 3) {
+#pragma unroll
+          for (int q = 0; q < PAIR; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          if (RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);      // up to LPT DMA pieces that belong here
+          if (MM > RD) __builtin_amdgcn_sched_group_barrier(0x008, MM - RD, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
+        }
+      }
+    }
+    RON_STAGE_END();
   }
+#undef RON_STAGE_BEGIN
+#undef RON_STAGE_PIECE
+#undef RON_STAGE_END
 
-#undef RON_STAGE_LOAD
   // epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
   int tap_off = 0, n_base = n0;
   if (p.up > 0) {
@@ -224,49 +361,113 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(ConvArgs p) {
     tap_off = ((tap / p.up) * p.out_Wp + (tap % p.up)) * p.out_cstride;
     n_base = n0 - tap * p.up_cout;
   }
+  // lane -> NR adjacent output channels starting at wn*TN + fr*NR
+  const int nloc = wn * TN + fr * NR;
   float bias_v[NR];
-  int ncol[NR];
-  bool nok[NR];
 #pragma unroll
-  for (int j = 0; j < NR; ++j) {
-    const int nn = wn * (BN / 2) + j * 32 + fr;
-    bias_v[j] = p.bias[n0 + nn];
-    ncol[j] = n_base + nn;
-    nok[j] = (n0 + nn) < p.Cout;
-  }
+  for (int j = 0; j < NR; ++j) bias_v[j] = p.bias[n0 + nloc + j];
+  const int n_valid = p.Cout - (n0 + nloc);            // channels of this lane's group that exist (may be <= 0)
+  const int ncol0 = n_base + nloc;
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int rt = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+      const int rt = wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
       const int ooff = s_out_off[rt];
-      if (ooff < 0) continue;
+      if (ooff < 0 || n_valid <= 0) continue;
+      const int o = ooff + tap_off + ncol0;
+      float v[NR];
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        if (!nok[j]) continue;
-        float v = acc[i][j][e] + bias_v[j];
-        if (p.relu) v = fmaxf(v, 0.f);
-        const int o = ooff + tap_off + ncol[j];
-        if (p.res != nullptr) v = fmaxf(v + Tr::load(p.res, o), 0.f);
-        if (p.out_f32) reinterpret_cast<float*>(p.out)[o] = v;
-        else Tr::store(p.out, o, v);
+        v[j] = acc[i][j][e] + bias_v[j];
+        if (p.relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (n_valid >= NR) {
+        if (p.res != nullptr) {
+          float rv[NR];
+          Tr::template load_vec<NR>(p.res, o, rv);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j] + rv[j], 0.f);
+        }
+        if (p.out_f32) store_f32_vec<NR>(reinterpret_cast<float*>(p.out) + o, v);
+        else Tr::template store_vec<NR>(p.out, o, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          if (j >= n_valid) break;
+          float x = v[j];
+          if (p.res != nullptr) x = fmaxf(x + Tr::load(p.res, o + j), 0.f);
+          if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = x;
+          else Tr::store(p.out, o + j, x);
+        }
       }
     }
   }
 }
 
-template <class Tr, int BM, int BN>
-int launch_t(const ConvArgs& a, int tiles_m, hipStream_t s) {
-  const size_t lds = 2 * (BM + BN) * kRowBytes + 2 * BM * sizeof(int);
+struct TileCfg { int bm, bn, wm, wn, stages, spread; };
+// index = ConvLaunch.cfg
+constexpr TileCfg kCfgs[] = {
+    {128, 128, 2, 2, 2, 0},   // 0: 64 KB LDS, 2 workgroups / CU (round-1 baseline structure)
+    {128, 64, 2, 2, 2, 0},    // 1
+    {256, 128, 4, 2, 3, 0},   // 2: 144 KB, 8 waves, 2 tiles in flight
+    {256, 64, 4, 2, 3, 0},    // 3
+    {128, 128, 2, 2, 2, 1},   // 4: as 0, DMA issue spread over the k-steps
+    {128, 64, 2, 2, 2, 1},    // 5
+    {256, 128, 4, 2, 3, 1},   // 6
+    {256, 64, 4, 2, 3, 1},    // 7
+    {256, 256, 2, 4, 2, 0},   // 8: 128 KB, 8 waves, wave tile 128 x 64 (the CDNA4 guide's 256^2 geometry)
+    {256, 256, 4, 2, 2, 0},   // 9: wave tile 64 x 128
+    {256, 256, 2, 4, 2, 1},   // 10
+    {256, 256, 4, 2, 2, 1},   // 11
+    {256, 256, 4, 2, 2, 1},   // 12: diagnostic, 11 without LDS-DMA
+    {256, 256, 4, 2, 2, 1},   // 13: diagnostic, 11 without LDS reads / MFMA
+    {128, 128, 2, 2, 2, 1},   // 14: diagnostic, 4 without LDS-DMA
+    {128, 128, 2, 2, 2, 1},   // 15: diagnostic, 4 without LDS reads / MFMA
+    {256, 256, 2, 2, 2, 1},   // 16: 4 waves, one per SIMD, wave tile 128 x 128 (256 accumulator registers)
+    {256, 256, 2, 2, 2, 1},   // 17: diagnostic, 16 without LDS-DMA
+};
+constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+
+template <class Tr, int BM, int BN, int WM, int WN, int S, bool SPREAD, int ABL = 0>
+int launch_t(const ConvArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)S * (BM + BN) * kRowBytes + 2 * BM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN>),
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN>), dim3(tiles_m * a.tiles_n), dim3(kThreads), lds, s, a);
+  const int tiles_m = (a.M + BM - 1) / BM;
+  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL>), dim3(tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
+}
+
+template <class Tr>
+int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
+  switch (cfg) {
+    case 0: return launch_t<Tr, 128, 128, 2, 2, 2, false>(a, s);
+    case 1: return launch_t<Tr, 128, 64, 2, 2, 2, false>(a, s);
+    case 2: return launch_t<Tr, 256, 128, 4, 2, 3, false>(a, s);
+    case 3: return launch_t<Tr, 256, 64, 4, 2, 3, false>(a, s);
+    case 4: return launch_t<Tr, 128, 128, 2, 2, 2, true>(a, s);
+    case 5: return launch_t<Tr, 128, 64, 2, 2, 2, true>(a, s);
+    case 6: return launch_t<Tr, 256, 128, 4, 2, 3, true>(a, s);
+    case 7: return launch_t<Tr, 256, 64, 4, 2, 3, true>(a, s);
+    case 8: return launch_t<Tr, 256, 256, 2, 4, 2, false>(a, s);
+    case 9: return launch_t<Tr, 256, 256, 4, 2, 2, false>(a, s);
+    case 10: return launch_t<Tr, 256, 256, 2, 4, 2, true>(a, s);
+    case 11: return launch_t<Tr, 256, 256, 4, 2, 2, true>(a, s);
+    case 12: return launch_t<Tr, 256, 256, 4, 2, 2, true, 1>(a, s);
+    case 13: return launch_t<Tr, 256, 256, 4, 2, 2, true, 2>(a, s);
+    case 14: return launch_t<Tr, 128, 128, 2, 2, 2, true, 1>(a, s);
+    case 15: return launch_t<Tr, 128, 128, 2, 2, 2, true, 2>(a, s);
+    case 16: return launch_t<Tr, 256, 256, 2, 2, 2, true>(a, s);
+    case 17: return launch_t<Tr, 256, 256, 2, 2, 2, true, 1>(a, s);
+  }
+  ron::set_error("conv: unknown tile config %d", cfg);
+  return RON_ERR_INVALID;
 }
 
 }  // namespace detail
@@ -275,6 +476,19 @@ using namespace detail;
 size_t dtype_size(int dtype) { return dtype == RON_DTYPE_F32 ? 4 : 2; }
 int conv_k_chunk(int dtype) { return kRowBytes / (int)dtype_size(dtype); }
 int conv_n_tile(int cout) { return cout <= 64 ? 64 : 128; }
+int conv_num_cfgs() { return kNumCfgs; }
+
+// Default tile choice, from tools/sweep_conv.py on MI355X at batch 32 (profiles/r01/sweep_*.txt):
+// the 256x256 tile wins once it yields >= ~160 workgroups, 256x128 (3 stages) down to ~190 workgroups, below that
+// the grid is the problem and the 128x128 / 2-workgroups-per-CU form keeps more CUs busy.
+int conv_pick_cfg(int M, int Npad, int K) {
+  (void)K;
+  const int tm256 = (M + 255) / 256;
+  if (Npad % 128 != 0) return 5;                                    // N tile 64
+  if (Npad % 256 == 0 && tm256 * (Npad / 256) >= 160) return 11;
+  if (tm256 * (Npad / 128) >= 190) return 6;
+  return 0;
+}
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   const int esz = (int)dtype_size(c.dtype);
@@ -284,17 +498,21 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   RON_REQUIRE(c.in.bytes > 0 && c.in.bytes < (int64_t)1 << 32, "conv: input allocation must be < 4 GiB for buffer addressing");
   RON_REQUIRE(c.wgt_bytes > 0 && c.wgt_bytes < (int64_t)1 << 32, "conv: weight allocation must be < 4 GiB");
   RON_REQUIRE((int64_t)c.out.N * c.out.Hp() * c.out.Wp() * c.out.cstride < (int64_t)1 << 31, "conv: output too large for 32-bit offsets");
-  const int BN = conv_n_tile(c.Cout);
+  const int K = c.kh * c.kw * c.in.C;
+  const int M = c.in.N * c.Ho * c.Wo;
+  const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg(M, c.Npad, K);
+  RON_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "conv: tile config %d out of range", cfg);
+  const int BN = kCfgs[cfg].bn;
   RON_REQUIRE(c.Npad % BN == 0, "conv: Npad %d not a multiple of the N tile %d", c.Npad, BN);
   if (c.up > 0) RON_REQUIRE(c.up_cout % BN == 0, "transposed conv: channels per tap %d not a multiple of %d", c.up_cout, BN);
   ConvArgs a;
   a.in = c.in.base; a.in_bytes = (unsigned)c.in.bytes;
   a.wgt = c.wgt; a.wgt_bytes = (unsigned)c.wgt_bytes;
   a.bias = c.bias; a.out = c.out.base; a.res = c.res;
-  a.Ho = c.Ho; a.Wo = c.Wo; a.M = c.in.N * c.Ho * c.Wo;
+  a.Ho = c.Ho; a.Wo = c.Wo; a.M = M;
   a.in_Hp = c.in.Hp(); a.in_Wp = c.in.Wp(); a.in_cstride = c.in.cstride; a.in_org = c.in.pad - c.cpad;
   a.in_coff = c.in.coff;
-  a.Cin = c.in.C; a.kw = c.kw; a.K = c.kh * c.kw * c.in.C; a.KT = a.K / chunk;
+  a.Cin = c.in.C; a.kw = c.kw; a.K = K; a.KT = a.K / chunk;
   a.stride = c.stride; a.dil = c.dil;
   a.Cout = c.Cout;
   a.out_Hp = c.out.Hp(); a.out_Wp = c.out.Wp(); a.out_cstride = c.out.cstride; a.out_pad = c.out.pad;
@@ -303,10 +521,9 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   a.relu = c.relu; a.out_f32 = c.out_f32;
   a.tiles_n = c.Npad / BN;
   RON_REQUIRE((int64_t)c.Npad * a.K * esz == c.wgt_bytes, "conv: packed weight size mismatch");
-  const int tiles_m = (a.M + 127) / 128;
-  if (c.dtype == RON_DTYPE_BF16) return BN == 64 ? launch_t<TraitsBF16, 128, 64>(a, tiles_m, stream) : launch_t<TraitsBF16, 128, 128>(a, tiles_m, stream);
-  if (c.dtype == RON_DTYPE_F16) return BN == 64 ? launch_t<TraitsF16, 128, 64>(a, tiles_m, stream) : launch_t<TraitsF16, 128, 128>(a, tiles_m, stream);
-  if (c.dtype == RON_DTYPE_F32) return BN == 64 ? launch_t<TraitsF32, 128, 64>(a, tiles_m, stream) : launch_t<TraitsF32, 128, 128>(a, tiles_m, stream);
+  if (c.dtype == RON_DTYPE_BF16) return launch_cfg<TraitsBF16>(cfg, a, stream);
+  if (c.dtype == RON_DTYPE_F16) return launch_cfg<TraitsF16>(cfg, a, stream);
+  if (c.dtype == RON_DTYPE_F32) return launch_cfg<TraitsF32>(cfg, a, stream);
   ron::set_error("conv: unknown dtype %d", c.dtype);
   return RON_ERR_INVALID;
 }

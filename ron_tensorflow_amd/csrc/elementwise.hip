@@ -120,6 +120,22 @@ __global__ void unpack_kernel(ViewDev in, float* __restrict__ y) {
   }
 }
 
+template <class T>
+__global__ void fill_random_kernel(ViewDev out, unsigned seed) {
+  const long long total = (long long)out.N * out.H * out.W * out.C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % out.C);
+    const long long pix = i / out.C;
+    const int px = (int)(pix % out.W);
+    const int py = (int)((pix / out.W) % out.H);
+    const long long img = pix / ((long long)out.W * out.H);
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const float v = (float)(h & 0xFFFF) / 32768.f - 1.f;          // uniform [-1, 1)
+    reinterpret_cast<T*>(out.base)[view_off(out, img, py, px) + c] = Cvt<T>::from_f(v);
+  }
+}
+
 int grid_for(long long total) { return (int)std::min<long long>((total + 255) / 256, 256 * 8); }
 
 }  // namespace
@@ -153,6 +169,15 @@ int launch_pack_input(const float* x, const TensorView& out, int dtype, hipStrea
   if (dtype == RON_DTYPE_BF16) hipLaunchKernelGGL(pack_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, s, x, to_dev(out));
   else if (dtype == RON_DTYPE_F16) hipLaunchKernelGGL(pack_kernel<_Float16>, dim3(g), dim3(256), 0, s, x, to_dev(out));
   else hipLaunchKernelGGL(pack_kernel<float>, dim3(g), dim3(256), 0, s, x, to_dev(out));
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+int launch_fill_random(const TensorView& out, int dtype, unsigned seed, hipStream_t s) {
+  const int g = grid_for((long long)out.N * out.H * out.W * out.C);
+  if (dtype == RON_DTYPE_BF16) hipLaunchKernelGGL(fill_random_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, s, to_dev(out), seed);
+  else if (dtype == RON_DTYPE_F16) hipLaunchKernelGGL(fill_random_kernel<_Float16>, dim3(g), dim3(256), 0, s, to_dev(out), seed);
+  else hipLaunchKernelGGL(fill_random_kernel<float>, dim3(g), dim3(256), 0, s, to_dev(out), seed);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }

@@ -6,9 +6,10 @@
 // MFMA implicit-GEMM kernel:
 //   * inference BatchNorm (eps 1e-5) is folded into the preceding conv at load time;
 //   * per scale, the three 3x3 convs that read the reference map (objectness hidden layer,
-//     inception-1 = 3x3 || 1x1 concat, box hidden layer) run as ONE conv with 2048 output
-//     channels (the 1x1 branch sits in the centre tap), consumers read channel slices;
-//   * inception-2 (3x3 || 1x1 on 1024 channels) is one conv with 1024 outputs;
+//     box hidden layer, inception-1 3x3 branch) run as ONE conv with 1536 output channels;
+//     the 1x1 branches run as their own 1x1 GEMMs (embedding them in the centre tap of a 3x3
+//     would execute 9x their MACs) and write their half of the concatenated tensor; the
+//     BatchNorm after each concat is split per branch and folded; consumers read channel slices;
 //   * the 2x2 stride-2 transposed conv is a GEMM with a pixel-shuffle epilogue, and the
 //     reverse-connection sum relu(left + up) is the epilogue of the left conv;
 //   * head logits are written as fp32 straight into the caller's buffers.
@@ -42,6 +43,8 @@ struct Var {
 struct Tensor {
   std::string name;
   int H, W, C, pad;
+  int cstride = 0;           // elements per pixel in memory (>= C): wide tensors get +64 so that the pixel stride
+                             // is not a power of two (4 KiB strides serialise on a few L2 channels)
   void* d = nullptr;
   int64_t bytes = 0;
 };
@@ -60,6 +63,7 @@ struct Op {
   std::string name;
   int in = -1, out = -1, res = -1;      // tensor indices; out == -2: caller head buffer
   int in_coff = 0, in_C = 0;            // channel slice of the input
+  int out_coff = 0, out_C = 0;          // channel slice of the output (out_C = 0: the whole tensor)
   int packed = -1;
   int kh = 1, kw = 1, stride = 1, dil = 1, cpad = 0, relu = 0;
   int up = 0, up_cout = 0;
@@ -103,6 +107,7 @@ struct ron_ctx {
   int add_tensor(const std::string& name, int H, int W, int C, int pad) {
     Tensor t;
     t.name = name; t.H = H; t.W = W; t.C = C; t.pad = pad;
+    t.cstride = C >= 1024 ? C + 64 : C;
     tensors.push_back(t);
     tensor_index[name] = (int)tensors.size() - 1;
     return (int)tensors.size() - 1;
@@ -118,7 +123,7 @@ struct ron_ctx {
   TensorView view(int t, int n, int coff = 0, int C = -1) const {
     const Tensor& T = tensors[t];
     TensorView v;
-    v.base = T.d; v.bytes = T.bytes; v.N = n; v.H = T.H; v.W = T.W; v.pad = T.pad; v.cstride = T.C;
+    v.base = T.d; v.bytes = T.bytes; v.N = n; v.H = T.H; v.W = T.W; v.pad = T.pad; v.cstride = T.cstride;
     v.coff = coff; v.C = C < 0 ? T.C : C;
     return v;
   }
@@ -203,14 +208,15 @@ struct Rows {
   }
   void add_bias(const Var& bv, int n_off) { for (size_t n = 0; n < bv.data.size(); ++n) b[n_off + n] += bv.data[n]; }
   // y = gamma * (x - mean) / sqrt(var + eps) + beta  folded into rows [n_off, n_off + ch)
-  void fold_bn(const ron_ctx* c, const std::string& scope, int n_off, int ch) {
+  void fold_bn(const ron_ctx* c, const std::string& scope, int n_off, int ch, int bn_off = 0) {
     const Var& be = c->var(scope + "/BatchNorm/beta"); const Var& ga = c->var(scope + "/BatchNorm/gamma");
     const Var& mu = c->var(scope + "/BatchNorm/moving_mean"); const Var& va = c->var(scope + "/BatchNorm/moving_variance");
     for (int n = 0; n < ch; ++n) {
-      const float s = ga.data[n] / sqrtf(va.data[n] + kBnEps);
+      const int q = bn_off + n;
+      const float s = ga.data[q] / sqrtf(va.data[q] + kBnEps);
       float* row = &w[(size_t)(n_off + n) * K];
       for (int k = 0; k < K; ++k) row[k] *= s;
-      b[n_off + n] = (b[n_off + n] - mu.data[n]) * s + be.data[n];
+      b[n_off + n] = (b[n_off + n] - mu.data[q]) * s + be.data[q];
     }
   }
 };
@@ -260,32 +266,33 @@ int pack_deconv(ron_ctx* c, const std::string& scope) {
   return upload(c, r, taps * co);
 }
 
-// rows 0..511 objectness hidden (conv+BN), 512..1535 inception1 (3x3 || 1x1, BN over the concat),
-// 1536..2047 box hidden (conv+BN)
-int pack_trio(ron_ctx* c, const std::string& L) {
+// The three 3x3 convs that read the reference map, as one GEMM with 1536 outputs:
+// rows 0..511 objectness hidden (conv+BN), 512..1023 box hidden (conv+BN), 1024..1535 inception-1 branch 0
+// (3x3 + bias, BN channels 0..511 of the concat).  Output channels [0, 1536) of the per-scale "hcat" tensor.
+int pack_trio3(ron_ctx* c, const std::string& L) {
   Rows r;
-  r.init(3, 3, 512, 2048, 128);
+  r.init(3, 3, 512, 1536, 256);
   r.place(c->var(L + "_objectness/weights"), 0);
   r.fold_bn(c, L + "_objectness", 0, 512);
-  r.place(c->var(L + "_inception1/Branch_0/Conv2d_3x3/weights"), 512);
-  r.add_bias(c->var(L + "_inception1/Branch_0/Conv2d_3x3/biases"), 512);
-  r.place(c->var(L + "_inception1/Branch_1/Conv2d_1x1/weights"), 1024);
-  r.add_bias(c->var(L + "_inception1/Branch_1/Conv2d_1x1/biases"), 1024);
-  r.fold_bn(c, L + "_inception1", 512, 1024);
-  r.place(c->var(L + "/Conv2d_0_3x3/weights"), 1536);
-  r.fold_bn(c, L + "/Conv2d_0_3x3", 1536, 512);
-  return upload(c, r, 2048);
+  r.place(c->var(L + "/Conv2d_0_3x3/weights"), 512);
+  r.fold_bn(c, L + "/Conv2d_0_3x3", 512, 512);
+  r.place(c->var(L + "_inception1/Branch_0/Conv2d_3x3/weights"), 1024);
+  r.add_bias(c->var(L + "_inception1/Branch_0/Conv2d_3x3/biases"), 1024);
+  r.fold_bn(c, L + "_inception1", 1024, 512, 0);
+  return upload(c, r, 1536);
 }
 
-int pack_inception2(ron_ctx* c, const std::string& L) {
+// One branch of an "inception" block (nets/ron_vgg_320.py:378-397): conv + bias, then its half of the BatchNorm
+// that follows the concat (branch 0 = channels 0..511, branch 1 = 512..1023), ReLU in the kernel epilogue.
+int pack_branch(ron_ctx* c, const std::string& I, int branch) {
+  const std::string scope = I + (branch == 0 ? "/Branch_0/Conv2d_3x3" : "/Branch_1/Conv2d_1x1");
+  const Var& w = c->var(scope + "/weights");
   Rows r;
-  r.init(3, 3, 1024, 1024, 128);
-  r.place(c->var(L + "_inception2/Branch_0/Conv2d_3x3/weights"), 0);
-  r.add_bias(c->var(L + "_inception2/Branch_0/Conv2d_3x3/biases"), 0);
-  r.place(c->var(L + "_inception2/Branch_1/Conv2d_1x1/weights"), 512);
-  r.add_bias(c->var(L + "_inception2/Branch_1/Conv2d_1x1/biases"), 512);
-  r.fold_bn(c, L + "_inception2", 0, 1024);
-  return upload(c, r, 1024);
+  r.init((int)w.shape[0], (int)w.shape[1], (int)w.shape[2], 512, 256);
+  r.place(w, 0);
+  r.add_bias(c->var(scope + "/biases"), 0);
+  r.fold_bn(c, I, 0, 512, branch * 512);
+  return upload(c, r, 512);
 }
 
 Op conv_op(const std::string& name, int in, int out, int packed, int k, int cpad, int relu, int Ho, int Wo) {
@@ -342,7 +349,7 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
     c->add_tensor(L + "_inc2", s_h, s_w, 1024, 1);
   }
   for (auto& t : c->tensors) {
-    t.bytes = (int64_t)cfg->max_batch * (t.H + 2 * t.pad) * (t.W + 2 * t.pad) * t.C * c->esz();
+    t.bytes = (int64_t)cfg->max_batch * (t.H + 2 * t.pad) * (t.W + 2 * t.pad) * t.cstride * c->esz();
     if (t.bytes >= ((int64_t)1 << 32)) {
       ron::set_error("tensor %s needs %lld bytes for max_batch %d: above the 4 GiB buffer-addressing limit; lower max_batch",
                      t.name.c_str(), (long long)t.bytes, cfg->max_batch);
@@ -477,11 +484,22 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       c->ops.push_back(o);
     }
     flops += conv_flops(c->var(L + "_conv_left/weights"), sh * sw); ATTR();
-    PACK(pack_trio(c, L));
-    c->ops.push_back(conv_op(Ln + "_trio", T(Ln + "_ref"), T(Ln + "_hcat"), rc, 3, 1, 1, sh, sw));
-    flops += conv_flops(c->var(L + "_objectness/weights"), sh * sw) + conv_flops(c->var(L + "/Conv2d_0_3x3/weights"), sh * sw) +
-             conv_flops(c->var(L + "_inception1/Branch_0/Conv2d_3x3/weights"), sh * sw) +
-             conv_flops(c->var(L + "_inception1/Branch_1/Conv2d_1x1/weights"), sh * sw); ATTR();
+    // hcat channels: [0,512) objectness hidden | [512,1024) box hidden | [1024,1536) inception-1 3x3 | [1536,2048) inception-1 1x1
+    PACK(pack_trio3(c, L));
+    {
+      Op o = conv_op(Ln + "_trio3", T(Ln + "_ref"), T(Ln + "_hcat"), rc, 3, 1, 1, sh, sw);
+      o.out_coff = 0;
+      c->ops.push_back(o);
+      flops += conv_flops(c->var(L + "_objectness/weights"), sh * sw) + conv_flops(c->var(L + "/Conv2d_0_3x3/weights"), sh * sw) +
+               conv_flops(c->var(L + "_inception1/Branch_0/Conv2d_3x3/weights"), sh * sw); ATTR();
+    }
+    PACK(pack_branch(c, L + "_inception1", 1));
+    {
+      Op o = conv_op(Ln + "_inception1_1x1", T(Ln + "_ref"), T(Ln + "_hcat"), rc, 1, 0, 1, sh, sw);
+      o.out_coff = 1536;
+      c->ops.push_back(o);
+      flops += conv_flops(c->var(L + "_inception1/Branch_1/Conv2d_1x1/weights"), sh * sw); ATTR();
+    }
     PACK(pack_plain(c, L + "_objectness_score", false));
     {
       Op o = conv_op(Ln + "_objectness_score", T(Ln + "_hcat"), -2, rc, 3, 1, 0, sh, sw);
@@ -489,13 +507,19 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       c->ops.push_back(o);
       flops += conv_flops(c->var(L + "_objectness_score/weights"), sh * sw); ATTR();
     }
-    PACK(pack_inception2(c, L));
+    PACK(pack_branch(c, L + "_inception2", 0));
     {
-      Op o = conv_op(Ln + "_inception2", T(Ln + "_hcat"), T(Ln + "_inc2"), rc, 3, 1, 1, sh, sw);
-      o.in_coff = 512; o.in_C = 1024;
+      Op o = conv_op(Ln + "_inception2_3x3", T(Ln + "_hcat"), T(Ln + "_inc2"), rc, 3, 1, 1, sh, sw);
+      o.in_coff = 1024; o.in_C = 1024; o.out_coff = 0;
       c->ops.push_back(o);
-      flops += conv_flops(c->var(L + "_inception2/Branch_0/Conv2d_3x3/weights"), sh * sw) +
-               conv_flops(c->var(L + "_inception2/Branch_1/Conv2d_1x1/weights"), sh * sw); ATTR();
+      flops += conv_flops(c->var(L + "_inception2/Branch_0/Conv2d_3x3/weights"), sh * sw); ATTR();
+    }
+    PACK(pack_branch(c, L + "_inception2", 1));
+    {
+      Op o = conv_op(Ln + "_inception2_1x1", T(Ln + "_hcat"), T(Ln + "_inc2"), rc, 1, 0, 1, sh, sw);
+      o.in_coff = 1024; o.in_C = 1024; o.out_coff = 512;
+      c->ops.push_back(o);
+      flops += conv_flops(c->var(L + "_inception2/Branch_1/Conv2d_1x1/weights"), sh * sw); ATTR();
     }
     PACK(pack_plain(c, L + "_inception2/Conv2d_pred_3x3", false));
     {
@@ -507,7 +531,7 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
     PACK(pack_plain(c, L + "/Conv2d_1_3x3", false));
     {
       Op o = conv_op(Ln + "_loc_pred", T(Ln + "_hcat"), -2, rc, 3, 1, 0, sh, sw);
-      o.in_coff = 1536; o.in_C = 512; o.head_kind = 2; o.head_layer = i;
+      o.in_coff = 512; o.in_C = 512; o.head_kind = 2; o.head_layer = i;
       c->ops.push_back(o);
       flops += conv_flops(c->var(L + "/Conv2d_1_3x3/weights"), sh * sw); ATTR();
     }
@@ -582,7 +606,7 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
         L.out = v;
         L.out_f32 = 1;
       } else {
-        L.out = c->view(o.out, n);
+        L.out = c->view(o.out, n, o.out_coff, o.out_C > 0 ? o.out_C : -1);
       }
       L.res = o.res >= 0 ? c->tensors[o.res].d : nullptr;
       L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.bias = p.d_bias; L.Cout = p.Cout; L.Npad = p.Npad;

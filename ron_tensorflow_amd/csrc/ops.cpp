@@ -1,6 +1,8 @@
 // Single-operator entry points (ron_conv2d_nhwc, ron_maxpool2x2_nhwc): the same kernels the
 // graph launches, wrapped with dense-fp32 <-> halo-tensor conversion so that the parity tests
 // can pin each kernel against the oracle.  They allocate scratch and synchronise: test/tool use.
+#include <math.h>
+
 #include <vector>
 
 #include "pack.h"
@@ -24,30 +26,33 @@ ron::TensorView make_view(void* base, int n, int h, int w, int c, int pad, int e
   return v;
 }
 
-}  // namespace
+struct ConvSetup {
+  ron::ConvLaunch c;
+  DevBuf d_w, d_b, d_in, d_out, d_res;
+  int ho = 0, wo = 0;
+  bool is_c3 = false;
+};
 
-extern "C" int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const float* w, const float* bias,
-                               const float* residual, float* y, void* stream) {
+// Packs weights like ron_finalize_weights does, uploads them and allocates the halo tensors.
+int setup_conv(const ron_conv_desc* d, const float* w, const float* bias, bool with_residual, ConvSetup* S) {
   using namespace ron;
-  RON_REQUIRE(d && x && w && y, "NULL argument");
   RON_REQUIRE(d->dtype >= 0 && d->dtype <= 2, "bad dtype");
-  hipStream_t s = (hipStream_t)stream;
   const int esz = (int)dtype_size(d->dtype);
   const int chunk = conv_k_chunk(d->dtype);
-  const bool is_c3 = (!d->transpose && d->cin == 3 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1);
-  RON_REQUIRE(is_c3 || d->cin % chunk == 0, "cin %d must be a multiple of %d (or the 3-channel 3x3 stem)", d->cin, chunk);
-  int ho, wo, cpad = 0;
-  ConvLaunch c;
+  S->is_c3 = (!d->transpose && d->cin == 3 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1);
+  RON_REQUIRE(S->is_c3 || d->cin % chunk == 0, "cin %d must be a multiple of %d (or the 3-channel 3x3 stem)", d->cin, chunk);
+  int cpad = 0;
+  ConvLaunch& c = S->c;
   c.dtype = d->dtype;
+  c.cfg = d->tile_cfg;
   std::vector<float> rows;
   std::vector<float> bias_pad;
   int cout_gemm;
   if (d->transpose) {
     RON_REQUIRE(d->kh == d->kw && d->kh == d->stride && d->dilation == 1, "transposed conv needs kernel == stride");
-    ho = d->h * d->stride; wo = d->w * d->stride;
+    S->ho = d->h * d->stride; S->wo = d->w * d->stride;
     cout_gemm = d->kh * d->kw * d->cout;
-    const int BN = conv_n_tile(cout_gemm);
-    RON_REQUIRE(d->cout % BN == 0, "transposed conv: cout %d must be a multiple of %d", d->cout, BN);
+    RON_REQUIRE(d->cout % 128 == 0, "transposed conv: cout %d must be a multiple of 128", d->cout);
     c.Npad = cout_gemm;
     // TF layout [kh,kw,cout,cin] -> rows[(t*cout + co)][ci]
     rows.assign((size_t)cout_gemm * d->cin, 0.f);
@@ -61,11 +66,10 @@ extern "C" int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const flo
     RON_REQUIRE(d->stride == 1 || (d->h % d->stride == 0 && d->w % d->stride == 0 && d->kh == d->stride),
                 "strided conv: only kernel == stride on divisible maps");
     cpad = d->stride == 1 ? ((d->kh - 1) * d->dilation) / 2 : 0;   // SAME
-    ho = d->h / d->stride; wo = d->w / d->stride;
+    S->ho = d->h / d->stride; S->wo = d->w / d->stride;
     cout_gemm = d->cout;
-    const int BN = conv_n_tile(cout_gemm);
-    c.Npad = round_up(cout_gemm, BN);
-    if (is_c3) {
+    c.Npad = round_up(cout_gemm, conv_n_tile(cout_gemm));
+    if (S->is_c3) {
       rows.assign((size_t)c.Npad * chunk, 0.f);
       for (int k = 0; k < 27; ++k) for (int n = 0; n < d->cout; ++n) rows[(size_t)n * chunk + k] = w[(size_t)k * d->cout + n];
       c.kh = c.kw = 1; c.cpad = 0;
@@ -76,44 +80,92 @@ extern "C" int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const flo
     bias_pad.assign(c.Npad, 0.f);
     if (bias) for (int n = 0; n < d->cout; ++n) bias_pad[n] = bias[n];
     c.stride = d->stride; c.dil = d->dilation;
-    c.Ho = ho; c.Wo = wo;
+    c.Ho = S->ho; c.Wo = S->wo;
   }
   c.Cout = cout_gemm;
   c.relu = d->relu;
   std::vector<uint8_t> wbytes = cast_rows(rows, d->dtype);
-
-  DevBuf d_w, d_b, d_in, d_out, d_res;
   int rc;
-  if ((rc = d_w.alloc((int64_t)wbytes.size(), false))) return rc;
-  if ((rc = d_b.alloc((int64_t)bias_pad.size() * 4, false))) return rc;
-  RON_HIP_CHECK(hipMemcpy(d_w.p, wbytes.data(), wbytes.size(), hipMemcpyHostToDevice));
-  RON_HIP_CHECK(hipMemcpy(d_b.p, bias_pad.data(), bias_pad.size() * 4, hipMemcpyHostToDevice));
-  c.wgt = d_w.p; c.wgt_bytes = (int64_t)wbytes.size(); c.bias = (const float*)d_b.p;
+  if ((rc = S->d_w.alloc((int64_t)wbytes.size(), false))) return rc;
+  if ((rc = S->d_b.alloc((int64_t)bias_pad.size() * 4, false))) return rc;
+  RON_HIP_CHECK(hipMemcpy(S->d_w.p, wbytes.data(), wbytes.size(), hipMemcpyHostToDevice));
+  RON_HIP_CHECK(hipMemcpy(S->d_b.p, bias_pad.data(), bias_pad.size() * 4, hipMemcpyHostToDevice));
+  c.wgt = S->d_w.p; c.wgt_bytes = (int64_t)wbytes.size(); c.bias = (const float*)S->d_b.p;
+  if (S->is_c3) c.in = make_view(nullptr, d->n, d->h, d->w, chunk, 0, esz);
+  else {
+    const int cs = d->in_cstride > 0 ? d->in_cstride : d->cin;
+    RON_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= cs, "bad channel slice");
+    c.in = make_view(nullptr, d->n, d->h, d->w, cs, cpad, esz);     // allocation of the wide tensor
+    c.in.C = d->cin;
+    c.in.coff = d->in_coff;
+  }
+  if ((rc = S->d_in.alloc(c.in.bytes, true))) return rc;
+  c.in.base = S->d_in.p;
+  c.out = make_view(nullptr, d->n, S->ho, S->wo, d->cout, 1, esz);   // halo 1: exercises padded stores
+  if ((rc = S->d_out.alloc(c.out.bytes, true))) return rc;
+  c.out.base = S->d_out.p;
+  if (with_residual) {
+    if ((rc = S->d_res.alloc(c.out.bytes, true))) return rc;
+    c.res = S->d_res.p;
+  }
+  return RON_OK;
+}
 
-  if (is_c3) {
-    c.in = make_view(nullptr, d->n, d->h, d->w, chunk, 0, esz);
-    if ((rc = d_in.alloc(c.in.bytes, false))) return rc;
-    c.in.base = d_in.p;
-    if ((rc = launch_im2col_c3(x, d->n, d->h, d->w, d->dtype, d_in.p, chunk, s))) return rc;
+}  // namespace
+
+extern "C" int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const float* w, const float* bias,
+                               const float* residual, float* y, void* stream) {
+  using namespace ron;
+  RON_REQUIRE(d && x && w && y, "NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvSetup S;
+  int rc;
+  if ((rc = setup_conv(d, w, bias, residual != nullptr, &S))) return rc;
+  if (S.is_c3) {
+    if ((rc = launch_im2col_c3(x, d->n, d->h, d->w, d->dtype, S.d_in.p, S.c.in.C, s))) return rc;
   } else {
-    c.in = make_view(nullptr, d->n, d->h, d->w, d->cin, cpad, esz);
-    if ((rc = d_in.alloc(c.in.bytes, true))) return rc;
-    c.in.base = d_in.p;
-    if ((rc = launch_pack_input(x, c.in, d->dtype, s))) return rc;
+    if ((rc = launch_pack_input(x, S.c.in, d->dtype, s))) return rc;
   }
-  c.out = make_view(nullptr, d->n, ho, wo, d->cout, 1, esz);   // halo 1: exercises padded stores
-  if ((rc = d_out.alloc(c.out.bytes, true))) return rc;
-  c.out.base = d_out.p;
   if (residual) {
-    TensorView rv = c.out;
-    if ((rc = d_res.alloc(rv.bytes, true))) return rc;
-    rv.base = d_res.p;
+    TensorView rv = S.c.out;
+    rv.base = S.d_res.p;
     if ((rc = launch_pack_input(residual, rv, d->dtype, s))) return rc;
-    c.res = d_res.p;
   }
-  if ((rc = launch_conv(c, s))) return rc;
-  if ((rc = launch_unpack(c.out, d->dtype, 0, y, s))) return rc;
+  if ((rc = launch_conv(S.c, s))) return rc;
+  if ((rc = launch_unpack(S.c.out, d->dtype, 0, y, s))) return rc;
   RON_HIP_CHECK(hipStreamSynchronize(s));
+  return RON_OK;
+}
+
+// Times the conv kernel alone on random data (tools/sweep_conv.py): ms per launch over `iters` launches.
+extern "C" int ron_conv2d_bench(const ron_conv_desc* d, int warmup, int iters, float* ms_per_launch) {
+  using namespace ron;
+  RON_REQUIRE(d && ms_per_launch && iters > 0 && warmup >= 0, "bad argument");
+  RON_REQUIRE(!(d->cin == 3), "the 3-channel stem is not benchmarked through this entry");
+  const size_t wn = (size_t)d->kh * d->kw * d->cin * d->cout;
+  std::vector<float> w(wn), b(d->cout);
+  uint32_t st = 12345u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.f - 1.f; };
+  const float scale = 1.f / sqrtf((float)(d->kh * d->kw * d->cin));
+  for (auto& v : w) v = rnd() * scale;
+  for (auto& v : b) v = rnd() * 0.1f;
+  ConvSetup S;
+  int rc;
+  if ((rc = setup_conv(d, w.data(), b.data(), false, &S))) return rc;
+  if ((rc = launch_fill_random(S.c.in, d->dtype, 777u, nullptr))) return rc;
+  hipEvent_t e0, e1;
+  RON_HIP_CHECK(hipEventCreate(&e0));
+  RON_HIP_CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < warmup; ++i) if ((rc = launch_conv(S.c, nullptr))) return rc;
+  RON_HIP_CHECK(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters; ++i) if ((rc = launch_conv(S.c, nullptr))) return rc;
+  RON_HIP_CHECK(hipEventRecord(e1, nullptr));
+  RON_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  RON_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_launch = ms / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return RON_OK;
 }
 
@@ -135,3 +187,5 @@ extern "C" int ron_maxpool2x2_nhwc(const float* x, int n, int h, int w, int c, i
   RON_HIP_CHECK(hipStreamSynchronize(s));
   return RON_OK;
 }
+
+extern "C" int ron_conv_num_tile_cfgs(void) { return ron::conv_num_cfgs(); }

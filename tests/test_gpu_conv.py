@@ -114,3 +114,26 @@ def test_maxpool(ops, dev, dtype):
     x = ROUND[dtype](rs.randn(2, 8, 12, 64).astype(np.float32))
     got = ops.maxpool2x2_nhwc(torch.from_numpy(x).to(dev), dtype=dtype).cpu().numpy()
     assert np.array_equal(got, orf.max_pool2x2_np(x))
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16])
+def test_every_tile_configuration(ops, dev, cfg, dtype):
+    """Each (tile, wave grid, stage count) variant of the kernel on a ragged multi-tile problem, K = 18 steps."""
+    from ron_tensorflow_amd import _lib
+    assert _lib.lib().ron_conv_num_tile_cfgs() == 18
+    rs = np.random.RandomState(40 + cfg)
+    x = rs.randn(3, 13, 11, 128).astype(np.float32)            # M = 429: two 256-row or four 128-row tiles, ragged
+    wt = (rs.randn(3, 3, 128, 192) * 0.03).astype(np.float32)  # Cout 192 -> padded to 256
+    b = (rs.randn(192) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=cfg).cpu().numpy()
+    _check(got, ref, dtype)
+    # K = 1 step and K = 2 steps (shorter than the pipeline depth)
+    for cin, k in ((64, 1), (128, 1)):
+        x2 = rs.randn(2, 9, 9, cin).astype(np.float32)
+        w2 = (rs.randn(k, k, cin, 256) * 0.1).astype(np.float32)
+        ref2 = orf.conv2d_np(rnd(x2), rnd(w2))
+        got2 = ops.conv2d_nhwc(torch.from_numpy(x2).to(dev), w2, None, relu=False, dtype=dtype, tile_cfg=cfg).cpu().numpy()
+        _check(got2, ref2, dtype)
