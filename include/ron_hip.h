@@ -252,6 +252,7 @@ typedef struct {
   int32_t tile_cfg;         /* tile configuration of the conv kernel (csrc/conv_mfma.hip kCfgs); -1 = by shape */
   int32_t in_cstride;       /* tooling: input laid out as a channel slice: elements per pixel (0 = cin) ...   */
   int32_t in_coff;          /* ... and first channel of the slice                                              */
+  int32_t splitk;           /* split-K factor: -1 = by grid size, 1 = off                                      */
 } ron_conv_desc;
 int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const float* w, const float* bias,
                     const float* residual, float* y, void* stream);

@@ -36,6 +36,9 @@ struct ConvLaunch {
   int up_cout = 0;               // channels per tap of the transposed conv (Cout = up*up*up_cout)
   int Ho = 0, Wo = 0;            // GEMM rows = N*Ho*Wo (input grid for a transposed conv)
   int cfg = -1;                  // tile configuration index (conv_mfma.hip kCfgs); -1 = pick by shape
+  int splitk = -1;               // split-K factor; -1 = pick by grid size, 1 = off
+  void* scratch = nullptr;       // fp32 slabs for split-K (conv_scratch_bytes); null disables split-K
+  int64_t scratch_bytes = 0;
 };
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream);
@@ -44,6 +47,8 @@ int conv_k_chunk(int dtype);
 int conv_n_tile(int cout);       // granularity Cout is padded to (64 or 128)
 int conv_num_cfgs();
 int conv_pick_cfg(int M, int Npad, int K);
+int conv_pick_splitk(int tiles, int KT, int slots);
+int64_t conv_scratch_bytes(int M, int Npad, int K, int dtype, int cfg, int splitk);
 size_t dtype_size(int dtype);
 
 // helpers (elementwise.hip)

@@ -59,6 +59,10 @@ struct ConvArgs {
   int up, up_cout;
   int relu, out_f32;
   int tiles_n;
+  // split-K: workgroup z of `splitk` covers K steps [z*kt_split, (z+1)*kt_split) and stores raw fp32 sums to
+  // partial[z][m][n] (n < Npad); splitk_finalize_kernel adds the slabs and applies the epilogue.
+  int splitk, kt_split, tiles_total, Npad;
+  float* partial;
 };
 
 struct TraitsBF16 {
@@ -177,9 +181,13 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
   const unsigned bid = blockIdx.x;
   const unsigned xcd = bid & 7u, q = nwg >> 3, r8 = nwg & 7u;
   const unsigned wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-  const int tile_n = (int)(wgid % (unsigned)p.tiles_n);
-  const int tile_m = (int)(wgid / (unsigned)p.tiles_n);
+  const int zsplit = (int)(wgid / (unsigned)p.tiles_total);
+  const unsigned tile = wgid - (unsigned)zsplit * (unsigned)p.tiles_total;
+  const int tile_n = (int)(tile % (unsigned)p.tiles_n);
+  const int tile_m = (int)(tile / (unsigned)p.tiles_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kt0 = zsplit * p.kt_split;
+  const int kt1 = min(p.KT, kt0 + p.kt_split);
 
   // per-row addressing, once per tile
   for (int r = tid; r < BM; r += kThreads) {
@@ -221,19 +229,21 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
   }
 
   // K-step bookkeeping (wave-uniform): tap (ky, kx) and channel chunk cc of the NEXT tile to stage
-  int ky = 0, kx = 0, cc = 0;
+  const int chunks_per_tap = p.Cin / kChunkElems;
+  const int tap0 = kt0 / chunks_per_tap;
+  int ky = tap0 / p.kw, kx = tap0 - (tap0 / p.kw) * p.kw, cc = (kt0 - tap0 * chunks_per_tap) * kChunkElems;
   // One tile = LPT LDS-DMA pieces per thread (A pieces first).  RON_STAGE_BEGIN computes the wave-uniform
   // part once per tile, RON_STAGE_PIECE issues piece i (compile-time), RON_STAGE_END advances the tap.
 #define RON_STAGE_BEGIN(kt_)                                                                                         \
     /* past the last tile: zero-record descriptors, the DMA moves nothing but keeps the vmcnt bookkeeping uniform */  \
-    const bool live_ = (kt_) < p.KT;                                                                                 \
+    const bool live_ = (kt_) < kt1;                                                                                  \
     const __amdgpu_buffer_rsrc_t rs_a =                                                                              \
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, live_ ? p.in_bytes : 0u, 0x00020000);          \
     const __amdgpu_buffer_rsrc_t rs_b =                                                                              \
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, live_ ? p.wgt_bytes : 0u, 0x00020000);        \
     const int a_soff = ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz;                         \
     const int b_soff = (kt_) * kRowBytes;                                                                            \
-    char* dst = smem + ((kt_) % S) * kStage + wave * (8 * kRowBytes);
+    char* dst = smem + (((kt_) - kt0) % S) * kStage + wave * (8 * kRowBytes);
 #define RON_STAGE_PIECE(i_)                                                                                          \
     do {                                                                                                             \
       if (ABL == 1) break;                                                                                           \
@@ -272,13 +282,13 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
   // prologue: S-1 tiles in flight
 #pragma unroll
   for (int t = 0; t < S - 1; ++t) {
-    RON_STAGE_BEGIN(t)
+    RON_STAGE_BEGIN(kt0 + t)
 #pragma unroll
     for (int i = 0; i < LPT; ++i) RON_STAGE_PIECE(i);
     RON_STAGE_END();
   }
 
-  for (int kt = 0; kt < p.KT; ++kt) {
+  for (int kt = kt0; kt < kt1; ++kt) {
     wait_vmcnt<(S - 2) * LPT>();            // this wave's share of tile kt has landed
     __builtin_amdgcn_s_barrier();           // ... everyone's has, and everyone is done reading tile kt-1
     // refill the stage tile kt-1 occupied; the LPT pieces are spread over the four k-steps below so that
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
 #pragma unroll
       for (int i = 0; i < LPT; ++i) RON_STAGE_PIECE(i);
     }
-    const char* sbuf = smem + (kt % S) * kStage;
+    const char* sbuf = smem + ((kt - kt0) % S) * kStage;
     // fragments of k-step s+1 are read while the MFMAs of k-step s run (two register sets)
     u32x4 fa[2][MR], fb[2][NR];
     if (ABL == 2) {
@@ -363,6 +373,22 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
   }
   // lane -> NR adjacent output channels starting at wn*TN + fr*NR
   const int nloc = wn * TN + fr * NR;
+  if (p.splitk > 1) {
+    float* slab = p.partial + (size_t)zsplit * p.M * p.Npad;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rt = wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (s_out_off[rt] < 0) continue;
+        float v[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) v[j] = acc[i][j][e];
+        store_f32_vec<NR>(slab + (size_t)(m0 + rt) * p.Npad + n0 + nloc, v);
+      }
+    }
+    return;
+  }
   float bias_v[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) bias_v[j] = p.bias[n0 + nloc + j];
@@ -405,6 +431,36 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
   }
 }
 
+// Adds the split-K slabs and applies the conv epilogue (bias, ReLU, relu(x + residual), dtype / fp32 store).
+template <class Tr>
+__global__ void splitk_finalize_kernel(ConvArgs p) {
+  const int groups = p.Npad / 4;
+  const long long total = (long long)p.M * groups;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % groups);
+    const int m = (int)(idx / groups);
+    const int n = g * 4;
+    if (n >= p.Cout) continue;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.splitk; ++z)
+      sum += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.M + m) * p.Npad + n);
+    const int hw = p.Ho * p.Wo;
+    const int img = m / hw;
+    const int rem = m - img * hw;
+    const int oy = rem / p.Wo, ox = rem - (rem / p.Wo) * p.Wo;
+    const int o = ((img * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cstride + p.out_coff + n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (n + j >= p.Cout) break;
+      float v = sum[j] + p.bias[n + j];
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.res != nullptr) v = fmaxf(v + Tr::load(p.res, o + j), 0.f);
+      if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = v;
+      else Tr::store(p.out, o + j, v);
+    }
+  }
+}
+
 struct TileCfg { int bm, bn, wm, wn, stages, spread; };
 // index = ConvLaunch.cfg
 constexpr TileCfg kCfgs[] = {
@@ -428,6 +484,8 @@ constexpr TileCfg kCfgs[] = {
     {256, 256, 2, 2, 2, 1},   // 17: diagnostic, 16 without LDS-DMA
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+// workgroups of configuration i the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
+inline int cfg_slots(int i) { return kCfgs[i].stages * (kCfgs[i].bm + kCfgs[i].bn) * 128 <= 80 * 1024 ? 512 : 256; }
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, bool SPREAD, int ABL = 0>
 int launch_t(const ConvArgs& a, hipStream_t s) {
@@ -438,8 +496,7 @@ int launch_t(const ConvArgs& a, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const int tiles_m = (a.M + BM - 1) / BM;
-  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL>), dim3(tiles_m * a.tiles_n), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -470,6 +527,15 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   return RON_ERR_INVALID;
 }
 
+template <class Tr>
+int launch_finalize(const ConvArgs& a, hipStream_t s) {
+  const long long total = (long long)a.M * (a.Npad / 4);
+  const int grid = (int)std::min<long long>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(splitk_finalize_kernel<Tr>, dim3(grid), dim3(256), 0, s, a);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
 }  // namespace detail
 using namespace detail;
 
@@ -477,6 +543,15 @@ size_t dtype_size(int dtype) { return dtype == RON_DTYPE_F32 ? 4 : 2; }
 int conv_k_chunk(int dtype) { return kRowBytes / (int)dtype_size(dtype); }
 int conv_n_tile(int cout) { return cout <= 64 ? 64 : 128; }
 int conv_num_cfgs() { return kNumCfgs; }
+
+// Split-K factor for grids that leave most CUs idle: such launches are a serial chain of KT dependent
+// HBM round trips per workgroup, so the K loop is spread over enough workgroups to fill the chip (>= 8 steps each).
+int conv_pick_splitk(int tiles, int KT, int slots) {
+  if (tiles * 2 > slots || KT < 16) return 1;
+  int sk = slots / tiles;
+  if (sk > KT / 8) sk = KT / 8;
+  return sk < 1 ? 1 : sk;
+}
 
 // Default tile choice, from tools/sweep_conv.py on MI355X at batch 32 (profiles/r01/sweep_*.txt):
 // the 256x256 tile wins once it yields >= ~160 workgroups, 256x128 (3 stages) down to ~190 workgroups, below that
@@ -520,12 +595,34 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   a.up = c.up; a.up_cout = c.up_cout;
   a.relu = c.relu; a.out_f32 = c.out_f32;
   a.tiles_n = c.Npad / BN;
+  a.tiles_total = ((M + kCfgs[cfg].bm - 1) / kCfgs[cfg].bm) * a.tiles_n;
+  a.Npad = c.Npad;
+  a.splitk = 1; a.kt_split = a.KT; a.partial = nullptr;
+  const int sk = c.splitk >= 0 ? c.splitk : conv_pick_splitk(a.tiles_total, a.KT, cfg_slots(cfg));
+  if (sk > 1 && c.up == 0 && c.scratch != nullptr && (int64_t)sk * M * c.Npad * 4 <= c.scratch_bytes) {
+    a.kt_split = (a.KT + sk - 1) / sk;
+    a.splitk = (a.KT + a.kt_split - 1) / a.kt_split;      // no empty split
+    a.partial = (float*)c.scratch;
+    if (a.splitk == 1) { a.kt_split = a.KT; a.partial = nullptr; }
+  }
   RON_REQUIRE((int64_t)c.Npad * a.K * esz == c.wgt_bytes, "conv: packed weight size mismatch");
-  if (c.dtype == RON_DTYPE_BF16) return launch_cfg<TraitsBF16>(cfg, a, stream);
-  if (c.dtype == RON_DTYPE_F16) return launch_cfg<TraitsF16>(cfg, a, stream);
-  if (c.dtype == RON_DTYPE_F32) return launch_cfg<TraitsF32>(cfg, a, stream);
-  ron::set_error("conv: unknown dtype %d", c.dtype);
-  return RON_ERR_INVALID;
+  int rc;
+  if (c.dtype == RON_DTYPE_BF16) rc = launch_cfg<TraitsBF16>(cfg, a, stream);
+  else if (c.dtype == RON_DTYPE_F16) rc = launch_cfg<TraitsF16>(cfg, a, stream);
+  else if (c.dtype == RON_DTYPE_F32) rc = launch_cfg<TraitsF32>(cfg, a, stream);
+  else { ron::set_error("conv: unknown dtype %d", c.dtype); return RON_ERR_INVALID; }
+  if (rc != RON_OK || a.splitk == 1) return rc;
+  if (c.dtype == RON_DTYPE_BF16) return launch_finalize<TraitsBF16>(a, stream);
+  if (c.dtype == RON_DTYPE_F16) return launch_finalize<TraitsF16>(a, stream);
+  return launch_finalize<TraitsF32>(a, stream);
+}
+
+int64_t conv_scratch_bytes(int M, int Npad, int K, int dtype, int cfg, int splitk) {
+  const int KT = K / conv_k_chunk(dtype);
+  const int c = cfg >= 0 ? cfg : conv_pick_cfg(M, Npad, K);
+  const int tiles = ((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * (Npad / kCfgs[c].bn);
+  const int sk = splitk >= 0 ? splitk : conv_pick_splitk(tiles, KT, cfg_slots(c));
+  return sk > 1 ? (int64_t)sk * M * Npad * 4 : 0;
 }
 
 }  // namespace ron

@@ -97,6 +97,8 @@ struct ron_ctx {
   float* d_head[3][4] = {};
   void* d_post_ws = nullptr;
   int64_t post_ws_bytes = 0;
+  void* d_splitk = nullptr;             // fp32 slabs of the split-K launches (sized at finalize for max_batch)
+  int64_t splitk_bytes = 0;
   // optional per-launch timing (ron_profile_*): event pairs recorded on the caller's stream
   bool profiling = false;
   std::vector<OpTiming> timing;                       // ops.size() + 1 (last = post-processing)
@@ -387,6 +389,7 @@ extern "C" int ron_destroy(ron_ctx* c) {
   for (auto& call : c->pending) for (hipEvent_t e : call) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->d_post_ws) (void)hipFree(c->d_post_ws);
+  if (c->d_splitk) (void)hipFree(c->d_splitk);
   delete c;
   return RON_OK;
 }
@@ -539,6 +542,17 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
 #undef PACK
 #undef ATTR
   c->flops_per_image = flops;
+  // split-K scratch: the largest slab set any launch can ask for at max_batch
+  for (const Op& o : c->ops) {
+    if (o.kind != OP_CONV || o.up > 0) continue;
+    const PackedConv& pk = c->packed[o.packed];
+    const int cin = o.in_C > 0 ? o.in_C : c->tensors[o.in].C;
+    for (int nb = 1; nb <= c->cfg.max_batch; ++nb) {
+      const int64_t b = conv_scratch_bytes(nb * o.Ho * o.Wo, pk.Npad, o.kh * o.kw * cin, c->cfg.dtype, -1, -1);
+      if (b > c->splitk_bytes) c->splitk_bytes = b;
+    }
+  }
+  if (c->splitk_bytes > 0) RON_HIP_CHECK(hipMalloc(&c->d_splitk, (size_t)c->splitk_bytes));
   c->timing.assign(c->ops.size() + 1, OpTiming());
   for (auto& v : c->vars) { v.data.clear(); v.data.shrink_to_fit(); }
   c->finalized = true;
@@ -612,6 +626,7 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
       L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.bias = p.d_bias; L.Cout = p.Cout; L.Npad = p.Npad;
       L.kh = o.kh; L.kw = o.kw; L.stride = o.stride; L.dil = o.dil; L.cpad = o.cpad; L.relu = o.relu;
       L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo;
+      L.scratch = c->d_splitk; L.scratch_bytes = c->splitk_bytes;
       if ((rc = launch_conv(L, s))) {
         std::string msg = ron_last_error();
         ron::set_error("%s: %s", o.name.c_str(), msg.c_str());

@@ -28,7 +28,7 @@ ron::TensorView make_view(void* base, int n, int h, int w, int c, int pad, int e
 
 struct ConvSetup {
   ron::ConvLaunch c;
-  DevBuf d_w, d_b, d_in, d_out, d_res;
+  DevBuf d_w, d_b, d_in, d_out, d_res, d_scratch;
   int ho = 0, wo = 0;
   bool is_c3 = false;
 };
@@ -107,6 +107,13 @@ int setup_conv(const ron_conv_desc* d, const float* w, const float* bias, bool w
   if (with_residual) {
     if ((rc = S->d_res.alloc(c.out.bytes, true))) return rc;
     c.res = S->d_res.p;
+  }
+  c.splitk = d->splitk;
+  const int64_t sb = conv_scratch_bytes(d->n * c.Ho * c.Wo, c.Npad, c.kh * c.kw * c.in.C, d->dtype, c.cfg, c.splitk);
+  if (sb > 0 && c.up == 0) {
+    if ((rc = S->d_scratch.alloc(sb, false))) return rc;
+    c.scratch = S->d_scratch.p;
+    c.scratch_bytes = sb;
   }
   return RON_OK;
 }

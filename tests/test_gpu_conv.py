@@ -137,3 +137,24 @@ def test_every_tile_configuration(ops, dev, cfg, dtype):
         ref2 = orf.conv2d_np(rnd(x2), rnd(w2))
         got2 = ops.conv2d_nhwc(torch.from_numpy(x2).to(dev), w2, None, relu=False, dtype=dtype, tile_cfg=cfg).cpu().numpy()
         _check(got2, ref2, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('splitk', [1, 2, 3, 7, -1])
+def test_split_k(ops, dev, dtype, splitk):
+    """Small grid, long K (the 5x5 / 10x10 head layers): K loop spread over workgroups, slabs summed by a second kernel."""
+    rs = np.random.RandomState(60)
+    x = rs.randn(2, 5, 5, 256).astype(np.float32)
+    rnd = ROUND[dtype]
+    for cout, relu, with_res in ((20, False, False), (128, True, True), (210, False, False)):
+        wt = (rs.randn(3, 3, 256, cout) * 0.03).astype(np.float32)
+        b = (rs.randn(cout) * 0.1).astype(np.float32)
+        res = np.maximum(rs.randn(2, 5, 5, cout), 0).astype(np.float32) if with_res else None
+        ref = orf.conv2d_np(rnd(x), rnd(wt)) + b
+        if relu:
+            ref = np.maximum(ref, 0)
+        if with_res:
+            ref = np.maximum(ref + rnd(res), 0)
+        got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, residual=None if res is None else torch.from_numpy(res).to(dev),
+                              relu=relu, dtype=dtype, splitk=splitk).cpu().numpy()
+        _check(got, ref, dtype)

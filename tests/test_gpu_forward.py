@@ -154,10 +154,16 @@ def test_forward_reduced_precision(pkg, dev, weights_reduced, images, oracle_red
         assert np.array_equal(det[b]['anchor_index'], want[b]['anchor_index'])
         assert np.array_equal(det[b]['scores'], want[b]['scores'])
         np.testing.assert_allclose(det[b]['bboxes'], want[b]['bboxes'], rtol=0, atol=1e-5)
-    # batch independence: image 1 alone == image 1 in the batch
+    # same batch twice -> bitwise identical (no atomics anywhere: split-K sums slabs in a fixed order)
+    again = net.forward_heads(x)
+    for i in range(4):
+        assert torch.equal(again[0][i], cls[i]) and torch.equal(again[2][i], loc[i])
+    # image 1 alone vs inside the batch: the split-K factor follows the grid size, so the fp32 summation order (and
+    # with it a few storage-type roundings) may differ between batch sizes -- equal within the dtype tolerance
     one = net.forward_heads(x[1:2])
     for i in range(4):
-        assert torch.equal(one[0][i][0], cls[i][1])
+        a, b = one[0][i][0].cpu().numpy(), cls[i][1].cpu().numpy()
+        assert float(np.abs(a - b).max() / np.abs(b).max()) < tol
     net.close()
 
 

@@ -54,6 +54,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--cstride', type=int, default=0)
     ap.add_argument('--coff', type=int, default=0)
+    ap.add_argument('--splitk', type=int, default=-1)
     a = ap.parse_args()
     lib = _lib.lib()
     ncfg = lib.ron_conv_num_tile_cfgs()
@@ -66,7 +67,7 @@ def main():
         flop = 2.0 * a.batch * (h * w if tr else ho * wo) * k * k * cin * cout
         cells = []
         for cfg in cfgs:
-            d = _lib.ConvDesc(a.batch, h, w, cin, cout, k, k, stride, rate, 1, tr, _lib.DTYPES[a.dtype], cfg, a.cstride, a.coff)
+            d = _lib.ConvDesc(a.batch, h, w, cin, cout, k, k, stride, rate, 1, tr, _lib.DTYPES[a.dtype], cfg, a.cstride, a.coff, a.splitk)
             ms = C.c_float()
             rc = lib.ron_conv2d_bench(C.byref(d), 3, a.iters, C.byref(ms))
             if rc != 0:
