@@ -1,5 +1,7 @@
 // Host-side description of one implicit-GEMM convolution launch (see conv_mfma.hip).
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace ron {
@@ -50,6 +52,11 @@ int conv_pick_cfg(int M, int Npad, int K);
 int conv_pick_splitk(int tiles, int KT, int slots);
 int64_t conv_scratch_bytes(int M, int Npad, int K, int dtype, int cfg, int splitk);
 size_t dtype_size(int dtype);
+
+// conv1_1 (stem.hip): 3 -> 64 channels straight from the fp32 image, bf16 / f16 only
+void stem_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* frags);
+int launch_stem_conv(const float* x, int n, int h, int w, int dtype, const void* d_wfrag, const float* d_bias,
+                     const TensorView& out, hipStream_t s);
 
 // helpers (elementwise.hip)
 int launch_im2col_c3(const float* x, int n, int h, int w, int dtype, void* out, int kchunk, hipStream_t s);

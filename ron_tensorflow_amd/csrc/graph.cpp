@@ -56,7 +56,7 @@ struct PackedConv {
   int Npad = 0, Cout = 0;
 };
 
-enum OpKind { OP_IM2COL, OP_CONV, OP_POOL };
+enum OpKind { OP_IM2COL, OP_CONV, OP_POOL, OP_STEM };
 
 struct Op {
   OpKind kind;
@@ -97,6 +97,8 @@ struct ron_ctx {
   float* d_head[3][4] = {};
   void* d_post_ws = nullptr;
   int64_t post_ws_bytes = 0;
+  void* d_stem_w = nullptr;             // conv1_1 fragments + bias for the dedicated stem kernel (bf16 / f16)
+  float* d_stem_b = nullptr;
   void* d_splitk = nullptr;             // fp32 slabs of the split-K launches (sized at finalize for max_batch)
   int64_t splitk_bytes = 0;
   // optional per-launch timing (ron_profile_*): event pairs recorded on the caller's stream
@@ -351,6 +353,7 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
     c->add_tensor(L + "_inc2", s_h, s_w, 1024, 1);
   }
   for (auto& t : c->tensors) {
+    if (t.name == "im2col" && cfg->dtype != RON_DTYPE_F32) continue;      // bf16 / f16 use the stem kernel
     t.bytes = (int64_t)cfg->max_batch * (t.H + 2 * t.pad) * (t.W + 2 * t.pad) * t.cstride * c->esz();
     if (t.bytes >= ((int64_t)1 << 32)) {
       ron::set_error("tensor %s needs %lld bytes for max_batch %d: above the 4 GiB buffer-addressing limit; lower max_batch",
@@ -390,6 +393,8 @@ extern "C" int ron_destroy(ron_ctx* c) {
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->d_post_ws) (void)hipFree(c->d_post_ws);
   if (c->d_splitk) (void)hipFree(c->d_splitk);
+  if (c->d_stem_w) (void)hipFree(c->d_stem_w);
+  if (c->d_stem_b) (void)hipFree(c->d_stem_b);
   delete c;
   return RON_OK;
 }
@@ -431,7 +436,8 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
 #define ATTR() do { c->ops.back().flops += flops - mark; mark = flops; } while (0)
 #define PACK(expr) do { rc = (expr); if (rc < 0) return rc; } while (0)
   // ---- VGG-16 body ----
-  {
+  const bool use_stem = c->cfg.dtype != RON_DTYPE_F32;
+  if (!use_stem) {
     Op o; o.kind = OP_IM2COL; o.name = "im2col"; o.out = T("im2col");
     c->ops.push_back(o);
   }
@@ -442,8 +448,19 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       const std::string nm = "conv" + std::to_string(b + 1) + "_" + std::to_string(r + 1);
       const std::string scope = "conv" + std::to_string(b + 1) + "/" + nm;
       const bool stem = b == 0 && r == 0;
-      PACK(stem ? pack_stem(c, scope) : pack_plain(c, scope, false));
-      c->ops.push_back(conv_op(nm, prev, T(nm), rc, stem ? 1 : 3, stem ? 0 : 1, 1, h, w));
+      if (stem && use_stem) {
+        std::vector<uint16_t> frags;
+        stem_pack_weights(c->var(scope + "/weights").data.data(), c->cfg.dtype, &frags);
+        RON_HIP_CHECK(hipMalloc(&c->d_stem_w, frags.size() * 2));
+        RON_HIP_CHECK(hipMemcpy(c->d_stem_w, frags.data(), frags.size() * 2, hipMemcpyHostToDevice));
+        RON_HIP_CHECK(hipMalloc((void**)&c->d_stem_b, 64 * sizeof(float)));
+        RON_HIP_CHECK(hipMemcpy(c->d_stem_b, c->var(scope + "/biases").data.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
+        Op o; o.kind = OP_STEM; o.name = nm; o.out = T(nm);
+        c->ops.push_back(o);
+      } else {
+        PACK(stem ? pack_stem(c, scope) : pack_plain(c, scope, false));
+        c->ops.push_back(conv_op(nm, prev, T(nm), rc, stem ? 1 : 3, stem ? 0 : 1, 1, h, w));
+      }
       flops += conv_flops(c->var(scope + "/weights"), h * w); ATTR();
       prev = T(nm);
     }
@@ -603,6 +620,9 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
     if (o.kind == OP_IM2COL) {
       const Tensor& t = c->tensors[o.out];
       if ((rc = launch_im2col_c3(d_images, n, t.H, t.W, c->cfg.dtype, t.d, t.C, s))) return rc;
+    } else if (o.kind == OP_STEM) {
+      const Tensor& t = c->tensors[o.out];
+      if ((rc = launch_stem_conv(d_images, n, t.H, t.W, c->cfg.dtype, c->d_stem_w, c->d_stem_b, c->view(o.out, n), s))) return rc;
     } else if (o.kind == OP_POOL) {
       if ((rc = launch_maxpool2x2(c->view(o.in, n), c->view(o.out, n), c->cfg.dtype, s))) return rc;
     } else {
@@ -708,6 +728,7 @@ extern "C" int ron_end_point_copy(ron_ctx* c, const char* name, int n, float* d_
   int64_t shp[4];
   const int idx = ron_end_point_shape(c, name, n, shp);
   if (idx < 0) return idx;
+  if (c->tensors[idx - 1].d == nullptr) { ron::set_error("end point '%s' is not materialised in this configuration", name); return RON_ERR_UNKNOWN_NAME; }
   return launch_unpack(c->view(idx - 1, n), c->cfg.dtype, 0, d_out, (hipStream_t)stream);
 }
 

@@ -128,6 +128,22 @@ extern "C" int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const flo
   ConvSetup S;
   int rc;
   if ((rc = setup_conv(d, w, bias, residual != nullptr, &S))) return rc;
+  if (S.is_c3 && d->dtype != RON_DTYPE_F32 && d->cout == 64 && d->w % 32 == 0 && d->relu && !residual) {
+    // conv1_1 through the dedicated stem kernel (what the graph runs for bf16 / f16)
+    std::vector<uint16_t> frags;
+    stem_pack_weights(w, d->dtype, &frags);
+    std::vector<float> b64(64, 0.f);
+    if (bias) memcpy(b64.data(), bias, 64 * sizeof(float));
+    DevBuf d_f, d_bb;
+    if ((rc = d_f.alloc((int64_t)frags.size() * 2, false))) return rc;
+    if ((rc = d_bb.alloc(64 * 4, false))) return rc;
+    RON_HIP_CHECK(hipMemcpy(d_f.p, frags.data(), frags.size() * 2, hipMemcpyHostToDevice));
+    RON_HIP_CHECK(hipMemcpy(d_bb.p, b64.data(), 64 * 4, hipMemcpyHostToDevice));
+    if ((rc = launch_stem_conv(x, d->n, d->h, d->w, d->dtype, d_f.p, (const float*)d_bb.p, S.c.out, s))) return rc;
+    if ((rc = launch_unpack(S.c.out, d->dtype, 0, y, s))) return rc;
+    RON_HIP_CHECK(hipStreamSynchronize(s));
+    return RON_OK;
+  }
   if (S.is_c3) {
     if ((rc = launch_im2col_c3(x, d->n, d->h, d->w, d->dtype, S.d_in.p, S.c.in.C, s))) return rc;
   } else {

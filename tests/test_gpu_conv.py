@@ -96,10 +96,12 @@ def test_conv2d_transpose_2x2(ops, dev, dtype):
     _check(got, ref, dtype)
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-def test_conv_stem_3_channels(ops, dev, dtype):
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('hw', [(16, 20), (12, 64), (7, 96)])
+def test_conv_stem_3_channels(ops, dev, dtype, hw):
+    """conv1_1: width % 32 == 0 goes through the dedicated stem kernel (bf16 / f16), otherwise im2col + 1x1 GEMM."""
     rs = np.random.RandomState(7)
-    x = (rs.uniform(0, 255, (2, 16, 20, 3)) - np.array([123., 117., 104.])).astype(np.float32)
+    x = (rs.uniform(0, 255, (2, hw[0], hw[1], 3)) - np.array([123., 117., 104.])).astype(np.float32)
     wt = (rs.randn(3, 3, 3, 64) * np.sqrt(2.0 / 27)).astype(np.float32)
     b = (rs.randn(64) * 0.1).astype(np.float32)
     rnd = ROUND[dtype]
