@@ -97,7 +97,7 @@ def main():
     ron_class = nets_factory.get_network('ron_320_vgg')
     ron_params = ron_class.default_params._replace(num_classes=21)
     weights = synthetic_weights(args.variant, seed=1)     # seed 1: ~4.8 k candidates, ~230 detections per image (full)
-    net = ron_class(ron_params, variant=args.variant, dtype=args.dtype, max_batch=args.batch, device=dev)
+    net = ron_class(ron_params, variant=args.variant, dtype=args.dtype, max_batch=args.batch, device=dev, fuse_pools=True)
     net.load_weights(weights)
     images = torch.from_numpy(synthetic_images(args.batch, seed=3 + rank)).to(dev)      # resident in HBM
     top_k = 400

@@ -190,8 +190,11 @@ typedef struct {
   int32_t num_classes;      /* 21                                                            */
   int32_t max_batch;        /* workspace is sized for this many images per call              */
   int32_t device;           /* HIP device ordinal                                            */
-  int32_t reserved;
+  uint32_t flags;           /* RON_CFG_*                                                     */
 } ron_config;
+/* Do not materialise block1..block3 (conv1_2, conv2_2, conv3_3 at full resolution): their 2x2 max-pool is
+ * fused into the conv epilogue.  ron_end_point_copy then fails for those names. */
+#define RON_CFG_FUSE_POOLS 1u
 
 int ron_create(ron_ctx** out, const ron_config* cfg);
 int ron_destroy(ron_ctx* ctx);
@@ -252,6 +255,7 @@ typedef struct {
   int32_t tile_cfg;         /* tile configuration of the conv kernel (csrc/conv_mfma.hip kCfgs); -1 = by shape */
   int32_t in_cstride;       /* tooling: input laid out as a channel slice: elements per pixel (0 = cin) ...   */
   int32_t in_coff;          /* ... and first channel of the slice                                              */
+  int32_t pool;             /* fuse a 2x2 stride-2 max-pool into the epilogue: y is [n, h/2, w/2, cout]        */
   int32_t splitk;           /* split-K factor: -1 = by grid size, 1 = off                                      */
 } ron_conv_desc;
 int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const float* w, const float* bias,

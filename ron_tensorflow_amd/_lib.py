@@ -15,6 +15,7 @@ RON_MAX_TOPK = 512
 RON_IN_CLS_IS_PROB = 1
 RON_IN_OBJ_IS_PROB = 2
 RON_IN_LOC_DECODED = 4
+RON_CFG_FUSE_POOLS = 1
 
 DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp16': 2, 'f16': 2, 'float16': 2}
 VARIANTS = {'reducedfc': 0, 'full': 1}
@@ -54,14 +55,14 @@ class Detections(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [('variant', C.c_int32), ('dtype', C.c_int32), ('img_h', C.c_int32), ('img_w', C.c_int32),
-                ('num_classes', C.c_int32), ('max_batch', C.c_int32), ('device', C.c_int32), ('reserved', C.c_int32)]
+                ('num_classes', C.c_int32), ('max_batch', C.c_int32), ('device', C.c_int32), ('flags', C.c_uint32)]
 
 
 class ConvDesc(C.Structure):
     _fields_ = [('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cin', C.c_int32), ('cout', C.c_int32),
                 ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('dilation', C.c_int32),
                 ('relu', C.c_int32), ('transpose', C.c_int32), ('dtype', C.c_int32), ('tile_cfg', C.c_int32),
-                ('in_cstride', C.c_int32), ('in_coff', C.c_int32), ('splitk', C.c_int32)]
+                ('in_cstride', C.c_int32), ('in_coff', C.c_int32), ('pool', C.c_int32), ('splitk', C.c_int32)]
 
 
 # every symbol include/ron_hip.h declares: (restype, argtypes)

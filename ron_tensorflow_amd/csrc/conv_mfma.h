@@ -37,6 +37,7 @@ struct ConvLaunch {
   int up = 0;
   int up_cout = 0;               // channels per tap of the transposed conv (Cout = up*up*up_cout)
   int Ho = 0, Wo = 0;            // GEMM rows = N*Ho*Wo (input grid for a transposed conv)
+  int pool = 0;                  // fuse slim.max_pool2d [2,2] into the epilogue: `out` is the pooled map
   int cfg = -1;                  // tile configuration index (conv_mfma.hip kCfgs); -1 = pick by shape
   int splitk = -1;               // split-K factor; -1 = pick by grid size, 1 = off
   void* scratch = nullptr;       // fp32 slabs for split-K (conv_scratch_bytes); null disables split-K

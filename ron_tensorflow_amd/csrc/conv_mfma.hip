@@ -63,6 +63,9 @@ struct ConvArgs {
   // partial[z][m][n] (n < Npad); splitk_finalize_kernel adds the slabs and applies the epilogue.
   int splitk, kt_split, tiles_total, Npad;
   float* partial;
+  // fused 2x2 / stride-2 max-pool: tile rows are ordered window-major (rows 4q..4q+3 = the four conv outputs of
+  // pooled pixel q), which puts a window into four consecutive accumulator registers of one lane.
+  int pool;
 };
 
 struct TraitsBF16 {
@@ -191,19 +194,33 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
 
   // per-row addressing, once per tile
   for (int r = tid; r < BM; r += kThreads) {
-    int m = m0 + r;
-    const bool valid = m < p.M;
-    m = valid ? m : p.M - 1;
-    const int hw = p.Ho * p.Wo;
-    const int img = m / hw;
-    const int rem = m - img * hw;
-    const int oy = rem / p.Wo;
-    const int ox = rem - oy * p.Wo;
+    int img, oy, ox, off;
+    bool valid;
+    if (p.pool) {
+      const int pw = p.Wo >> 1, ph = p.Ho >> 1;
+      int P = (m0 >> 2) + (r >> 2);                 // pooled pixel of this window
+      valid = P < (p.M >> 2);
+      P = valid ? P : (p.M >> 2) - 1;
+      img = P / (ph * pw);
+      const int rem = P - img * (ph * pw);
+      const int py = rem / pw, px = rem - (rem / pw) * pw;
+      oy = 2 * py + ((r >> 1) & 1);
+      ox = 2 * px + (r & 1);
+      off = ((img * p.out_Hp + py + p.out_pad) * p.out_Wp + px + p.out_pad) * p.out_cstride + p.out_coff;
+    } else {
+      int m = m0 + r;
+      valid = m < p.M;
+      m = valid ? m : p.M - 1;
+      const int hw = p.Ho * p.Wo;
+      img = m / hw;
+      const int rem = m - img * hw;
+      oy = rem / p.Wo;
+      ox = rem - oy * p.Wo;
+      const int os = p.up > 0 ? p.up : 1;
+      off = ((img * p.out_Hp + oy * os + p.out_pad) * p.out_Wp + ox * os + p.out_pad) * p.out_cstride + p.out_coff;
+    }
     const int iy = oy * p.stride + p.in_org, ix = ox * p.stride + p.in_org;
     s_in_off[r] = (int)((((unsigned)(img * p.in_Hp + iy) * p.in_Wp + ix) * p.in_cstride + p.in_coff) * Tr::kEsz);
-    const int os = p.up > 0 ? p.up : 1;
-    const int off = ((img * p.out_Hp + oy * os + p.out_pad) * p.out_Wp + ox * os + p.out_pad) * p.out_cstride +
-                    p.out_coff;
     s_out_off[r] = valid ? off : -1;
   }
   __syncthreads();
@@ -394,6 +411,32 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
   for (int j = 0; j < NR; ++j) bias_v[j] = p.bias[n0 + nloc + j];
   const int n_valid = p.Cout - (n0 + nloc);            // channels of this lane's group that exist (may be <= 0)
   const int ncol0 = n_base + nloc;
+  if (p.pool) {
+    // max over the 2x2 window = max over registers 4t..4t+3; relu(max(x) + b) == max(relu(x + b))
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ooff = s_out_off[wm * TM + i * 32 + 8 * t + 4 * fh];
+        if (ooff < 0 || n_valid <= 0) continue;
+        float v[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const float mx = fmaxf(fmaxf(acc[i][j][4 * t], acc[i][j][4 * t + 1]), fmaxf(acc[i][j][4 * t + 2], acc[i][j][4 * t + 3]));
+          v[j] = mx + bias_v[j];
+          if (p.relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        const int o = ooff + ncol0;
+        if (n_valid >= NR) {
+          Tr::template store_vec<NR>(p.out, o, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NR; ++j) if (j < n_valid) Tr::store(p.out, o + j, v[j]);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
 #pragma unroll
@@ -598,8 +641,14 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   a.tiles_total = ((M + kCfgs[cfg].bm - 1) / kCfgs[cfg].bm) * a.tiles_n;
   a.Npad = c.Npad;
   a.splitk = 1; a.kt_split = a.KT; a.partial = nullptr;
+  a.pool = c.pool;
+  if (c.pool) {
+    RON_REQUIRE(c.up == 0 && c.res == nullptr && !c.out_f32 && c.Ho % 2 == 0 && c.Wo % 2 == 0 && c.stride == 1,
+                "conv + fused pool: plain stride-1 conv on an even map only");
+    RON_REQUIRE(c.out.H == c.Ho / 2 && c.out.W == c.Wo / 2, "conv + fused pool: output view must be the pooled map");
+  }
   const int sk = c.splitk >= 0 ? c.splitk : conv_pick_splitk(a.tiles_total, a.KT, cfg_slots(cfg));
-  if (sk > 1 && c.up == 0 && c.scratch != nullptr && (int64_t)sk * M * c.Npad * 4 <= c.scratch_bytes) {
+  if (sk > 1 && c.up == 0 && !c.pool && c.scratch != nullptr && (int64_t)sk * M * c.Npad * 4 <= c.scratch_bytes) {
     a.kt_split = (a.KT + sk - 1) / sk;
     a.splitk = (a.KT + a.kt_split - 1) / a.kt_split;      // no empty split
     a.partial = (float*)c.scratch;

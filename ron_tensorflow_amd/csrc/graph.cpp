@@ -66,7 +66,7 @@ struct Op {
   int out_coff = 0, out_C = 0;          // channel slice of the output (out_C = 0: the whole tensor)
   int packed = -1;
   int kh = 1, kw = 1, stride = 1, dil = 1, cpad = 0, relu = 0;
-  int up = 0, up_cout = 0;
+  int up = 0, up_cout = 0, pool = 0;
   int head_kind = -1, head_layer = -1;  // 0 cls, 1 obj, 2 loc
   int Ho = 0, Wo = 0;
   double flops = 0;                     // algorithmic 2*MAC per image of this launch
@@ -354,6 +354,7 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
   }
   for (auto& t : c->tensors) {
     if (t.name == "im2col" && cfg->dtype != RON_DTYPE_F32) continue;      // bf16 / f16 use the stem kernel
+    if ((cfg->flags & RON_CFG_FUSE_POOLS) && (t.name == "conv1_2" || t.name == "conv2_2" || t.name == "conv3_3")) continue;
     t.bytes = (int64_t)cfg->max_batch * (t.H + 2 * t.pad) * (t.W + 2 * t.pad) * t.cstride * c->esz();
     if (t.bytes >= ((int64_t)1 << 32)) {
       ron::set_error("tensor %s needs %lld bytes for max_batch %d: above the 4 GiB buffer-addressing limit; lower max_batch",
@@ -464,9 +465,16 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       flops += conv_flops(c->var(scope + "/weights"), h * w); ATTR();
       prev = T(nm);
     }
-    Op p; p.kind = OP_POOL; p.name = "pool" + std::to_string(b + 1); p.in = prev; p.out = T(p.name);
-    c->ops.push_back(p);
-    prev = p.out;
+    const std::string pname = "pool" + std::to_string(b + 1);
+    if ((c->cfg.flags & RON_CFG_FUSE_POOLS) && b < 3 && c->ops.back().kind == OP_CONV) {
+      c->ops.back().pool = 1;                 // block1..3 feed nothing but their pool: never written at full size
+      c->ops.back().out = T(pname);
+      c->ops.back().name += "+" + pname;
+    } else {
+      Op p; p.kind = OP_POOL; p.name = pname; p.in = prev; p.out = T(p.name);
+      c->ops.push_back(p);
+    }
+    prev = T(pname);
     h /= 2; w /= 2;
   }
   // ---- fc6 / fc7 ----
@@ -645,7 +653,7 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
       L.res = o.res >= 0 ? c->tensors[o.res].d : nullptr;
       L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.bias = p.d_bias; L.Cout = p.Cout; L.Npad = p.Npad;
       L.kh = o.kh; L.kw = o.kw; L.stride = o.stride; L.dil = o.dil; L.cpad = o.cpad; L.relu = o.relu;
-      L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo;
+      L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo; L.pool = o.pool;
       L.scratch = c->d_splitk; L.scratch_bytes = c->splitk_bytes;
       if ((rc = launch_conv(L, s))) {
         std::string msg = ron_last_error();

@@ -101,6 +101,8 @@ int setup_conv(const ron_conv_desc* d, const float* w, const float* bias, bool w
   }
   if ((rc = S->d_in.alloc(c.in.bytes, true))) return rc;
   c.in.base = S->d_in.p;
+  c.pool = d->pool;
+  if (d->pool) { S->ho /= 2; S->wo /= 2; }
   c.out = make_view(nullptr, d->n, S->ho, S->wo, d->cout, 1, esz);   // halo 1: exercises padded stores
   if ((rc = S->d_out.alloc(c.out.bytes, true))) return rc;
   c.out.base = S->d_out.p;

@@ -39,13 +39,16 @@ class RONNet(object):
         anchor_offset=0.5,
         prior_scaling=[0.1, 0.1, 0.2, 0.2])
 
-    def __init__(self, params=None, variant='reducedfc', dtype='bf16', max_batch=32, device=None):
+    def __init__(self, params=None, variant='reducedfc', dtype='bf16', max_batch=32, device=None, fuse_pools=False):
         self.params = params if isinstance(params, RONParams) else RONNet.default_params
         if variant not in _lib.VARIANTS:
             raise ValueError('Unknown RON variant %s' % variant)
         if dtype not in _lib.DTYPES:
             raise ValueError('Unknown dtype %s' % dtype)
         self.variant, self.dtype, self.max_batch = variant, dtype, max_batch
+        # fuse_pools: block1..block3 are never written at full resolution (their max-pool runs in the conv epilogue);
+        # end_points then offers block4..block7 only
+        self.fuse_pools = fuse_pools
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self._ctx = None
         self._anchors_dev = None
@@ -55,7 +58,7 @@ class RONNet(object):
         if self._ctx is None:
             cfg = _lib.Config(_lib.VARIANTS[self.variant], _lib.DTYPES[self.dtype], self.params.img_shape[0],
                               self.params.img_shape[1], self.params.num_classes, self.max_batch,
-                              self.device.index or 0, 0)
+                              self.device.index or 0, _lib.RON_CFG_FUSE_POOLS if self.fuse_pools else 0)
             h = C.c_void_p()
             check(lib().ron_create(C.byref(h), C.byref(cfg)))
             self._ctx = h
@@ -131,7 +134,8 @@ class RONNet(object):
         fn = prediction_fn if prediction_fn is not None else ops.softmax_last
         predictions = [fn(l) for l in logits]
         objness_pred = [ops.softmax_last(o, pick=1) if prediction_fn is None else fn(o)[..., 1:2] for o in objness_logits]
-        eps = {name: self.end_point(name, inputs.shape[0]) for name in (end_points or ())}
+        names = [n for n in (end_points or ()) if not (self.fuse_pools and n in ('block1', 'block2', 'block3'))]
+        eps = {name: self.end_point(name, inputs.shape[0]) for name in names}
         return predictions, logits, objness_pred, objness_logits, localisations, eps
 
     def end_point(self, name, n):

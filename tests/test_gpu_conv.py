@@ -160,3 +160,22 @@ def test_split_k(ops, dev, dtype, splitk):
         got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, residual=None if res is None else torch.from_numpy(res).to(dev),
                               relu=relu, dtype=dtype, splitk=splitk).cpu().numpy()
         _check(got, ref, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('cfg', [-1, 0, 5, 6, 11])
+def test_conv_with_fused_maxpool(ops, dev, dtype, cfg):
+    """conv3x3 + bias + ReLU + 2x2/2 max-pool in one kernel == pool(conv) (nets/ron_vgg_320.py:454-466)."""
+    rs = np.random.RandomState(70)
+    cout = 64 if cfg == 5 else 256
+    x = rs.randn(3, 12, 20, 64).astype(np.float32)
+    wt = (rs.randn(3, 3, 64, cout) * 0.05).astype(np.float32)
+    b = (rs.randn(cout) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = orf.max_pool2x2_np(np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0))
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=cfg, pool=True).cpu().numpy()
+    assert got.shape == (3, 6, 10, cout)
+    _check(got, ref, dtype)
+    # same kernel configuration without split-K: fused pooling == pooling the stored conv output, bit for bit
+    full = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=cfg, splitk=1)
+    assert np.array_equal(ops.maxpool2x2_nhwc(full, dtype=dtype).cpu().numpy(), got)

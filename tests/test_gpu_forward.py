@@ -167,6 +167,29 @@ def test_forward_reduced_precision(pkg, dev, weights_reduced, images, oracle_red
     net.close()
 
 
+def test_fused_pools_give_identical_heads(pkg, dev, weights_reduced, images):
+    """RON_CFG_FUSE_POOLS only changes where the max-pool runs.  max commutes with the monotonic bias / ReLU / rounding
+    steps, so fused and separate pooling agree bit for bit per element; at this tiny batch the un-fused conv3_3 runs
+    split-K (a different fp32 summation order), hence a few bf16 ulps instead of bitwise equality."""
+    x = torch.from_numpy(images).to(dev)
+    a = pkg['ron'].RONNet(variant='reducedfc', dtype='bf16', max_batch=2).load_weights(weights_reduced)
+    b = pkg['ron'].RONNet(variant='reducedfc', dtype='bf16', max_batch=2, fuse_pools=True).load_weights(weights_reduced)
+    ha, hb = a.forward_heads(x), b.forward_heads(x)
+    for la, lb in zip(ha, hb):
+        for ta, tb in zip(la, lb):
+            ta, tb = ta.cpu().numpy(), tb.cpu().numpy()
+            assert float(np.abs(ta - tb).max() / np.abs(ta).max()) < 0.04
+            assert float(np.abs(ta - tb).mean() / np.abs(ta).max()) < 0.002
+    ea, eb = a.end_point('block4', 2).cpu().numpy(), b.end_point('block4', 2).cpu().numpy()
+    assert float(np.abs(ea - eb).max() / np.abs(ea).max()) < 0.04
+    with pytest.raises(Exception):
+        b.end_point('block1', 2)
+    out = b.net(x, is_training=False)
+    assert sorted(out[5]) == ['block4', 'block5', 'block6', 'block7']
+    a.close()
+    b.close()
+
+
 def test_network_fn_uses_full_variant(pkg, dev, weights_full, images):
     fn = pkg['factory'].get_network_fn('ron_320_vgg', 21, is_training=False, weights=weights_full, dtype='bf16', max_batch=1)
     assert fn.default_image_size == 320

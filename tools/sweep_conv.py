@@ -67,7 +67,7 @@ def main():
         flop = 2.0 * a.batch * (h * w if tr else ho * wo) * k * k * cin * cout
         cells = []
         for cfg in cfgs:
-            d = _lib.ConvDesc(a.batch, h, w, cin, cout, k, k, stride, rate, 1, tr, _lib.DTYPES[a.dtype], cfg, a.cstride, a.coff, a.splitk)
+            d = _lib.ConvDesc(a.batch, h, w, cin, cout, k, k, stride, rate, 1, tr, _lib.DTYPES[a.dtype], cfg, a.cstride, a.coff, 0, a.splitk)
             ms = C.c_float()
             rc = lib.ron_conv2d_bench(C.byref(d), 3, a.iters, C.byref(ms))
             if rc != 0:
