@@ -41,7 +41,8 @@ typedef enum {
   RON_ERR_UNSUPPORTED = -5
 } ron_status;
 
-typedef enum { RON_VARIANT_REDUCEDFC = 0, RON_VARIANT_FULL = 1 } ron_variant;
+/* REDUCEDFC / FULL: RON-320 bodies (nets/ron_vgg_320.py:510-580 / :434-508); SSD512: nets/ssd_vgg_512.py:364-460 */
+typedef enum { RON_VARIANT_REDUCEDFC = 0, RON_VARIANT_FULL = 1, RON_VARIANT_SSD512 = 2 } ron_variant;
 typedef enum { RON_DTYPE_F32 = 0, RON_DTYPE_BF16 = 1, RON_DTYPE_F16 = 2 } ron_dtype;
 
 const char* ron_last_error(void);
@@ -60,6 +61,14 @@ int ron_anchor_one_layer(int img_h, int img_w, int feat_h, int feat_w,
                          const double* ratios, int n_ratios,
                          double step, double offset,
                          float* y, float* x, float* h, float* w);
+
+/* SSD flavour: ssd_anchor_one_layer (nets/ssd_vgg_512.py:286-338); A = n_sizes + n_ratios anchors per cell:
+ * [sizes[0] square, sqrt(sizes[0]*sizes[1]) square, sizes[0] at each ratio]. */
+int ron_ssd_anchor_one_layer(int img_h, int img_w, int feat_h, int feat_w,
+                             const double* sizes, int n_sizes,
+                             const double* ratios, int n_ratios,
+                             double step, double offset,
+                             float* y, float* x, float* h, float* w);
 
 /* ------------------------------------------------------------------------------------------
  * Head tensors of one batch (device pointers, fp32).  This is what RONNet.net() returns as

@@ -18,7 +18,7 @@ RON_IN_LOC_DECODED = 4
 RON_CFG_FUSE_POOLS = 1
 
 DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp16': 2, 'f16': 2, 'float16': 2}
-VARIANTS = {'reducedfc': 0, 'full': 1}
+VARIANTS = {'reducedfc': 0, 'full': 1, 'ssd512': 2}
 
 
 class RonError(RuntimeError):
@@ -72,6 +72,8 @@ SIGNATURES = {
     'ron_abi_version': (C.c_int, []),
     'ron_anchor_one_layer': (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
                                                        C.c_double, C.c_double, _P, _P, _P, _P]),
+    'ron_ssd_anchor_one_layer': (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
+                                                           C.c_double, C.c_double, _P, _P, _P, _P]),
     'ron_post_np_workspace_bytes': (C.c_int64, [C.POINTER(Heads), C.c_int]),
     'ron_post_np': (C.c_int, [C.POINTER(Heads), C.c_int, C.POINTER(PostCfg), _P, C.c_int64, C.POINTER(Detections),
                               C.POINTER(Detections), _P, _P]),

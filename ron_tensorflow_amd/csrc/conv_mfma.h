@@ -62,6 +62,8 @@ int launch_stem_conv(const float* x, int n, int h, int w, int dtype, const void*
 // helpers (elementwise.hip)
 int launch_im2col_c3(const float* x, int n, int h, int w, int dtype, void* out, int kchunk, hipStream_t s);
 int launch_maxpool2x2(const TensorView& in, const TensorView& out, int dtype, hipStream_t s);
+int launch_maxpool3x3s1(const TensorView& in, const TensorView& out, int dtype, hipStream_t s);
+int launch_l2norm(const TensorView& in, const TensorView& out, const float* d_gamma, int dtype, hipStream_t s);
 int launch_pack_input(const float* x, const TensorView& out, int dtype, hipStream_t s);      // dense fp32 -> view
 int launch_fill_random(const TensorView& out, int dtype, unsigned seed, hipStream_t s);       // interior <- U[-1,1)
 int launch_unpack(const TensorView& in, int dtype, int in_is_f32, float* y, hipStream_t s);  // view -> dense fp32

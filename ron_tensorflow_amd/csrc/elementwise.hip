@@ -94,6 +94,72 @@ __global__ void maxpool2x2_kernel(ViewDev in, ViewDev out) {
   }
 }
 
+// slim.max_pool2d [3,3] stride 1 SAME (nets/ssd_vgg_512.py:391, pool5 of SSD).  Inputs are post-ReLU (>= 0), so the
+// zero halo is equivalent to TF's "ignore the padding" for a max.
+template <class T>
+__global__ void maxpool3x3s1_kernel(ViewDev in, ViewDev out) {
+  constexpr int V = 16 / sizeof(T);
+  const int groups = out.C / V;
+  const long long total = (long long)out.N * out.H * out.W * groups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const long long pix = i / groups;
+    const int ox = (int)(pix % out.W);
+    const int oy = (int)((pix / out.W) % out.H);
+    const long long img = pix / ((long long)out.W * out.H);
+    const T* ib = reinterpret_cast<const T*>(in.base);
+    float m[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) m[e] = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const Vec<T, V> a = *reinterpret_cast<const Vec<T, V>*>(ib + view_off(in, img, oy + dy, ox + dx) + g * V);
+#pragma unroll
+        for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], Cvt<T>::to_f(a.v[e]));
+      }
+    Vec<T, V> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) o.v[e] = Cvt<T>::from_f(m[e]);
+    *reinterpret_cast<Vec<T, V>*>(reinterpret_cast<T*>(out.base) + view_off(out, img, oy, ox) + g * V) = o;
+  }
+}
+
+// custom_layers.l2_normalization(scaling=True) over the channel axis (nets/custom_layers.py:66-135):
+// y = x * rsqrt(max(sum_c x^2, 1e-12)) * gamma[c].  One wave per pixel, 16 B per lane per pass.
+template <class T>
+__global__ void l2norm_kernel(ViewDev in, ViewDev out, const float* __restrict__ gamma) {
+  constexpr int V = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const long long n_pix = (long long)in.N * in.H * in.W;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long pix = wave0; pix < n_pix; pix += n_waves) {
+    const int px = (int)(pix % in.W);
+    const int py = (int)((pix / in.W) % in.H);
+    const long long img = pix / ((long long)in.W * in.H);
+    const T* ib = reinterpret_cast<const T*>(in.base) + view_off(in, img, py, px);
+    T* ob = reinterpret_cast<T*>(out.base) + view_off(out, img, py, px);
+    float ss = 0.f;
+    for (int c0 = lane * V; c0 < in.C; c0 += 64 * V) {
+      const Vec<T, V> a = *reinterpret_cast<const Vec<T, V>*>(ib + c0);
+#pragma unroll
+      for (int e = 0; e < V; ++e) { const float f = Cvt<T>::to_f(a.v[e]); ss += f * f; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d, 64);
+    const float inv = 1.f / sqrtf(fmaxf(ss, 1e-12f));
+    for (int c0 = lane * V; c0 < in.C; c0 += 64 * V) {
+      const Vec<T, V> a = *reinterpret_cast<const Vec<T, V>*>(ib + c0);
+      Vec<T, V> o;
+#pragma unroll
+      for (int e = 0; e < V; ++e) o.v[e] = Cvt<T>::from_f(Cvt<T>::to_f(a.v[e]) * inv * gamma[c0 + e]);
+      *reinterpret_cast<Vec<T, V>*>(ob + c0) = o;
+    }
+  }
+}
+
 template <class T>
 __global__ void pack_kernel(const float* __restrict__ x, ViewDev out) {
   const long long total = (long long)out.N * out.H * out.W * out.C;
@@ -160,6 +226,30 @@ int launch_maxpool2x2(const TensorView& in, const TensorView& out, int dtype, hi
   if (dtype == RON_DTYPE_BF16) hipLaunchKernelGGL(maxpool2x2_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out));
   else if (dtype == RON_DTYPE_F16) hipLaunchKernelGGL(maxpool2x2_kernel<_Float16>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out));
   else hipLaunchKernelGGL(maxpool2x2_kernel<float>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out));
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+int launch_maxpool3x3s1(const TensorView& in, const TensorView& out, int dtype, hipStream_t s) {
+  const int V = 16 / (int)dtype_size(dtype);
+  RON_REQUIRE(in.H == out.H && in.W == out.W && in.C == out.C && in.N == out.N && in.pad >= 1, "maxpool3x3: shape / halo mismatch");
+  RON_REQUIRE(out.C % V == 0 && in.cstride % V == 0 && out.cstride % V == 0, "maxpool3x3: channels must be a multiple of %d", V);
+  const int g = grid_for((long long)out.N * out.H * out.W * (out.C / V));
+  if (dtype == RON_DTYPE_BF16) hipLaunchKernelGGL(maxpool3x3s1_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out));
+  else if (dtype == RON_DTYPE_F16) hipLaunchKernelGGL(maxpool3x3s1_kernel<_Float16>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out));
+  else hipLaunchKernelGGL(maxpool3x3s1_kernel<float>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out));
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+int launch_l2norm(const TensorView& in, const TensorView& out, const float* d_gamma, int dtype, hipStream_t s) {
+  const int V = 16 / (int)dtype_size(dtype);
+  RON_REQUIRE(in.H == out.H && in.W == out.W && in.C == out.C && in.N == out.N && in.C % V == 0, "l2norm: shape mismatch");
+  const long long waves = (long long)in.N * in.H * in.W;
+  const int g = (int)std::min<long long>((waves + 3) / 4, 256 * 8);
+  if (dtype == RON_DTYPE_BF16) hipLaunchKernelGGL(l2norm_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out), d_gamma);
+  else if (dtype == RON_DTYPE_F16) hipLaunchKernelGGL(l2norm_kernel<_Float16>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out), d_gamma);
+  else hipLaunchKernelGGL(l2norm_kernel<float>, dim3(g), dim3(256), 0, s, to_dev(in), to_dev(out), d_gamma);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }

@@ -29,7 +29,6 @@ using namespace ron;
 namespace {
 
 constexpr float kBnEps = 1e-5f;
-const char* kScope = "ron_320_vgg";
 const char* kFeatLayers[4] = {"block7", "block6", "block5", "block4"};
 
 struct Var {
@@ -56,7 +55,7 @@ struct PackedConv {
   int Npad = 0, Cout = 0;
 };
 
-enum OpKind { OP_IM2COL, OP_CONV, OP_POOL, OP_STEM };
+enum OpKind { OP_IM2COL, OP_CONV, OP_POOL, OP_STEM, OP_POOL3, OP_L2NORM };
 
 struct Op {
   OpKind kind;
@@ -82,8 +81,15 @@ struct OpTiming {
 struct ron_ctx {
   ron_config cfg;
   int c6 = 0;                 // fc6 / fc7 channels
-  int num_anchors = 10;
+  int num_anchors = 10;                 // RON: anchors per cell on every scale
   int feat[4] = {0, 0, 0, 0};
+  // head layers, generic (RON: 4 scales x 10 anchors + objectness; SSD-512: 7 scales, 4/6 anchors, no objectness)
+  int n_feat = 4;
+  int feat_h[RON_MAX_LAYERS] = {}, feat_w[RON_MAX_LAYERS] = {}, feat_A[RON_MAX_LAYERS] = {};
+  bool has_obj = true;
+  bool is_ssd() const { return cfg.variant == RON_VARIANT_SSD512; }
+  const char* scope() const { return is_ssd() ? "ssd_512_vgg" : "ron_320_vgg"; }
+  float* d_l2_gamma = nullptr;          // SSD block4 L2Normalization scale
   std::vector<Var> vars;
   std::map<std::string, int> var_index;
   std::vector<Tensor> tensors;
@@ -93,8 +99,8 @@ struct ron_ctx {
   bool finalized = false;
   double flops_per_image = 0;
   // anchors (device) + head buffers / workspace for ron_detect
-  float* d_anchor[4][4] = {};
-  float* d_head[3][4] = {};
+  float* d_anchor[RON_MAX_LAYERS][4] = {};
+  float* d_head[3][RON_MAX_LAYERS] = {};
   void* d_post_ws = nullptr;
   int64_t post_ws_bytes = 0;
   void* d_stem_w = nullptr;             // conv1_1 fragments + bias for the dedicated stem kernel (bf16 / f16)
@@ -118,12 +124,12 @@ struct ron_ctx {
   }
   void add_var(const std::string& rel, std::vector<int64_t> shape) {
     Var v;
-    v.name = std::string(kScope) + "/" + rel;
+    v.name = std::string(scope()) + "/" + rel;
     v.shape = shape;
     var_index[v.name] = (int)vars.size();
     vars.push_back(v);
   }
-  const Var& var(const std::string& rel) const { return vars[var_index.at(std::string(kScope) + "/" + rel)]; }
+  const Var& var(const std::string& rel) const { return vars[var_index.at(std::string(scope()) + "/" + rel)]; }
   TensorView view(int t, int n, int coff = 0, int C = -1) const {
     const Tensor& T = tensors[t];
     TensorView v;
@@ -299,6 +305,99 @@ int pack_branch(ron_ctx* c, const std::string& I, int branch) {
   return upload(c, r, 512);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// SSD-512 (nets/ssd_vgg_512.py:364-460, multibox heads nets/ssd_vgg_300.py:403-431)
+// ---------------------------------------------------------------------------------------------------------
+const char* kSsdFeat[7] = {"block4", "block7", "block8", "block9", "block10", "block11", "block12"};
+const int kSsdAnchors[7] = {4, 6, 6, 6, 6, 4, 4};       // len(sizes) + len(ratios), nets/ssd_vgg_512.py:86-99
+const int kSsdFeatC[7] = {512, 1024, 512, 256, 256, 256, 256};
+
+void declare_variables_ssd(ron_ctx* c) {
+  const int nc = c->cfg.num_classes;
+  const int widths[5] = {64, 128, 256, 512, 512};
+  const int reps[5] = {2, 2, 3, 3, 3};
+  int cin = 3;
+  for (int b = 0; b < 5; ++b)
+    for (int r = 0; r < reps[b]; ++r) {
+      const std::string s = "conv" + std::to_string(b + 1) + "/conv" + std::to_string(b + 1) + "_" + std::to_string(r + 1);
+      c->add_var(s + "/weights", {3, 3, cin, widths[b]});
+      c->add_var(s + "/biases", {widths[b]});
+      cin = widths[b];
+    }
+  c->add_var("conv6/weights", {3, 3, 512, 1024});
+  c->add_var("conv6/biases", {1024});
+  c->add_var("conv7/weights", {1, 1, 1024, 1024});
+  c->add_var("conv7/biases", {1024});
+  const int mid[5] = {256, 128, 128, 128, 128}, outc[5] = {512, 256, 256, 256, 256}, inc[5] = {1024, 512, 256, 256, 256};
+  for (int b = 0; b < 5; ++b) {
+    const std::string B = "block" + std::to_string(8 + b);
+    c->add_var(B + "/conv1x1/weights", {1, 1, inc[b], mid[b]});
+    c->add_var(B + "/conv1x1/biases", {mid[b]});
+    const int k = b == 4 ? 4 : 3;
+    c->add_var(B + (b == 4 ? "/conv4x4" : "/conv3x3") + "/weights", {k, k, mid[b], outc[b]});
+    c->add_var(B + (b == 4 ? "/conv4x4" : "/conv3x3") + "/biases", {outc[b]});
+  }
+  for (int i = 0; i < 7; ++i) {
+    const std::string L = std::string(kSsdFeat[i]) + "_box";
+    if (i == 0) c->add_var(L + "/L2Normalization/gamma", {512});
+    c->add_var(L + "/conv_loc/weights", {3, 3, kSsdFeatC[i], kSsdAnchors[i] * 4});
+    c->add_var(L + "/conv_loc/biases", {kSsdAnchors[i] * 4});
+    c->add_var(L + "/conv_cls/weights", {3, 3, kSsdFeatC[i], kSsdAnchors[i] * nc});
+    c->add_var(L + "/conv_cls/biases", {kSsdAnchors[i] * nc});
+  }
+}
+
+void declare_tensors_ssd(ron_ctx* c) {
+  const int H = c->cfg.img_h, W = c->cfg.img_w;
+  c->add_tensor("im2col", H, W, conv_k_chunk(c->cfg.dtype), 0);
+  const int widths[5] = {64, 128, 256, 512, 512};
+  const int reps[5] = {2, 2, 3, 3, 3};
+  int h = H, w = W;
+  for (int b = 0; b < 5; ++b) {
+    for (int r = 0; r < reps[b]; ++r)
+      c->add_tensor("conv" + std::to_string(b + 1) + "_" + std::to_string(r + 1), h, w, widths[b], 1);
+    if (b < 4) { h /= 2; w /= 2; }
+    c->add_tensor("pool" + std::to_string(b + 1), h, w, widths[b], b == 4 ? 6 : 1);   // pool5 feeds the rate-6 conv
+  }
+  c->add_tensor("block4_norm", H / 8, W / 8, 512, 1);
+  c->add_tensor("conv6", h, w, 1024, 0);
+  c->add_tensor("conv7", h, w, 1024, 1);
+  const int mid[5] = {256, 128, 128, 128, 128}, outc[5] = {512, 256, 256, 256, 256};
+  for (int b = 0; b < 5; ++b) {
+    const std::string B = "block" + std::to_string(8 + b);
+    c->add_tensor(B + "_mid", h, w, mid[b], 1);            // pad2d(1) of the reference = the halo
+    if (b < 4) { h /= 2; w /= 2; } else { h = 1; w = 1; }
+    c->add_tensor(B, h, w, outc[b], 1);
+  }
+  c->n_feat = 7;
+  c->has_obj = false;
+  const int fh[7] = {H / 8, H / 16, H / 32, H / 64, H / 128, H / 256, 1}, fw[7] = {W / 8, W / 16, W / 32, W / 64, W / 128, W / 256, 1};
+  for (int i = 0; i < 7; ++i) { c->feat_h[i] = fh[i]; c->feat_w[i] = fw[i]; c->feat_A[i] = kSsdAnchors[i]; }
+}
+
+// SSDNet.default_params anchors (nets/ssd_vgg_512.py:79-102) with ssd_anchor_one_layer (:286-338): anchors per cell are
+// [s0 square, sqrt(s0*s1) square, s0 at each ratio]; centres as in the RON version.
+int make_anchors_ssd(ron_ctx* c) {
+  const int H = c->cfg.img_h, W = c->cfg.img_w;
+  const double sizes[7][2] = {{20.48, 51.2}, {51.2, 133.12}, {133.12, 215.04}, {215.04, 296.96}, {296.96, 378.88}, {378.88, 460.8}, {460.8, 542.72}};
+  const double ratios[7][4] = {{2, .5, 0, 0}, {2, .5, 3, 1. / 3}, {2, .5, 3, 1. / 3}, {2, .5, 3, 1. / 3}, {2, .5, 3, 1. / 3}, {2, .5, 0, 0}, {2, .5, 0, 0}};
+  const int n_ratios[7] = {2, 4, 4, 4, 4, 2, 2};
+  const double steps[7] = {8, 16, 32, 64, 128, 256, 512};
+  for (int i = 0; i < 7; ++i) {
+    const int fh = c->feat_h[i], fw = c->feat_w[i], A = c->feat_A[i];
+    std::vector<float> y(fh * fw), x(fh * fw), hh(A), ww(A);
+    int rc = ron_ssd_anchor_one_layer(H, W, fh, fw, sizes[i], 2, ratios[i], n_ratios[i], steps[i], 0.5, y.data(), x.data(), hh.data(), ww.data());
+    if (rc) return rc;
+    const std::vector<float>* src[4] = {&y, &x, &hh, &ww};
+    for (int k = 0; k < 4; ++k) {
+      RON_HIP_CHECK(hipMalloc((void**)&c->d_anchor[i][k], src[k]->size() * sizeof(float)));
+      RON_HIP_CHECK(hipMemcpy(c->d_anchor[i][k], src[k]->data(), src[k]->size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
+  return RON_OK;
+}
+
 Op conv_op(const std::string& name, int in, int out, int packed, int k, int cpad, int relu, int Ho, int Wo) {
   Op o;
   o.kind = OP_CONV; o.name = name; o.in = in; o.out = out; o.packed = packed;
@@ -313,19 +412,24 @@ double conv_flops(const Var& w, int out_pixels) { return 2.0 * (double)w.numel()
 // ------------------------------------------------------------------------------------------
 extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
   RON_REQUIRE(out && cfg, "NULL argument");
-  RON_REQUIRE(cfg->variant == RON_VARIANT_REDUCEDFC || cfg->variant == RON_VARIANT_FULL, "unknown variant %d", cfg->variant);
+  RON_REQUIRE(cfg->variant >= RON_VARIANT_REDUCEDFC && cfg->variant <= RON_VARIANT_SSD512, "unknown variant %d", cfg->variant);
   RON_REQUIRE(cfg->dtype >= 0 && cfg->dtype <= 2, "unknown dtype %d", cfg->dtype);
   RON_REQUIRE(cfg->img_h > 0 && cfg->img_h % 64 == 0 && cfg->img_w > 0 && cfg->img_w % 64 == 0, "image size must be a multiple of 64");
+  if (cfg->variant == RON_VARIANT_SSD512) RON_REQUIRE(cfg->img_h == 512 && cfg->img_w == 512, "SSD-512 runs on 512 x 512 inputs");
   RON_REQUIRE(cfg->num_classes >= 2 && cfg->num_classes <= 64, "num_classes out of range");
   RON_REQUIRE(cfg->max_batch >= 1, "max_batch must be >= 1");
   RON_HIP_CHECK(hipSetDevice(cfg->device));
   std::unique_ptr<ron_ctx> c(new ron_ctx());
   c->cfg = *cfg;
   c->c6 = cfg->variant == RON_VARIANT_FULL ? 4096 : 1024;
+  const int H = cfg->img_h, W = cfg->img_w;
+  if (c->is_ssd()) {
+    declare_variables_ssd(c.get());
+    declare_tensors_ssd(c.get());
+  } else {
   declare_variables(c.get());
 
   // ---- tensors ----
-  const int H = cfg->img_h, W = cfg->img_w;
   const int chunk = conv_k_chunk(cfg->dtype);
   c->add_tensor("im2col", H, W, chunk, 0);
   const int widths[5] = {64, 128, 256, 512, 512};
@@ -346,11 +450,13 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
   for (int i = 0; i < 4; ++i) {
     const int s_h = (H / 64) << i, s_w = (W / 64) << i;
     c->feat[i] = s_h;
+    c->feat_h[i] = s_h; c->feat_w[i] = s_w; c->feat_A[i] = c->num_anchors;
     const std::string L = kFeatLayers[i];
     if (i > 0) c->add_tensor(L + "_up", s_h, s_w, 512, 1);
     c->add_tensor(L + "_ref", s_h, s_w, 512, 1);
     c->add_tensor(L + "_hcat", s_h, s_w, 2048, 1);
     c->add_tensor(L + "_inc2", s_h, s_w, 1024, 1);
+  }
   }
   for (auto& t : c->tensors) {
     if (t.name == "im2col" && cfg->dtype != RON_DTYPE_F32) continue;      // bf16 / f16 use the stem kernel
@@ -366,6 +472,12 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
     RON_HIP_CHECK(hipMemset(t.d, 0, (size_t)t.bytes));     // halos stay zero forever: kernels write interiors only
   }
   // ---- anchors (RONNet.default_params, nets/ron_vgg_320.py:97-124) ----
+  if (c->is_ssd()) {
+    int rc = make_anchors_ssd(c.get());
+    if (rc) return rc;
+    *out = c.release();
+    return RON_OK;
+  }
   const double sizes[4][2] = {{224., 256.}, {160., 192.}, {96., 128.}, {32., 64.}};
   const double ratios[5] = {1., 2., 3., 1. / 2, 1. / 3};
   const double steps[4] = {64, 32, 16, 8};
@@ -388,8 +500,9 @@ extern "C" int ron_destroy(ron_ctx* c) {
   if (!c) return RON_OK;
   for (auto& t : c->tensors) if (t.d) (void)hipFree(t.d);
   for (auto& p : c->packed) { if (p.d_w) (void)hipFree(p.d_w); if (p.d_bias) (void)hipFree(p.d_bias); }
-  for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) if (c->d_anchor[i][k]) (void)hipFree(c->d_anchor[i][k]);
-  for (int k = 0; k < 3; ++k) for (int i = 0; i < 4; ++i) if (c->d_head[k][i]) (void)hipFree(c->d_head[k][i]);
+  for (int i = 0; i < RON_MAX_LAYERS; ++i) for (int k = 0; k < 4; ++k) if (c->d_anchor[i][k]) (void)hipFree(c->d_anchor[i][k]);
+  for (int k = 0; k < 3; ++k) for (int i = 0; i < RON_MAX_LAYERS; ++i) if (c->d_head[k][i]) (void)hipFree(c->d_head[k][i]);
+  if (c->d_l2_gamma) (void)hipFree(c->d_l2_gamma);
   for (auto& call : c->pending) for (hipEvent_t e : call) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->d_post_ws) (void)hipFree(c->d_post_ws);
@@ -466,6 +579,12 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       prev = T(nm);
     }
     const std::string pname = "pool" + std::to_string(b + 1);
+    if (c->is_ssd() && b == 4) {              // SSD: pool5 is 3x3 stride 1 (nets/ssd_vgg_512.py:391)
+      Op p; p.kind = OP_POOL3; p.name = pname; p.in = prev; p.out = T(p.name);
+      c->ops.push_back(p);
+      prev = T(pname);
+      continue;
+    }
     if ((c->cfg.flags & RON_CFG_FUSE_POOLS) && b < 3 && c->ops.back().kind == OP_CONV) {
       c->ops.back().pool = 1;                 // block1..3 feed nothing but their pool: never written at full size
       c->ops.back().out = T(pname);
@@ -477,6 +596,49 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
     prev = T(pname);
     h /= 2; w /= 2;
   }
+  if (c->is_ssd()) {
+    // ---- conv6 (3x3 rate 6), conv7 (1x1), blocks 8-12 (1x1 then pad2d(1) + 3x3 stride 2 VALID; block12: 4x4 VALID) ----
+    PACK(pack_plain(c, "conv6", false));
+    { Op o = conv_op("conv6", prev, T("conv6"), rc, 3, 6, 1, h, w); o.dil = 6; c->ops.push_back(o); }
+    flops += conv_flops(c->var("conv6/weights"), h * w); ATTR();
+    PACK(pack_plain(c, "conv7", false));
+    c->ops.push_back(conv_op("conv7", T("conv6"), T("conv7"), rc, 1, 0, 1, h, w));
+    flops += conv_flops(c->var("conv7/weights"), h * w); ATTR();
+    int src = T("conv7");
+    for (int b = 0; b < 5; ++b) {
+      const std::string B = "block" + std::to_string(8 + b);
+      PACK(pack_plain(c, B + "/conv1x1", false));
+      c->ops.push_back(conv_op(B + "_conv1x1", src, T(B + "_mid"), rc, 1, 0, 1, h, w));
+      flops += conv_flops(c->var(B + "/conv1x1/weights"), h * w); ATTR();
+      const std::string cs = B + (b == 4 ? "/conv4x4" : "/conv3x3");
+      PACK(pack_plain(c, cs, false));
+      const int ho = b == 4 ? 1 : h / 2, wo = b == 4 ? 1 : w / 2;
+      Op o = conv_op(B + (b == 4 ? "_conv4x4" : "_conv3x3"), T(B + "_mid"), T(B), rc, b == 4 ? 4 : 3, 1, 1, ho, wo);
+      o.stride = b == 4 ? 1 : 2;
+      c->ops.push_back(o);
+      flops += conv_flops(c->var(cs + "/weights"), ho * wo); ATTR();
+      src = T(B); h = ho; w = wo;
+    }
+    // ---- multibox heads (nets/ssd_vgg_300.py:403-431) ----
+    {
+      const Var& g = c->var("block4_box/L2Normalization/gamma");
+      RON_HIP_CHECK(hipMalloc((void**)&c->d_l2_gamma, g.data.size() * sizeof(float)));
+      RON_HIP_CHECK(hipMemcpy(c->d_l2_gamma, g.data.data(), g.data.size() * sizeof(float), hipMemcpyHostToDevice));
+      Op o; o.kind = OP_L2NORM; o.name = "block4_l2norm"; o.in = T("conv4_3"); o.out = T("block4_norm");
+      c->ops.push_back(o);
+    }
+    const char* feat_src[7] = {"block4_norm", "conv7", "block8", "block9", "block10", "block11", "block12"};
+    for (int i = 0; i < 7; ++i) {
+      const std::string L = std::string(kSsdFeat[i]) + "_box";
+      const int fh = c->feat_h[i], fw = c->feat_w[i];
+      PACK(pack_plain(c, L + "/conv_loc", false));
+      { Op o = conv_op(L + "_conv_loc", T(feat_src[i]), -2, rc, 3, 1, 0, fh, fw); o.head_kind = 2; o.head_layer = i; c->ops.push_back(o); }
+      flops += conv_flops(c->var(L + "/conv_loc/weights"), fh * fw); ATTR();
+      PACK(pack_plain(c, L + "/conv_cls", false));
+      { Op o = conv_op(L + "_conv_cls", T(feat_src[i]), -2, rc, 3, 1, 0, fh, fw); o.head_kind = 0; o.head_layer = i; c->ops.push_back(o); }
+      flops += conv_flops(c->var(L + "/conv_cls/weights"), fh * fw); ATTR();
+    }
+  } else {
   // ---- fc6 / fc7 ----
   PACK(pack_plain(c, "fc6", false));
   {
@@ -564,6 +726,7 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       flops += conv_flops(c->var(L + "/Conv2d_1_3x3/weights"), sh * sw); ATTR();
     }
   }
+  }   // RON tail
 #undef PACK
 #undef ATTR
   c->flops_per_image = flops;
@@ -588,14 +751,15 @@ extern "C" double ron_flops_per_image(const ron_ctx* c) { return c ? c->flops_pe
 
 extern "C" int ron_heads_describe(const ron_ctx* c, ron_heads* hd) {
   RON_REQUIRE(c && hd, "NULL argument");
-  hd->num_layers = 4;
+  hd->num_layers = c->n_feat;
   hd->num_classes = c->cfg.num_classes;
-  for (int i = 0; i < 4; ++i) {
-    hd->feat_h[i] = (c->cfg.img_h / 64) << i;
-    hd->feat_w[i] = (c->cfg.img_w / 64) << i;
-    hd->num_anchors[i] = c->num_anchors;
+  for (int i = 0; i < c->n_feat; ++i) {
+    hd->feat_h[i] = c->feat_h[i];
+    hd->feat_w[i] = c->feat_w[i];
+    hd->num_anchors[i] = c->feat_A[i];
     hd->anchor_y[i] = c->d_anchor[i][0]; hd->anchor_x[i] = c->d_anchor[i][1];
     hd->anchor_h[i] = c->d_anchor[i][2]; hd->anchor_w[i] = c->d_anchor[i][3];
+    if (!c->has_obj) hd->obj[i] = nullptr;
   }
   return RON_OK;
 }
@@ -607,8 +771,6 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
   hipStream_t s = (hipStream_t)stream;
   int rc = ron_heads_describe(c, out);
   if (rc) return rc;
-  const int A = c->num_anchors;
-  const int head_c[3] = {A * c->cfg.num_classes, 2 * A, 4 * A};
   std::vector<hipEvent_t>* ev = nullptr;
   if (c->profiling && c->pending.size() < 256) {
     c->pending.emplace_back();
@@ -633,6 +795,10 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
       if ((rc = launch_stem_conv(d_images, n, t.H, t.W, c->cfg.dtype, c->d_stem_w, c->d_stem_b, c->view(o.out, n), s))) return rc;
     } else if (o.kind == OP_POOL) {
       if ((rc = launch_maxpool2x2(c->view(o.in, n), c->view(o.out, n), c->cfg.dtype, s))) return rc;
+    } else if (o.kind == OP_POOL3) {
+      if ((rc = launch_maxpool3x3s1(c->view(o.in, n), c->view(o.out, n), c->cfg.dtype, s))) return rc;
+    } else if (o.kind == OP_L2NORM) {
+      if ((rc = launch_l2norm(c->view(o.in, n), c->view(o.out, n), c->d_l2_gamma, c->cfg.dtype, s))) return rc;
     } else {
       const PackedConv& p = c->packed[o.packed];
       ConvLaunch L;
@@ -643,7 +809,10 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
         float* dst = const_cast<float*>(arr[o.head_layer]);
         RON_REQUIRE(dst != nullptr, "ron_forward: head buffer (kind %d, layer %d) is NULL", o.head_kind, o.head_layer);
         TensorView v;
-        v.base = dst; v.N = n; v.H = o.Ho; v.W = o.Wo; v.C = head_c[o.head_kind]; v.pad = 0; v.cstride = v.C; v.coff = 0;
+        const int A = c->feat_A[o.head_layer];
+        v.base = dst; v.N = n; v.H = o.Ho; v.W = o.Wo; v.pad = 0; v.coff = 0;
+        v.C = o.head_kind == 0 ? A * c->cfg.num_classes : (o.head_kind == 1 ? 2 * A : 4 * A);
+        v.cstride = v.C;
         v.bytes = (int64_t)n * v.H * v.W * v.C * 4;
         L.out = v;
         L.out_f32 = 1;
@@ -723,6 +892,7 @@ extern "C" int ron_end_point_shape(const ron_ctx* c, const char* name, int n, in
                                                            {"block7", "fc7"}};
   auto a = alias.find(key);
   if (a != alias.end()) key = a->second;
+  if (c->is_ssd()) { if (key == "fc6") key = "conv6"; else if (key == "fc7") key = "conv7"; }
   auto it = c->tensor_index.find(key);
   if (it == c->tensor_index.end()) { ron::set_error("unknown end point '%s'", name); return RON_ERR_UNKNOWN_NAME; }
   const Tensor& t = c->tensors[it->second];
@@ -743,19 +913,20 @@ extern "C" int ron_end_point_copy(ron_ctx* c, const char* name, int n, float* d_
 extern "C" int ron_detect(ron_ctx* c, const float* d_images, int n, const ron_post_cfg* cfg, ron_detections* out, void* stream) {
   RON_REQUIRE(c && cfg && out, "NULL argument");
   RON_REQUIRE(n >= 1 && n <= c->cfg.max_batch, "batch %d outside [1, max_batch=%d]", n, c->cfg.max_batch);
-  const int A = c->num_anchors, mb = c->cfg.max_batch;
-  const int head_c[3] = {A * c->cfg.num_classes, 2 * A, 4 * A};
+  const int mb = c->cfg.max_batch;
   ron_heads hd;
   memset(&hd, 0, sizeof(hd));
   if (c->d_head[0][0] == nullptr) {          // first call: allocate ctx-owned head buffers + scratch
     RON_HIP_CHECK(hipSetDevice(c->cfg.device));
-    for (int k = 0; k < 3; ++k)
-      for (int i = 0; i < 4; ++i) {
-        const int fh = (c->cfg.img_h / 64) << i, fw = (c->cfg.img_w / 64) << i;
-        RON_HIP_CHECK(hipMalloc((void**)&c->d_head[k][i], (size_t)mb * fh * fw * head_c[k] * sizeof(float)));
-      }
+    for (int i = 0; i < c->n_feat; ++i) {
+      const int A = c->feat_A[i];
+      const size_t cells = (size_t)mb * c->feat_h[i] * c->feat_w[i];
+      RON_HIP_CHECK(hipMalloc((void**)&c->d_head[0][i], cells * A * c->cfg.num_classes * sizeof(float)));
+      if (c->has_obj) RON_HIP_CHECK(hipMalloc((void**)&c->d_head[1][i], cells * A * 2 * sizeof(float)));
+      RON_HIP_CHECK(hipMalloc((void**)&c->d_head[2][i], cells * A * 4 * sizeof(float)));
+    }
   }
-  for (int i = 0; i < 4; ++i) { hd.cls[i] = c->d_head[0][i]; hd.obj[i] = c->d_head[1][i]; hd.loc[i] = c->d_head[2][i]; }
+  for (int i = 0; i < c->n_feat; ++i) { hd.cls[i] = c->d_head[0][i]; hd.obj[i] = c->d_head[1][i]; hd.loc[i] = c->d_head[2][i]; }
   int rc = ron_forward(c, d_images, n, &hd, stream);
   if (rc) return rc;
   if (c->d_post_ws == nullptr) {

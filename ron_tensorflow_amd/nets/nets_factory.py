@@ -1,13 +1,14 @@
 """Network factory with the interface of the reference's ``nets/nets_factory.py:34-93``."""
 import functools
 
-from . import ron_vgg_320
+from . import ron_vgg_320, ssd_vgg_512
 
-networks_obj = {'ron_320_vgg': ron_vgg_320.RONNet}
+networks_obj = {'ron_320_vgg': ron_vgg_320.RONNet,
+                'ssd_512_vgg': ssd_vgg_512.SSDNet}
 
 # name -> variant built by the *function* entry of the reference: networks_map['ron_320_vgg'] is
 # ron_vgg_320.ron_net, the full VGG-16 fc6/fc7 body (nets_factory.py:37).
-_fn_variant = {'ron_320_vgg': 'full'}
+_fn_variant = {'ron_320_vgg': 'full', 'ssd_512_vgg': 'ssd512'}
 
 
 def get_network(name):
@@ -24,8 +25,11 @@ def get_network_fn(name, num_classes, is_training=False, **kwargs):
         raise ValueError('Name of network unknown %s' % name)
     cls = networks_obj[name]
     params = cls.default_params._replace(num_classes=num_classes)
-    net = cls(params, variant=_fn_variant[name], dtype=kwargs.pop('dtype', 'bf16'),
-              max_batch=kwargs.pop('max_batch', 32))
+    if name == 'ssd_512_vgg':
+        net = cls(params, dtype=kwargs.pop('dtype', 'bf16'), max_batch=kwargs.pop('max_batch', 16))
+    else:
+        net = cls(params, variant=_fn_variant[name], dtype=kwargs.pop('dtype', 'bf16'),
+                  max_batch=kwargs.pop('max_batch', 32))
     weights = kwargs.pop('weights', None)
     if weights is not None:
         net.load_weights(weights)

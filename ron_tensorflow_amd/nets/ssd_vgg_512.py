@@ -1,0 +1,113 @@
+"""SSD-512 (VGG) network object with the interface of the reference's ``nets/ssd_vgg_512.py`` (BASELINE config 5).
+
+``SSDNet`` keeps names / defaults / return arity of the reference class (nets/ssd_vgg_512.py:63-218): ``net`` returns
+``(predictions, localisations, logits, end_points)``; ``detected_bboxes`` is select -> top-k sort -> NMS with no clipping
+and no min-size filter (:182-201).  Everything runs through libron_hip.so (ron_ctx variant RON_VARIANT_SSD512)."""
+import contextlib
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from .._lib import check, current_stream, lib, ptr
+from .ron_vgg_320 import RONNet
+
+# same field names as the reference namedtuple (nets/ssd_vgg_512.py:44-60)
+SSDParams = namedtuple('SSDParameters', ['img_shape', 'num_classes', 'no_annotation_label', 'feat_layers', 'feat_shapes',
+                                         'anchor_size_bounds', 'anchor_sizes', 'anchor_ratios', 'anchor_steps',
+                                         'anchor_offset', 'normalizations', 'prior_scaling'])
+
+
+class SSDNet(RONNet):
+    """SSD VGG-based 512 network: conv4 64x64, conv7 32x32, conv8 16x16, conv9 8x8, conv10 4x4, conv11 2x2, conv12 1x1."""
+    default_params = SSDParams(
+        img_shape=(512, 512),
+        num_classes=21,
+        no_annotation_label=21,
+        feat_layers=['block4', 'block7', 'block8', 'block9', 'block10', 'block11', 'block12'],
+        feat_shapes=[(64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (2, 2), (1, 1)],
+        anchor_size_bounds=[0.10, 0.90],
+        anchor_sizes=[(20.48, 51.2), (51.2, 133.12), (133.12, 215.04), (215.04, 296.96), (296.96, 378.88),
+                      (378.88, 460.8), (460.8, 542.72)],
+        anchor_ratios=[[2, .5], [2, .5, 3, 1. / 3], [2, .5, 3, 1. / 3], [2, .5, 3, 1. / 3], [2, .5, 3, 1. / 3], [2, .5], [2, .5]],
+        anchor_steps=[8, 16, 32, 64, 128, 256, 512],
+        anchor_offset=0.5,
+        normalizations=[20, -1, -1, -1, -1, -1, -1],
+        prior_scaling=[0.1, 0.1, 0.2, 0.2])
+
+    def __init__(self, params=None, dtype='bf16', max_batch=16, device=None, fuse_pools=False):
+        self.params = params if isinstance(params, SSDParams) else SSDNet.default_params
+        if dtype not in _lib.DTYPES:
+            raise ValueError('Unknown dtype %s' % dtype)
+        self.variant, self.dtype, self.max_batch, self.fuse_pools = 'ssd512', dtype, max_batch, fuse_pools
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self._ctx = None
+        self._anchors_dev = None
+
+    def _head_buffers(self, n):
+        nc = self.params.num_classes
+        cls, loc = [], []
+        for i, (fh, fw) in enumerate(self.params.feat_shapes):
+            a = len(self.params.anchor_sizes[i]) + len(self.params.anchor_ratios[i])
+            cls.append(torch.empty((n, fh, fw, a, nc), dtype=torch.float32, device=self.device))
+            loc.append(torch.empty((n, fh, fw, a, 4), dtype=torch.float32, device=self.device))
+        return cls, None, loc
+
+    def forward_heads(self, inputs):
+        """Conv stack only: (logits, None, localisations)."""
+        inputs = inputs.to(self.device, torch.float32).contiguous()
+        n = inputs.shape[0]
+        assert tuple(inputs.shape[1:]) == tuple(self.params.img_shape) + (3,)
+        cls, _, loc = self._head_buffers(n)
+        hd = _lib.Heads()
+        for i in range(len(cls)):
+            hd.cls[i], hd.loc[i] = cls[i].data_ptr(), loc[i].data_ptr()
+        check(lib().ron_forward(self._context(), ptr(inputs), n, C.byref(hd), current_stream()))
+        return cls, None, loc
+
+    def net(self, inputs, is_training=True, update_feat_shapes=True, dropout_keep_prob=0.5, prediction_fn=None, reuse=None,
+            scope='ssd_512_vgg', end_points=('block4', 'block7', 'block8', 'block9', 'block10', 'block11', 'block12')):
+        """nets/ssd_vgg_512.py:108-133 -> (predictions, localisations, logits, end_points)."""
+        logits, _, localisations = self.forward_heads(inputs)
+        fn = prediction_fn if prediction_fn is not None else ops.softmax_last
+        predictions = [fn(l) for l in logits]
+        eps = {name: self.end_point(name, inputs.shape[0]) for name in (end_points or ())}
+        return predictions, localisations, logits, eps
+
+    def update_feature_shapes(self, predictions):
+        """nets/ssd_vgg_512.py:141-146: feat_shapes from the prediction tensors."""
+        self.params = self.params._replace(feat_shapes=[tuple(p.shape[1:3]) for p in predictions])
+
+    def anchors(self, img_shape, dtype=np.float32):
+        """nets/ssd_vgg_512.py:148-157: list of (y, x, h, w) per layer."""
+        p = self.params
+        out = []
+        for i, s in enumerate(p.feat_shapes):
+            fh, fw = int(s[0]), int(s[1])
+            sizes, ratios = p.anchor_sizes[i], p.anchor_ratios[i]
+            na = len(sizes) + len(ratios)
+            y = np.empty((fh, fw, 1), np.float32)
+            x = np.empty((fh, fw, 1), np.float32)
+            h = np.empty((na,), np.float32)
+            w = np.empty((na,), np.float32)
+            sz = (C.c_double * len(sizes))(*[float(v) for v in sizes])
+            rt = (C.c_double * max(len(ratios), 1))(*[float(v) for v in ratios])
+            check(lib().ron_ssd_anchor_one_layer(int(img_shape[0]), int(img_shape[1]), fh, fw, sz, len(sizes), rt, len(ratios),
+                                                 float(p.anchor_steps[i]), float(p.anchor_offset), ptr(y), ptr(x), ptr(h), ptr(w)))
+            out.append((y.astype(dtype, copy=False), x.astype(dtype, copy=False), h.astype(dtype, copy=False), w.astype(dtype, copy=False)))
+        return out
+
+    def detected_bboxes(self, predictions, localisations, select_threshold=None, nms_threshold=0.5, clipping_bbox=None,
+                        top_k=400, keep_top_k=200, nms_mode='min'):
+        """nets/ssd_vgg_512.py:182-201: select -> sort -> NMS; `clipping_bbox` is accepted and ignored like there."""
+        from .. import tfe
+        return tfe.detected_bboxes(predictions, localisations, num_classes=self.params.num_classes,
+                                   select_threshold=select_threshold, nms_threshold=nms_threshold, clipping_bbox=None,
+                                   top_k=top_k, keep_top_k=keep_top_k, nms_mode=nms_mode, min_size=None)
+
+    def detect(self, inputs, select_threshold=0.01, nms_threshold=0.45, top_k=400, bbox_img=(0., 0., 1., 1.)):
+        """forward + np_methods post-processing (no objectness gate for SSD)."""
+        return RONNet.detect(self, inputs, objectness_thres=0.0, select_threshold=select_threshold,
+                             nms_threshold=nms_threshold, top_k=top_k, bbox_img=bbox_img)

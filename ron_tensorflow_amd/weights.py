@@ -52,6 +52,63 @@ def variable_shapes(variant='reducedfc', num_classes=21, num_anchors=10):
     return out
 
 
+SSD_SCOPE = 'ssd_512_vgg'
+SSD_FEAT_LAYERS = ['block4', 'block7', 'block8', 'block9', 'block10', 'block11', 'block12']
+SSD_ANCHORS = [4, 6, 6, 6, 6, 4, 4]
+SSD_FEAT_CHANNELS = [512, 1024, 512, 256, 256, 256, 256]
+
+
+def ssd_variable_shapes(num_classes=21):
+    """(tf_name, shape) of SSD-512 (nets/ssd_vgg_512.py:364-460, multibox layer nets/ssd_vgg_300.py:403-431)."""
+    out = []
+
+    def conv(scope, k, cin, cout):
+        out.append(('%s/%s/weights' % (SSD_SCOPE, scope), (k, k, cin, cout)))
+        out.append(('%s/%s/biases' % (SSD_SCOPE, scope), (cout,)))
+
+    cin = 3
+    for b, (reps, width) in enumerate([(2, 64), (2, 128), (3, 256), (3, 512), (3, 512)]):
+        for r in range(reps):
+            conv('conv%d/conv%d_%d' % (b + 1, b + 1, r + 1), 3, cin, width)
+            cin = width
+    conv('conv6', 3, 512, 1024)
+    conv('conv7', 1, 1024, 1024)
+    for b, (inc, mid, outc) in enumerate([(1024, 256, 512), (512, 128, 256), (256, 128, 256), (256, 128, 256), (256, 128, 256)]):
+        conv('block%d/conv1x1' % (8 + b), 1, inc, mid)
+        conv('block%d/%s' % (8 + b, 'conv4x4' if b == 4 else 'conv3x3'), 4 if b == 4 else 3, mid, outc)
+    for i, layer in enumerate(SSD_FEAT_LAYERS):
+        if i == 0:
+            out.append(('%s/%s_box/L2Normalization/gamma' % (SSD_SCOPE, layer), (512,)))
+        conv(layer + '_box/conv_loc', 3, SSD_FEAT_CHANNELS[i], SSD_ANCHORS[i] * 4)
+        conv(layer + '_box/conv_cls', 3, SSD_FEAT_CHANNELS[i], SSD_ANCHORS[i] * num_classes)
+    return out
+
+
+def ssd_synthetic_weights(num_classes=21, seed=5, bg=6.0, input_scale=1.0 / 64.0):
+    """Seeded He-normal weights for SSD-512; +bg on every background logit; L2-norm scale 20 (the reference's init)."""
+    rs = np.random.RandomState(seed)
+    w = {}
+    for name, shape in ssd_variable_shapes(num_classes):
+        leaf = name.rsplit('/', 1)[1]
+        if leaf == 'weights':
+            a = rs.standard_normal(int(np.prod(shape))).astype(np.float32).reshape(shape)
+            a *= np.float32(np.sqrt(2.0 / (shape[0] * shape[1] * shape[2])))
+            if name.endswith('conv1/conv1_1/weights'):
+                a *= np.float32(input_scale)
+            if '_box/' in name:
+                a *= np.float32(0.3 / np.sqrt(2.0))           # logit std ~1 (block4's input is L2-normalised to norm 20)
+        elif leaf == 'biases':
+            a = (rs.standard_normal(shape) * 0.01).astype(np.float32)
+            if name.endswith('conv_cls/biases'):
+                a.reshape(-1, num_classes)[:, 0] += np.float32(bg)
+        elif leaf == 'gamma':
+            a = np.full(shape, 20.0, dtype=np.float32)
+        else:
+            raise AssertionError(name)
+        w[name] = a
+    return w
+
+
 def synthetic_weights(variant='reducedfc', num_classes=21, num_anchors=10, seed=1, bg=8.0, ob=-4.0,
                       input_scale=1.0 / 64.0, head_gain=0.25):
     """Seeded random weights of the exact architecture.

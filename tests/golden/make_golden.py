@@ -70,6 +70,17 @@ def g1_anchors(ron):
     return layers
 
 
+def g5_anchors_ssd(ron_module):
+    """SSD-512 anchors from the reference's ssd_anchors_all_layers (nets/ssd_vgg_512.py:286-358)."""
+    from nets import ssd_vgg_512
+    net = ssd_vgg_512.SSDNet()
+    layers = net.anchors((512, 512))
+    out = {}
+    for i, (y, x, h, w) in enumerate(layers):
+        out['y%d' % i], out['x%d' % i], out['h%d' % i], out['w%d' % i] = y, x, h, w
+    np.savez_compressed(os.path.join(HERE, 'g5_anchors_ssd512.npz'), **out)
+
+
 def g2_decode(npm, anchors):
     out = {'seed': np.int64(11)}
     rs = np.random.RandomState(11)
@@ -207,6 +218,7 @@ def main():
     npm = load_np_methods()
     ron = load_ref_ron()
     anchors = g1_anchors(ron)
+    g5_anchors_ssd(ron)
     g2_decode(npm, anchors)
     g3_pipeline(npm, anchors)
     g4_edge(npm)

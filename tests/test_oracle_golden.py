@@ -136,3 +136,14 @@ def test_g4_select_threshold_and_topk_cut(golden_dir):
     assert np.array_equal(c, g['cut/sorted_classes'])
     assert np.array_equal(s, g['cut/sorted_scores'])
     assert np.array_equal(b, g['cut/sorted_bboxes'])
+
+
+def test_g5_ssd512_anchors_bit_exact(golden_dir):
+    from oracle import ssd_forward as osf
+    g = _load(golden_dir, 'g5_anchors_ssd512.npz')
+    layers = osf.anchors_all_layers()
+    assert [len(l[2]) for l in layers] == [4, 6, 6, 6, 6, 4, 4]
+    assert sum(l[0].shape[0] * l[0].shape[1] * len(l[2]) for l in layers) == 24564
+    for i, (y, x, h, w) in enumerate(layers):
+        for nm, arr in (('y', y), ('x', x), ('h', h), ('w', w)):
+            assert np.array_equal(arr, g['%s%d' % (nm, i)]), (nm, i)
