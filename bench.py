@@ -37,7 +37,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step (BASELINE config 2: 32)')
-    ap.add_argument('--variant', default='full', choices=['full', 'reducedfc'])
+    ap.add_argument('--variant', default='full', choices=['full', 'reducedfc', 'ssd512'],
+                    help="full = BASELINE configs 2/3 (default); reducedfc = config 4; ssd512 = config 5")
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4, help='images in the bounded CPU-baseline sample')
@@ -50,11 +51,16 @@ def cpu_baseline(variant, weights, n_images):
     from oracle import anchors as oanchors
     from oracle import np_post
     from oracle import ron_forward as orf
+    from oracle import ssd_forward as osf
     from ron_tensorflow_amd.weights import synthetic_images
-    anchors = oanchors.anchors_all_layers()
-    x = synthetic_images(n_images + 1, seed=10)
+    ssd = variant == 'ssd512'
+    anchors = osf.anchors_all_layers() if ssd else oanchors.anchors_all_layers()
+    x = synthetic_images(n_images + 1, seed=10, img_shape=(512, 512) if ssd else (320, 320))
 
     def run(batch):
+        if ssd:
+            pred, loc, _, _ = osf.ssd_forward(batch, weights)
+            return np_post.detect_from_predictions(pred, loc, anchors, objness_pred=None)
         pred, _, objp, _, loc, _ = orf.ron_forward(batch, weights, variant, backend='numpy')
         return np_post.detect_from_predictions(pred, loc, anchors, objness_pred=objp)
 
@@ -90,16 +96,21 @@ def main():
 
     from ron_tensorflow_amd import _lib
     from ron_tensorflow_amd.nets import nets_factory
-    from ron_tensorflow_amd.weights import synthetic_images, synthetic_weights
+    from ron_tensorflow_amd.weights import ssd_synthetic_weights, synthetic_images, synthetic_weights
     import ctypes as C
 
     # ---- the reference's call pattern (eval_ron_network.py:148-152): factory -> class -> params -> net
-    ron_class = nets_factory.get_network('ron_320_vgg')
+    ssd = args.variant == 'ssd512'
+    ron_class = nets_factory.get_network('ssd_512_vgg' if ssd else 'ron_320_vgg')
     ron_params = ron_class.default_params._replace(num_classes=21)
-    weights = synthetic_weights(args.variant, seed=1)     # seed 1: ~4.8 k candidates, ~230 detections per image (full)
-    net = ron_class(ron_params, variant=args.variant, dtype=args.dtype, max_batch=args.batch, device=dev, fuse_pools=True)
+    if ssd:
+        weights = ssd_synthetic_weights(seed=5)
+        net = ron_class(ron_params, dtype=args.dtype, max_batch=args.batch, device=dev, fuse_pools=True)
+    else:
+        weights = synthetic_weights(args.variant, seed=1)     # seed 1: ~4.8 k candidates, ~230 detections per image (full)
+        net = ron_class(ron_params, variant=args.variant, dtype=args.dtype, max_batch=args.batch, device=dev, fuse_pools=True)
     net.load_weights(weights)
-    images = torch.from_numpy(synthetic_images(args.batch, seed=3 + rank)).to(dev)      # resident in HBM
+    images = torch.from_numpy(synthetic_images(args.batch, seed=3 + rank, img_shape=ron_params.img_shape)).to(dev)   # resident in HBM
     top_k = 400
 
     from ron_tensorflow_amd import parallel
@@ -108,7 +119,10 @@ def main():
         gathered = torch.empty((world, args.batch, top_k + 1, parallel.RECORD_WIDTH), dtype=torch.float32, device=dev)
 
     def step():
-        det = net.detect(images, objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45, top_k=top_k)
+        if ssd:
+            det = net.detect(images, select_threshold=0.01, nms_threshold=0.45, top_k=top_k)
+        else:
+            det = net.detect(images, objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45, top_k=top_k)
         if world > 1:
             rec = parallel.pack_records(det.classes, det.scores, det.bboxes, det.anchor_index, det.count)
             parallel.gather_detections(rec, out=gathered)
@@ -155,7 +169,7 @@ def main():
     if rank == 0:
         total_images = world * args.batch * args.steps
         out = {
-            'metric': 'images/sec RON-VGG16-320 inference',
+            'metric': 'images/sec SSD-VGG-512 inference' if ssd else 'images/sec RON-VGG16-320 inference',
             'value': total_images / dt,
             'unit': 'images/s',
             'n_gpus': world,
@@ -167,9 +181,10 @@ def main():
             'vs_baseline': None,
             'dtype': args.dtype,
             'data': 'synthetic',
-            'config': {'workload': 'RON-320 %s (%s) batch=%d per GPU, synthetic 320x320x3 inputs resident in HBM, '
+            'config': {'workload': '%s (%s) batch=%d per GPU, synthetic %dx%dx3 inputs resident in HBM, '
                                    'forward + np_methods decode/select/top-400/NMS%s'
-                                   % ('VGG16 ron_net' if args.variant == 'full' else 'reducedfc', args.dtype, args.batch,
+                                   % ({'full': 'RON-320 VGG16 ron_net', 'reducedfc': 'RON-320 reducedfc', 'ssd512': 'SSD-VGG-512'}[args.variant],
+                                      args.dtype, args.batch, ron_params.img_shape[0], ron_params.img_shape[1],
                                       ', RCCL all-gather of detection records' if world > 1 else ''),
                        'images_per_step': world * args.batch,
                        'gflop_per_image': net.flops_per_image() / 1e9,
