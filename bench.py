@@ -75,6 +75,18 @@ def cpu_baseline(variant, weights, n_images):
                       'post-processing; %.1f s' % (n_images, variant, dt)}
 
 
+def load_traffic(args):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_bench.sh ->
+    profiles/<round>/traffic_*.json); None when no measurement exists for this configuration."""
+    import glob
+    key = '%s_%s_bs%d' % (args.variant, args.dtype, args.batch)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'traffic_%s.json' % key)))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get('hbm_bytes_per_conv_launch')
+
+
 def main():
     args = parse()
     import torch
@@ -156,14 +168,18 @@ def main():
     nops = lib.ron_profile_num_ops(net._context())
     for i in range(nops):
         name, is_conv, fl, ms, ln = C.c_char_p(), C.c_int(), C.c_double(), C.c_double(), C.c_int()
-        _lib.check(lib.ron_profile_get(net._context(), i, C.byref(name), C.byref(is_conv), C.byref(fl), C.byref(ms), C.byref(ln)))
+        ab, wb = C.c_double(), C.c_double()
+        _lib.check(lib.ron_profile_get(net._context(), i, C.byref(name), C.byref(is_conv), C.byref(fl), C.byref(ms), C.byref(ln),
+                                       C.byref(ab), C.byref(wb)))
         rows.append(dict(name=name.value.decode(), is_conv=bool(is_conv.value), gflop_per_image=fl.value / 1e9,
-                         total_ms=ms.value, launches=ln.value))
+                         total_ms=ms.value, launches=ln.value, bytes_per_launch=ab.value * args.batch + wb.value))
     conv = [r for r in rows if r['is_conv'] and r['launches'] > 0]
     conv_ms = sum(r['total_ms'] for r in conv)
     conv_launches = sum(r['launches'] for r in conv)
     conv_flop = sum(r['gflop_per_image'] * 1e9 * args.batch * r['launches'] for r in conv)
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    algo_bytes = sum(r['bytes_per_launch'] * r['launches'] for r in conv) / max(conv_launches, 1)
+    traffic = load_traffic(args)
     peak = {'bf16': PEAK_BF16_TFLOPS, 'fp16': PEAK_F16_TFLOPS, 'fp32': PEAK_F32_TFLOPS}[args.dtype]
 
     if rank == 0:
@@ -191,7 +207,8 @@ def main():
                        'conv_stack_tflops_per_gpu': net.flops_per_image() * args.batch * args.steps / dt / 1e12,
                        'mean_detections_per_image': float(det.count.float().mean().item())},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel', 'achieved': achieved, 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': algo_bytes,
                          'avg_launch_us': conv_ms / max(conv_launches, 1) * 1e3,
                          'launches_per_step': conv_launches // max(args.steps, 1),
                          'kernel_time_share': conv_ms / (dt * 1e3)},

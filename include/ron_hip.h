@@ -239,11 +239,12 @@ double ron_flops_per_image(const ron_ctx* ctx);
  * only timing is wall-clock prints, eval_ron_network.py:353,363-366).  While enabled, ron_forward /
  * ron_detect bracket every launch with an event; ron_profile_get synchronises on the recorded events and
  * returns, for launch i (the last index is the post-processing stage of ron_detect), its name, whether it is
- * the implicit-GEMM conv kernel, its algorithmic FLOPs per image, the accumulated time and launch count. */
+ * the implicit-GEMM conv kernel, its algorithmic FLOPs per image, the accumulated time and launch count, and its
+ * algorithmic HBM bytes (activations in + out per image; packed weights once per launch). */
 int ron_profile_enable(ron_ctx* ctx, int enable);
 int ron_profile_num_ops(const ron_ctx* ctx);
 int ron_profile_get(ron_ctx* ctx, int i, const char** name, int* is_conv, double* flops_per_image,
-                    double* total_ms, int* launches);
+                    double* total_ms, int* launches, double* act_bytes_per_image, double* weight_bytes);
 int ron_profile_reset(ron_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------

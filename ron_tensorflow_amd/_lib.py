@@ -100,7 +100,7 @@ SIGNATURES = {
     'ron_profile_enable': (C.c_int, [_P, C.c_int]),
     'ron_profile_num_ops': (C.c_int, [_P]),
     'ron_profile_get': (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_double),
-                                  C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'ron_profile_reset': (C.c_int, [_P]),
     'ron_conv2d_nhwc': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     'ron_maxpool2x2_nhwc': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

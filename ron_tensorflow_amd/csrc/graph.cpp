@@ -69,6 +69,8 @@ struct Op {
   int head_kind = -1, head_layer = -1;  // 0 cls, 1 obj, 2 loc
   int Ho = 0, Wo = 0;
   double flops = 0;                     // algorithmic 2*MAC per image of this launch
+  double act_bytes = 0;                 // algorithmic HBM bytes per image: input read once + output written once
+  double wgt_bytes = 0;                 // ... plus the packed weights, once per launch
 };
 
 struct OpTiming {
@@ -741,6 +743,18 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
     }
   }
   if (c->splitk_bytes > 0) RON_HIP_CHECK(hipMalloc(&c->d_splitk, (size_t)c->splitk_bytes));
+  for (Op& o : c->ops) {
+    if (o.kind != OP_CONV) continue;
+    const PackedConv& pk = c->packed[o.packed];
+    const Tensor& ti = c->tensors[o.in];
+    const int cin = o.in_C > 0 ? o.in_C : ti.C;
+    const double out_esz = o.out == -2 ? 4.0 : (double)c->esz();
+    const int os = o.up > 0 ? o.up * o.up : 1;
+    const double out_px = o.pool ? (double)o.Ho * o.Wo / 4 : (double)o.Ho * o.Wo * os;
+    const double out_ch = o.up > 0 ? (double)o.up_cout : (double)pk.Cout;
+    o.act_bytes = (double)ti.H * ti.W * cin * c->esz() + out_px * out_ch * out_esz + (o.res >= 0 ? out_px * out_ch * c->esz() : 0.0);
+    o.wgt_bytes = (double)pk.w_bytes;
+  }
   c->timing.assign(c->ops.size() + 1, OpTiming());
   for (auto& v : c->vars) { v.data.clear(); v.data.shrink_to_fit(); }
   c->finalized = true;
@@ -862,7 +876,7 @@ static int profile_collect(ron_ctx* c) {
 extern "C" int ron_profile_num_ops(const ron_ctx* c) { return c ? (int)c->ops.size() + 1 : RON_ERR_INVALID; }
 
 extern "C" int ron_profile_get(ron_ctx* c, int i, const char** name, int* is_conv, double* flops_per_image,
-                               double* total_ms, int* launches) {
+                               double* total_ms, int* launches, double* act_bytes_per_image, double* weight_bytes) {
   RON_REQUIRE(c && i >= 0 && i <= (int)c->ops.size(), "op index out of range");
   int rc = profile_collect(c);
   if (rc) return rc;
@@ -872,6 +886,8 @@ extern "C" int ron_profile_get(ron_ctx* c, int i, const char** name, int* is_con
   if (flops_per_image) *flops_per_image = post ? 0.0 : c->ops[i].flops;
   if (total_ms) *total_ms = c->timing[i].ms;
   if (launches) *launches = c->timing[i].launches;
+  if (act_bytes_per_image) *act_bytes_per_image = post ? 0.0 : c->ops[i].act_bytes;
+  if (weight_bytes) *weight_bytes = post ? 0.0 : c->ops[i].wgt_bytes;
   return RON_OK;
 }
 
