@@ -1,0 +1,134 @@
+// Device-side pieces shared by the implicit-GEMM conv kernels (conv_mfma.hip, conv_patch.hip): kernel arguments,
+// dtype traits (MFMA + conversions), vector stores.
+#pragma once
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "conv_mfma.h"
+
+namespace ron {
+namespace detail {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int N> struct alignas(4 * N) F32Vec { float v[N]; };
+template <int N> __device__ __forceinline__ void store_f32_vec(float* p, const float* v) {
+  F32Vec<N> t;
+#pragma unroll
+  for (int j = 0; j < N; ++j) t.v[j] = v[j];
+  *reinterpret_cast<F32Vec<N>*>(p) = t;
+}
+template <class E, int N> struct alignas(sizeof(E) * N) EVec { E v[N]; };
+
+struct ConvArgs {
+  const void* in;
+  unsigned in_bytes;
+  const void* wgt;
+  unsigned wgt_bytes;
+  const float* bias;
+  void* out;
+  const void* res;
+  int M, Ho, Wo;
+  int in_Hp, in_Wp, in_cstride, in_org;     // in_org = in.pad - cpad  (first tap of output (0,0))
+  int in_coff;
+  int Cin, kw, KT;                          // KT = kh*kw*Cin / chunk
+  int stride, dil;
+  int K;                                    // elements per weight row
+  int Cout;
+  int out_Hp, out_Wp, out_cstride, out_pad, out_coff;
+  int up, up_cout;
+  int relu, out_f32;
+  int tiles_n;
+  // split-K: workgroup z of `splitk` covers K steps [z*kt_split, (z+1)*kt_split) and stores raw fp32 sums to
+  // partial[z][m][n] (n < Npad); splitk_finalize_kernel adds the slabs and applies the epilogue.
+  int splitk, kt_split, tiles_total, Npad;
+  float* partial;
+  // fused 2x2 / stride-2 max-pool: tile rows are ordered window-major (rows 4q..4q+3 = the four conv outputs of
+  // pooled pixel q), which puts a window into four consecutive accumulator registers of one lane.
+  int pool;
+};
+
+struct TraitsBF16 {
+  typedef __hip_bfloat16 elem;
+  static constexpr int kEsz = 2;
+  static constexpr int kMfmaPerMma = 1;
+  static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float load(const void* p, int i) {
+    return __bfloat162float(reinterpret_cast<const __hip_bfloat16*>(p)[i]);
+  }
+  static __device__ __forceinline__ void store(void* p, int i, float v) {
+    reinterpret_cast<__hip_bfloat16*>(p)[i] = __float2bfloat16(v);
+  }
+  template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
+    EVec<__hip_bfloat16, N> t;
+#pragma unroll
+    for (int j = 0; j < N; ++j) t.v[j] = __float2bfloat16(v[j]);
+    *reinterpret_cast<EVec<__hip_bfloat16, N>*>(reinterpret_cast<__hip_bfloat16*>(p) + i) = t;
+  }
+  template <int N> static __device__ __forceinline__ void load_vec(const void* p, int i, float* v) {
+    const EVec<__hip_bfloat16, N> t = *reinterpret_cast<const EVec<__hip_bfloat16, N>*>(reinterpret_cast<const __hip_bfloat16*>(p) + i);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = __bfloat162float(t.v[j]);
+  }
+};
+struct TraitsF16 {
+  typedef _Float16 elem;
+  static constexpr int kEsz = 2;
+  static constexpr int kMfmaPerMma = 1;
+  static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float load(const void* p, int i) {
+    return (float)reinterpret_cast<const _Float16*>(p)[i];
+  }
+  static __device__ __forceinline__ void store(void* p, int i, float v) {
+    reinterpret_cast<_Float16*>(p)[i] = (_Float16)v;
+  }
+  template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
+    EVec<_Float16, N> t;
+#pragma unroll
+    for (int j = 0; j < N; ++j) t.v[j] = (_Float16)v[j];
+    *reinterpret_cast<EVec<_Float16, N>*>(reinterpret_cast<_Float16*>(p) + i) = t;
+  }
+  template <int N> static __device__ __forceinline__ void load_vec(const void* p, int i, float* v) {
+    const EVec<_Float16, N> t = *reinterpret_cast<const EVec<_Float16, N>*>(reinterpret_cast<const _Float16*>(p) + i);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = (float)t.v[j];
+  }
+};
+struct TraitsF32 {
+  typedef float elem;
+  static constexpr int kEsz = 4;
+  static constexpr int kMfmaPerMma = 4;
+  static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
+    // lane half h holds k = 4*(2s+h) + q, q = 0..3, for both operands: four exact-f32 MFMAs
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float load(const void* p, int i) { return reinterpret_cast<const float*>(p)[i]; }
+  static __device__ __forceinline__ void store(void* p, int i, float v) { reinterpret_cast<float*>(p)[i] = v; }
+  template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
+    store_f32_vec<N>(reinterpret_cast<float*>(p) + i, v);
+  }
+  template <int N> static __device__ __forceinline__ void load_vec(const void* p, int i, float* v) {
+    const F32Vec<N> t = *reinterpret_cast<const F32Vec<N>*>(reinterpret_cast<const float*>(p) + i);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = t.v[j];
+  }
+};
+
+constexpr int kRowBytes = 128;   // one LDS row = one K chunk of one tile row
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+}  // namespace detail
+}  // namespace ron

@@ -45,6 +45,10 @@ struct ConvLaunch {
 };
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream);
+// 3x3 / stride 1 / pad 1 with the input halo patch staged once per channel chunk (conv_patch.hip); cfg = kCfgPatch forces it
+constexpr int kCfgPatch = 100;
+bool conv_patch_applicable(const ConvLaunch& c);
+int launch_conv_patch(const ConvLaunch& c, hipStream_t stream);
 // Elements along K one staging step covers for this dtype (Cin must be a multiple of it).
 int conv_k_chunk(int dtype);
 int conv_n_tile(int cout);       // granularity Cout is padded to (64 or 128)

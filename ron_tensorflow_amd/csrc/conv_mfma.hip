@@ -17,134 +17,11 @@
 // (one per 16 k), f32 uses v_mfma_f32_32x32x2_f32 (exact fp32 fma chain; the parity mode).
 // Epilogue: + bias, ReLU, optional  relu(x + residual)  (reverse-connection sum), optional
 // pixel-shuffle addressing (2x2 stride-2 transposed conv), store as dtype or fp32.
-#include <hip/hip_bf16.h>
-#include <hip/hip_fp16.h>
-
-#include "conv_mfma.h"
+#include "conv_device.h"
 
 namespace ron {
 namespace detail {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-template <int N> struct alignas(4 * N) F32Vec { float v[N]; };
-template <int N> __device__ __forceinline__ void store_f32_vec(float* p, const float* v) {
-  F32Vec<N> t;
-#pragma unroll
-  for (int j = 0; j < N; ++j) t.v[j] = v[j];
-  *reinterpret_cast<F32Vec<N>*>(p) = t;
-}
-template <class E, int N> struct alignas(sizeof(E) * N) EVec { E v[N]; };
-
-struct ConvArgs {
-  const void* in;
-  unsigned in_bytes;
-  const void* wgt;
-  unsigned wgt_bytes;
-  const float* bias;
-  void* out;
-  const void* res;
-  int M, Ho, Wo;
-  int in_Hp, in_Wp, in_cstride, in_org;     // in_org = in.pad - cpad  (first tap of output (0,0))
-  int in_coff;
-  int Cin, kw, KT;                          // KT = kh*kw*Cin / chunk
-  int stride, dil;
-  int K;                                    // elements per weight row
-  int Cout;
-  int out_Hp, out_Wp, out_cstride, out_pad, out_coff;
-  int up, up_cout;
-  int relu, out_f32;
-  int tiles_n;
-  // split-K: workgroup z of `splitk` covers K steps [z*kt_split, (z+1)*kt_split) and stores raw fp32 sums to
-  // partial[z][m][n] (n < Npad); splitk_finalize_kernel adds the slabs and applies the epilogue.
-  int splitk, kt_split, tiles_total, Npad;
-  float* partial;
-  // fused 2x2 / stride-2 max-pool: tile rows are ordered window-major (rows 4q..4q+3 = the four conv outputs of
-  // pooled pixel q), which puts a window into four consecutive accumulator registers of one lane.
-  int pool;
-};
-
-struct TraitsBF16 {
-  typedef __hip_bfloat16 elem;
-  static constexpr int kEsz = 2;
-  static constexpr int kMfmaPerMma = 1;
-  static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ float load(const void* p, int i) {
-    return __bfloat162float(reinterpret_cast<const __hip_bfloat16*>(p)[i]);
-  }
-  static __device__ __forceinline__ void store(void* p, int i, float v) {
-    reinterpret_cast<__hip_bfloat16*>(p)[i] = __float2bfloat16(v);
-  }
-  template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
-    EVec<__hip_bfloat16, N> t;
-#pragma unroll
-    for (int j = 0; j < N; ++j) t.v[j] = __float2bfloat16(v[j]);
-    *reinterpret_cast<EVec<__hip_bfloat16, N>*>(reinterpret_cast<__hip_bfloat16*>(p) + i) = t;
-  }
-  template <int N> static __device__ __forceinline__ void load_vec(const void* p, int i, float* v) {
-    const EVec<__hip_bfloat16, N> t = *reinterpret_cast<const EVec<__hip_bfloat16, N>*>(reinterpret_cast<const __hip_bfloat16*>(p) + i);
-#pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = __bfloat162float(t.v[j]);
-  }
-};
-struct TraitsF16 {
-  typedef _Float16 elem;
-  static constexpr int kEsz = 2;
-  static constexpr int kMfmaPerMma = 1;
-  static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ float load(const void* p, int i) {
-    return (float)reinterpret_cast<const _Float16*>(p)[i];
-  }
-  static __device__ __forceinline__ void store(void* p, int i, float v) {
-    reinterpret_cast<_Float16*>(p)[i] = (_Float16)v;
-  }
-  template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
-    EVec<_Float16, N> t;
-#pragma unroll
-    for (int j = 0; j < N; ++j) t.v[j] = (_Float16)v[j];
-    *reinterpret_cast<EVec<_Float16, N>*>(reinterpret_cast<_Float16*>(p) + i) = t;
-  }
-  template <int N> static __device__ __forceinline__ void load_vec(const void* p, int i, float* v) {
-    const EVec<_Float16, N> t = *reinterpret_cast<const EVec<_Float16, N>*>(reinterpret_cast<const _Float16*>(p) + i);
-#pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = (float)t.v[j];
-  }
-};
-struct TraitsF32 {
-  typedef float elem;
-  static constexpr int kEsz = 4;
-  static constexpr int kMfmaPerMma = 4;
-  static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
-    // lane half h holds k = 4*(2s+h) + q, q = 0..3, for both operands: four exact-f32 MFMAs
-    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ float load(const void* p, int i) { return reinterpret_cast<const float*>(p)[i]; }
-  static __device__ __forceinline__ void store(void* p, int i, float v) { reinterpret_cast<float*>(p)[i] = v; }
-  template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
-    store_f32_vec<N>(reinterpret_cast<float*>(p) + i, v);
-  }
-  template <int N> static __device__ __forceinline__ void load_vec(const void* p, int i, float* v) {
-    const F32Vec<N> t = *reinterpret_cast<const F32Vec<N>*>(reinterpret_cast<const float*>(p) + i);
-#pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = t.v[j];
-  }
-};
-
-constexpr int kRowBytes = 128;   // one LDS row = one K chunk of one tile row
-
-typedef __attribute__((address_space(3))) void lds_void;
 
 // all of this wave's LDS reads retired (the stage about to be refilled is no longer being read) and all but
 // its N youngest LDS-DMA transfers landed
@@ -253,7 +130,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
   // part once per tile, RON_STAGE_PIECE issues piece i (compile-time), RON_STAGE_END advances the tap.
 #define RON_STAGE_BEGIN(kt_)                                                                                         \
     /* past the last tile: zero-record descriptors, the DMA moves nothing but keeps the vmcnt bookkeeping uniform */  \
-    const bool live_ = (kt_) < kt1;                                                                                  \
+    const bool live_ = ABL != 4 && (kt_) < kt1;                                                                               \
     const __amdgpu_buffer_rsrc_t rs_a =                                                                              \
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, live_ ? p.in_bytes : 0u, 0x00020000);          \
     const __amdgpu_buffer_rsrc_t rs_b =                                                                              \
@@ -263,7 +140,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
     char* dst = smem + (((kt_) - kt0) % S) * kStage + wave * (8 * kRowBytes);
 #define RON_STAGE_PIECE(i_)                                                                                          \
     do {                                                                                                             \
-      if (ABL == 1) break;                                                                                           \
+      if (ABL == 1 || ABL == 3) break;                                                                                        \
       if ((i_) < A_IT)                                                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst + (i_) * kRowsPerIt * kRowBytes), 16,         \
                                                  a_voff[(i_) < A_IT ? (i_) : 0], a_soff, 0, 0);                      \
@@ -306,8 +183,10 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
   }
 
   for (int kt = kt0; kt < kt1; ++kt) {
+    if (ABL != 3) {
     wait_vmcnt<(S - 2) * LPT>();            // this wave's share of tile kt has landed
     __builtin_amdgcn_s_barrier();           // ... everyone's has, and everyone is done reading tile kt-1
+    }
     // refill the stage tile kt-1 occupied; the LPT pieces are spread over the four k-steps below so that
     // their issue slots fall into the MFMA shadow instead of ahead of it (SPREAD) or are issued up front
     RON_STAGE_BEGIN(kt + S - 1)
@@ -525,6 +404,8 @@ constexpr TileCfg kCfgs[] = {
     {128, 128, 2, 2, 2, 1},   // 15: diagnostic, 4 without LDS reads / MFMA
     {256, 256, 2, 2, 2, 1},   // 16: 4 waves, one per SIMD, wave tile 128 x 128 (256 accumulator registers)
     {256, 256, 2, 2, 2, 1},   // 17: diagnostic, 16 without LDS-DMA
+    {256, 256, 4, 2, 2, 1},   // 18: diagnostic, 11 without LDS-DMA, waits and barriers (free-running ds_read + MFMA)
+    {256, 256, 4, 2, 2, 1},   // 19: diagnostic, 11 with zero-record descriptors (DMA instructions issue, nothing moves)
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 // workgroups of configuration i the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
@@ -565,6 +446,8 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 15: return launch_t<Tr, 128, 128, 2, 2, 2, true, 2>(a, s);
     case 16: return launch_t<Tr, 256, 256, 2, 2, 2, true>(a, s);
     case 17: return launch_t<Tr, 256, 256, 2, 2, 2, true, 1>(a, s);
+    case 18: return launch_t<Tr, 256, 256, 4, 2, 2, true, 3>(a, s);
+    case 19: return launch_t<Tr, 256, 256, 4, 2, 2, true, 4>(a, s);
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;
@@ -609,6 +492,7 @@ int conv_pick_cfg(int M, int Npad, int K) {
 }
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
+  if (c.cfg == kCfgPatch) return launch_conv_patch(c, stream);
   const int esz = (int)dtype_size(c.dtype);
   const int chunk = conv_k_chunk(c.dtype);
   RON_REQUIRE(c.in.C % chunk == 0, "conv: Cin %d is not a multiple of the K chunk %d", c.in.C, chunk);
@@ -667,6 +551,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
 }
 
 int64_t conv_scratch_bytes(int M, int Npad, int K, int dtype, int cfg, int splitk) {
+  if (cfg == kCfgPatch) return 0;                       // the halo-patch kernel never splits K
   const int KT = K / conv_k_chunk(dtype);
   const int c = cfg >= 0 ? cfg : conv_pick_cfg(M, Npad, K);
   const int tiles = ((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * (Npad / kCfgs[c].bn);

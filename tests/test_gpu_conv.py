@@ -123,7 +123,7 @@ def test_maxpool(ops, dev, dtype):
 def test_every_tile_configuration(ops, dev, cfg, dtype):
     """Each (tile, wave grid, stage count) variant of the kernel on a ragged multi-tile problem, K = 18 steps."""
     from ron_tensorflow_amd import _lib
-    assert _lib.lib().ron_conv_num_tile_cfgs() == 18
+    assert _lib.lib().ron_conv_num_tile_cfgs() == 20
     rs = np.random.RandomState(40 + cfg)
     x = rs.randn(3, 13, 11, 128).astype(np.float32)            # M = 429: two 256-row or four 128-row tiles, ragged
     wt = (rs.randn(3, 3, 128, 192) * 0.03).astype(np.float32)  # Cout 192 -> padded to 256
@@ -179,3 +179,48 @@ def test_conv_with_fused_maxpool(ops, dev, dtype, cfg):
     # same kernel configuration without split-K: fused pooling == pooling the stored conv output, bit for bit
     full = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=cfg, splitk=1)
     assert np.array_equal(ops.maxpool2x2_nhwc(full, dtype=dtype).cpu().numpy(), got)
+
+
+PATCH_SHAPES = [  # n, h, w, cin, cout
+    (2, 40, 40, 64, 128),     # six full 40-wide rows per tile, ragged last tile row
+    (1, 12, 64, 128, 64),     # 4 x 64 strips, N tile 64
+    (2, 16, 96, 64, 256),     # 8 x 32 tiles
+    (1, 80, 80, 64, 210),     # 40-wide half rows, Cout 210 -> masked tail
+    (3, 44, 40, 192, 20),     # Cout 20
+]
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('shape', PATCH_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_patch_kernel_conv3x3(ops, dev, shape, dtype):
+    """The halo-patch 3x3 kernel (csrc/conv_patch.hip, tile_cfg = 100) vs the oracle conv."""
+    n, h, w, cin, cout = shape
+    rs = np.random.RandomState(sum(shape))
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(3, 3, cin, cout) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rs.randn(cout) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=100).cpu().numpy()
+    _check(got, ref, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_patch_kernel_residual_and_pool(ops, dev, dtype):
+    rs = np.random.RandomState(91)
+    rnd = ROUND[dtype]
+    x = rs.randn(2, 40, 40, 128).astype(np.float32)
+    wt = (rs.randn(3, 3, 128, 128) * 0.03).astype(np.float32)
+    b = (rs.randn(128) * 0.1).astype(np.float32)
+    res = np.maximum(rs.randn(2, 40, 40, 128), 0).astype(np.float32)
+    ref = np.maximum(np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0) + rnd(res), 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, residual=torch.from_numpy(res).to(dev), relu=True, dtype=dtype,
+                          tile_cfg=100).cpu().numpy()
+    _check(got, ref, dtype)
+    for (h, w) in ((40, 40), (16, 64), (24, 96)):
+        x = rs.randn(2, h, w, 64).astype(np.float32)
+        wt = (rs.randn(3, 3, 64, 128) * 0.05).astype(np.float32)
+        ref = orf.max_pool2x2_np(np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0))
+        got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=100, pool=True).cpu().numpy()
+        assert got.shape == ref.shape
+        _check(got, ref, dtype)

@@ -58,7 +58,7 @@ def main():
     a = ap.parse_args()
     lib = _lib.lib()
     ncfg = lib.ron_conv_num_tile_cfgs()
-    cfgs = [int(c) for c in a.cfgs.split(',')] if a.cfgs else list(range(ncfg))
+    cfgs = [int(c) for c in a.cfgs.split(',')] if a.cfgs else list(range(ncfg))     # 100 = halo-patch 3x3 kernel, -1 = auto
     print('%-14s %8s %9s | ' % ('layer', 'GFLOP', 'M') + ' '.join('cfg%-2d us/TF   ' % c for c in cfgs))
     for (name, h, w, cin, cout, k, stride, rate, tr) in LAYERS:
         if a.only and a.only not in name:
