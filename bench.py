@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F16_TFLOPS = 2500.0
 PEAK_F32_TFLOPS = 157.3
+PROFILED_STEPS = 3
 
 
 def parse():
@@ -42,6 +43,9 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-images', type=int, default=4, help='images in the bounded CPU-baseline sample')
+    ap.add_argument('--multi-stream', action='store_true',
+                    help='run the block7/6/5 head branches on side streams (RON_CFG_MULTI_STREAM): +5 %% images/s measured, but the '
+                         'per-launch durations then overlap and no longer describe one kernel each, so it is off by default')
     ap.add_argument('--layers', default='', help='write the per-launch timing table to this file')
     return ap.parse_args()
 
@@ -120,7 +124,8 @@ def main():
         net = ron_class(ron_params, dtype=args.dtype, max_batch=args.batch, device=dev, fuse_pools=True)
     else:
         weights = synthetic_weights(args.variant, seed=1)     # seed 1: ~4.8 k candidates, ~230 detections per image (full)
-        net = ron_class(ron_params, variant=args.variant, dtype=args.dtype, max_batch=args.batch, device=dev, fuse_pools=True)
+        net = ron_class(ron_params, variant=args.variant, dtype=args.dtype, max_batch=args.batch, device=dev, fuse_pools=True,
+                        multi_stream=args.multi_stream)
     net.load_weights(weights)
     images = torch.from_numpy(synthetic_images(args.batch, seed=3 + rank, img_shape=ron_params.img_shape)).to(dev)   # resident in HBM
     top_k = 400
@@ -147,7 +152,9 @@ def main():
         dist.barrier()
     lib = _lib.lib()
     _lib.check(lib.ron_profile_reset(net._context()))
-    _lib.check(lib.ron_profile_enable(net._context(), 1))
+    # HIP events around every launch for PROFILED_STEPS of the timed steps (each event costs ~3 us of host + queue time,
+    # so not on all of them)
+    _lib.check(lib.ron_profile_enable(net._context(), min(PROFILED_STEPS, args.steps)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -177,6 +184,7 @@ def main():
     conv_ms = sum(r['total_ms'] for r in conv)
     conv_launches = sum(r['launches'] for r in conv)
     conv_flop = sum(r['gflop_per_image'] * 1e9 * args.batch * r['launches'] for r in conv)
+    profiled_steps = max((r['launches'] for r in conv), default=0)
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     algo_bytes = sum(r['bytes_per_launch'] * r['launches'] for r in conv) / max(conv_launches, 1)
     traffic = load_traffic(args)
@@ -210,8 +218,9 @@ def main():
                          'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': algo_bytes,
                          'avg_launch_us': conv_ms / max(conv_launches, 1) * 1e3,
-                         'launches_per_step': conv_launches // max(args.steps, 1),
-                         'kernel_time_share': conv_ms / (dt * 1e3)},
+                         'launches_per_step': conv_launches // max(profiled_steps, 1),
+                         'profiled_steps': profiled_steps,
+                         'kernel_time_share': conv_ms / max(profiled_steps, 1) / (dt / args.steps * 1e3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.variant, weights, args.cpu_images)

@@ -204,6 +204,9 @@ typedef struct {
 /* Do not materialise block1..block3 (conv1_2, conv2_2, conv3_3 at full resolution): their 2x2 max-pool is
  * fused into the conv epilogue.  ron_end_point_copy then fails for those names. */
 #define RON_CFG_FUSE_POOLS 1u
+/* Run the head branches of the three coarse scales (block7/6/5: small grids) on internal side streams beside the
+ * main chain; ron_forward / ron_detect fork after each reference map and join before returning control to `stream`. */
+#define RON_CFG_MULTI_STREAM 2u
 
 int ron_create(ron_ctx** out, const ron_config* cfg);
 int ron_destroy(ron_ctx* ctx);
@@ -236,8 +239,8 @@ int ron_detect(ron_ctx* ctx, const float* d_images, int n, const ron_post_cfg* c
 double ron_flops_per_image(const ron_ctx* ctx);
 
 /* Per-launch timing with HIP events on the caller's stream (what bench.py's roofline uses; the reference's
- * only timing is wall-clock prints, eval_ron_network.py:353,363-366).  While enabled, ron_forward /
- * ron_detect bracket every launch with an event; ron_profile_get synchronises on the recorded events and
+ * only timing is wall-clock prints, eval_ron_network.py:353,363-366).  ron_profile_enable(ctx, n) makes the next n
+ * ron_forward / ron_detect calls record one event per launch on the launch's stream (n = 0: off); ron_profile_get synchronises on the recorded events and
  * returns, for launch i (the last index is the post-processing stage of ron_detect), its name, whether it is
  * the implicit-GEMM conv kernel, its algorithmic FLOPs per image, the accumulated time and launch count, and its
  * algorithmic HBM bytes (activations in + out per image; packed weights once per launch). */

@@ -68,6 +68,7 @@ struct Op {
   int up = 0, up_cout = 0, pool = 0;
   int head_kind = -1, head_layer = -1;  // 0 cls, 1 obj, 2 loc
   int Ho = 0, Wo = 0;
+  int lane = 0;                         // 0 = the caller's stream; 1..3 = side streams (independent head branches)
   double flops = 0;                     // algorithmic 2*MAC per image of this launch
   double act_bytes = 0;                 // algorithmic HBM bytes per image: input read once + output written once
   double wgt_bytes = 0;                 // ... plus the packed weights, once per launch
@@ -107,12 +108,17 @@ struct ron_ctx {
   int64_t post_ws_bytes = 0;
   void* d_stem_w = nullptr;             // conv1_1 fragments + bias for the dedicated stem kernel (bf16 / f16)
   float* d_stem_b = nullptr;
-  void* d_splitk = nullptr;             // fp32 slabs of the split-K launches (sized at finalize for max_batch)
-  int64_t splitk_bytes = 0;
+  void* d_splitk[4] = {};               // fp32 slabs of the split-K launches, one set per stream lane
+  int64_t splitk_bytes[4] = {};
+  // RON_CFG_MULTI_STREAM: the heads of the three coarse scales run on side streams beside the main chain
+  hipStream_t side[4] = {};
+  hipEvent_t lane_ready[4] = {}, lane_done[4] = {};
   // optional per-launch timing (ron_profile_*): event pairs recorded on the caller's stream
-  bool profiling = false;
+  int profiling = 0;                    // calls still to be recorded (ron_profile_enable)
   std::vector<OpTiming> timing;                       // ops.size() + 1 (last = post-processing)
-  std::vector<std::vector<hipEvent_t>> pending;       // per recorded call: 2 events per op (+2 for post)
+  std::vector<std::vector<hipEvent_t>> pending;       // per recorded call: one event per stamp ...
+  std::vector<std::vector<int>> pending_ops;          // ... and what it marks: op index (its start), -1 = end of a lane,
+                                                      //     -2 / -3 = start / end of the post-processing stage
   std::vector<hipEvent_t> event_pool;
 
   int esz() const { return (int)dtype_size(cfg.dtype); }
@@ -508,7 +514,12 @@ extern "C" int ron_destroy(ron_ctx* c) {
   for (auto& call : c->pending) for (hipEvent_t e : call) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->d_post_ws) (void)hipFree(c->d_post_ws);
-  if (c->d_splitk) (void)hipFree(c->d_splitk);
+  for (int l = 0; l < 4; ++l) {
+    if (c->d_splitk[l]) (void)hipFree(c->d_splitk[l]);
+    if (c->side[l]) (void)hipStreamDestroy(c->side[l]);
+    if (c->lane_ready[l]) (void)hipEventDestroy(c->lane_ready[l]);
+    if (c->lane_done[l]) (void)hipEventDestroy(c->lane_done[l]);
+  }
   if (c->d_stem_w) (void)hipFree(c->d_stem_w);
   if (c->d_stem_b) (void)hipFree(c->d_stem_b);
   delete c;
@@ -732,17 +743,33 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
 #undef PACK
 #undef ATTR
   c->flops_per_image = flops;
-  // split-K scratch: the largest slab set any launch can ask for at max_batch
+  // stream lanes: heads of block7 / block6 / block5 are independent of the main chain once their reference map exists
+  if ((c->cfg.flags & RON_CFG_MULTI_STREAM) && !c->is_ssd()) {
+    for (Op& o : c->ops)
+      for (int i = 0; i < 3; ++i) {
+        const std::string pre = std::string(kFeatLayers[i]) + "_";
+        if (o.name.compare(0, pre.size(), pre) == 0 && o.name.find("_conv_left") == std::string::npos &&
+            o.name.find("_deconv_right") == std::string::npos)
+          o.lane = i + 1;
+      }
+    for (int l = 1; l < 4; ++l) {
+      RON_HIP_CHECK(hipStreamCreateWithFlags(&c->side[l], hipStreamNonBlocking));
+      RON_HIP_CHECK(hipEventCreateWithFlags(&c->lane_ready[l], hipEventDisableTiming));
+      RON_HIP_CHECK(hipEventCreateWithFlags(&c->lane_done[l], hipEventDisableTiming));
+    }
+  }
+  // split-K scratch: the largest slab set any launch of a lane can ask for at max_batch
   for (const Op& o : c->ops) {
     if (o.kind != OP_CONV || o.up > 0) continue;
     const PackedConv& pk = c->packed[o.packed];
     const int cin = o.in_C > 0 ? o.in_C : c->tensors[o.in].C;
     for (int nb = 1; nb <= c->cfg.max_batch; ++nb) {
       const int64_t b = conv_scratch_bytes(nb * o.Ho * o.Wo, pk.Npad, o.kh * o.kw * cin, c->cfg.dtype, -1, -1);
-      if (b > c->splitk_bytes) c->splitk_bytes = b;
+      if (b > c->splitk_bytes[o.lane]) c->splitk_bytes[o.lane] = b;
     }
   }
-  if (c->splitk_bytes > 0) RON_HIP_CHECK(hipMalloc(&c->d_splitk, (size_t)c->splitk_bytes));
+  for (int l = 0; l < 4; ++l)
+    if (c->splitk_bytes[l] > 0) RON_HIP_CHECK(hipMalloc(&c->d_splitk[l], (size_t)c->splitk_bytes[l]));
   for (Op& o : c->ops) {
     if (o.kind != OP_CONV) continue;
     const PackedConv& pk = c->packed[o.packed];
@@ -782,25 +809,39 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
   RON_REQUIRE(c && d_images && out, "NULL argument");
   if (!c->finalized) { ron::set_error("ron_forward before ron_finalize_weights"); return RON_ERR_STATE; }
   RON_REQUIRE(n >= 1 && n <= c->cfg.max_batch, "batch %d outside [1, max_batch=%d]", n, c->cfg.max_batch);
-  hipStream_t s = (hipStream_t)stream;
   int rc = ron_heads_describe(c, out);
   if (rc) return rc;
   std::vector<hipEvent_t>* ev = nullptr;
-  if (c->profiling && c->pending.size() < 256) {
+  if (c->profiling > 0 && c->pending.size() < 256) {
+    --c->profiling;
     c->pending.emplace_back();
+    c->pending_ops.emplace_back();
     ev = &c->pending.back();
   }
-  auto stamp = [&]() -> int {
+  // one event per op start on the op's stream; an op ends where the next op of its lane starts (or at the lane's end stamp)
+  auto stamp = [&](hipStream_t st, int what) -> int {
     if (!ev) return RON_OK;
     hipEvent_t e;
     if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
     else RON_HIP_CHECK(hipEventCreate(&e));
-    RON_HIP_CHECK(hipEventRecord(e, s));
+    RON_HIP_CHECK(hipEventRecord(e, st));
     ev->push_back(e);
+    c->pending_ops.back().push_back(what);
     return RON_OK;
   };
+  const hipStream_t main_stream = (hipStream_t)stream;
+  bool lane_started[4] = {false, false, false, false};
   for (const Op& o : c->ops) {
-    if ((rc = stamp())) return rc;
+    hipStream_t s = main_stream;
+    if (o.lane > 0) {
+      s = c->side[o.lane];
+      if (!lane_started[o.lane]) {          // everything enqueued on the main stream so far (incl. this scale's reference map)
+        RON_HIP_CHECK(hipEventRecord(c->lane_ready[o.lane], main_stream));
+        RON_HIP_CHECK(hipStreamWaitEvent(s, c->lane_ready[o.lane], 0));
+        lane_started[o.lane] = true;
+      }
+    }
+    if ((rc = stamp(s, (int)(&o - &c->ops[0])))) return rc;
     if (o.kind == OP_IM2COL) {
       const Tensor& t = c->tensors[o.out];
       if ((rc = launch_im2col_c3(d_images, n, t.H, t.W, c->cfg.dtype, t.d, t.C, s))) return rc;
@@ -837,7 +878,7 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
       L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.bias = p.d_bias; L.Cout = p.Cout; L.Npad = p.Npad;
       L.kh = o.kh; L.kw = o.kw; L.stride = o.stride; L.dil = o.dil; L.cpad = o.cpad; L.relu = o.relu;
       L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo; L.pool = o.pool;
-      L.scratch = c->d_splitk; L.scratch_bytes = c->splitk_bytes;
+      L.scratch = c->d_splitk[o.lane]; L.scratch_bytes = c->splitk_bytes[o.lane];
       if ((rc = launch_conv(L, s))) {
         std::string msg = ron_last_error();
         ron::set_error("%s: %s", o.name.c_str(), msg.c_str());
@@ -845,31 +886,53 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
       }
     }
   }
-  if ((rc = stamp())) return rc;      // closes the last op
+  if (ev) {
+    if ((rc = stamp(main_stream, -1))) return rc;
+    for (int l = 1; l < 4; ++l) if (lane_started[l] && (rc = stamp(c->side[l], -1 - 10 * l))) return rc;
+  }
+  for (int l = 1; l < 4; ++l)
+    if (lane_started[l]) {                  // join: the caller's stream continues after every side branch
+      RON_HIP_CHECK(hipEventRecord(c->lane_done[l], c->side[l]));
+      RON_HIP_CHECK(hipStreamWaitEvent(main_stream, c->lane_done[l], 0));
+    }
   return RON_OK;
 }
 
 // ---- per-launch timing -----------------------------------------------------------------------
 extern "C" int ron_profile_enable(ron_ctx* c, int enable) {
   RON_REQUIRE(c, "NULL ctx");
-  c->profiling = enable != 0;
+  c->profiling = enable > 0 ? enable : 0;
   return RON_OK;
 }
 
 static int profile_collect(ron_ctx* c) {
-  for (auto& call : c->pending) {
+  for (size_t k = 0; k < c->pending.size(); ++k) {
+    auto& call = c->pending[k];
+    const auto& what = c->pending_ops[k];
     if (call.empty()) continue;
-    RON_HIP_CHECK(hipEventSynchronize(call.back()));
-    for (size_t i = 0; i + 1 < call.size(); ++i) {
+    for (hipEvent_t e : call) RON_HIP_CHECK(hipEventSynchronize(e));
+    // the end of op i = the next stamp recorded on the same lane
+    for (size_t i = 0; i < call.size(); ++i) {
+      int slot, lane;
+      if (what[i] >= 0) { slot = what[i]; lane = c->ops[slot].lane; }
+      else if (what[i] == -2) { slot = (int)c->ops.size(); lane = 0; }
+      else continue;
+      size_t j = i + 1;
+      for (; j < call.size(); ++j) {
+        const int w = what[j];
+        const int lj = w >= 0 ? c->ops[w].lane : (w == -1 || w == -2 || w == -3 ? 0 : (-1 - w) / 10);
+        if (lj == lane) break;
+      }
+      if (j == call.size()) continue;
       float ms = 0.f;
-      RON_HIP_CHECK(hipEventElapsedTime(&ms, call[i], call[i + 1]));
-      const size_t slot = i < c->ops.size() ? i : c->ops.size();
+      RON_HIP_CHECK(hipEventElapsedTime(&ms, call[i], call[j]));
       c->timing[slot].ms += ms;
       c->timing[slot].launches += 1;
     }
     for (hipEvent_t e : call) c->event_pool.push_back(e);
   }
   c->pending.clear();
+  c->pending_ops.clear();
   return RON_OK;
 }
 
@@ -951,13 +1014,19 @@ extern "C" int ron_detect(ron_ctx* c, const float* d_images, int n, const ron_po
   }
   ron_post_cfg pc = *cfg;
   pc.input_flags = 0;      // logits + raw offsets straight from the conv stack
-  rc = ron_post_np(&hd, n, &pc, c->d_post_ws, c->post_ws_bytes, out, nullptr, nullptr, stream);
-  if (rc == RON_OK && c->profiling && !c->pending.empty() && c->pending.back().size() == c->ops.size() + 1) {
+  const bool prof = !c->pending.empty() && !c->pending_ops.back().empty() && c->pending_ops.back().back() <= -1 &&
+                    c->pending_ops.back().back() != -3 && c->pending_ops.back().back() != -2;   // this call was recorded
+  auto post_stamp = [&](int what) -> int {
     hipEvent_t e;
     if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
     else RON_HIP_CHECK(hipEventCreate(&e));
     RON_HIP_CHECK(hipEventRecord(e, (hipStream_t)stream));
-    c->pending.back().push_back(e);          // [ops.size()] .. [ops.size()+1] = post-processing
-  }
+    c->pending.back().push_back(e);
+    c->pending_ops.back().push_back(what);
+    return RON_OK;
+  };
+  if (prof && (rc = post_stamp(-2))) return rc;
+  rc = ron_post_np(&hd, n, &pc, c->d_post_ws, c->post_ws_bytes, out, nullptr, nullptr, stream);
+  if (rc == RON_OK && prof) rc = post_stamp(-3);
   return rc;
 }

@@ -39,7 +39,8 @@ class RONNet(object):
         anchor_offset=0.5,
         prior_scaling=[0.1, 0.1, 0.2, 0.2])
 
-    def __init__(self, params=None, variant='reducedfc', dtype='bf16', max_batch=32, device=None, fuse_pools=False):
+    def __init__(self, params=None, variant='reducedfc', dtype='bf16', max_batch=32, device=None, fuse_pools=False,
+                 multi_stream=False):
         self.params = params if isinstance(params, RONParams) else RONNet.default_params
         if variant not in _lib.VARIANTS:
             raise ValueError('Unknown RON variant %s' % variant)
@@ -49,6 +50,8 @@ class RONNet(object):
         # fuse_pools: block1..block3 are never written at full resolution (their max-pool runs in the conv epilogue);
         # end_points then offers block4..block7 only
         self.fuse_pools = fuse_pools
+        # multi_stream: heads of block7/6/5 on side streams (fork/join inside every forward)
+        self.multi_stream = multi_stream
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self._ctx = None
         self._anchors_dev = None
@@ -58,7 +61,9 @@ class RONNet(object):
         if self._ctx is None:
             cfg = _lib.Config(_lib.VARIANTS[self.variant], _lib.DTYPES[self.dtype], self.params.img_shape[0],
                               self.params.img_shape[1], self.params.num_classes, self.max_batch,
-                              self.device.index or 0, _lib.RON_CFG_FUSE_POOLS if self.fuse_pools else 0)
+                              self.device.index or 0,
+                              (_lib.RON_CFG_FUSE_POOLS if self.fuse_pools else 0) |
+                              (_lib.RON_CFG_MULTI_STREAM if getattr(self, 'multi_stream', False) else 0))
             h = C.c_void_p()
             check(lib().ron_create(C.byref(h), C.byref(cfg)))
             self._ctx = h

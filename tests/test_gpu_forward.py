@@ -190,6 +190,29 @@ def test_fused_pools_give_identical_heads(pkg, dev, weights_reduced, images):
     b.close()
 
 
+def test_multi_stream_heads_are_identical(pkg, dev, weights_reduced, images):
+    """RON_CFG_MULTI_STREAM only changes which stream a head branch is enqueued on: bitwise the same tensors,
+    also when calls follow each other without a host sync (fork/join ordering)."""
+    x = torch.from_numpy(images).to(dev)
+    a = pkg['ron'].RONNet(variant='reducedfc', dtype='bf16', max_batch=2).load_weights(weights_reduced)
+    b = pkg['ron'].RONNet(variant='reducedfc', dtype='bf16', max_batch=2, multi_stream=True).load_weights(weights_reduced)
+    ha = a.forward_heads(x)
+    for _ in range(3):
+        hb = b.forward_heads(x)
+    x2 = torch.flip(x, dims=[0]).contiguous()
+    hb2 = b.forward_heads(x2)                 # back-to-back call with different data, no sync in between
+    for la, lb, lb2 in zip(ha, hb, hb2):
+        for ta, tb, tb2 in zip(la, lb, lb2):
+            assert torch.equal(ta, tb)
+            assert torch.equal(ta, torch.flip(tb2, dims=[0]))
+    da, db = a.detect(x).to_lists(), b.detect(x).to_lists()
+    for u, v in zip(da, db):
+        for k in ('classes', 'scores', 'bboxes', 'anchor_index'):
+            assert np.array_equal(u[k], v[k])
+    a.close()
+    b.close()
+
+
 def test_network_fn_uses_full_variant(pkg, dev, weights_full, images):
     fn = pkg['factory'].get_network_fn('ron_320_vgg', 21, is_training=False, weights=weights_full, dtype='bf16', max_batch=1)
     assert fn.default_image_size == 320
