@@ -18,6 +18,8 @@ constexpr int kSortCap = 4096;     // keys sorted in LDS by one workgroup
 constexpr int kMaxTopK = RON_MAX_TOPK;
 constexpr int kTopkThreads = 1024;
 constexpr int kMaskWords = kMaxTopK / 64;
+constexpr int kCountStride = 32;   // ints: every per-image candidate counter on its own 128-B line (they are atomic targets)
+constexpr int kSelectCap = 1024;   // the radix select narrows to at most this many keys before the LDS sort
 
 typedef unsigned long long u64;
 
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(HeadsDev hd, Pos
   }
   const int wave_total = __shfl(incl, 63, 64);
   int base = 0;
-  if (lane == 63 && wave_total > 0) base = atomicAdd(&counts[img], wave_total);
+  if (lane == 63 && wave_total > 0) base = atomicAdd(&counts[img * kCountStride], wave_total);
   base = __shfl(base, 63, 64);
   if (n_sel > 0) {
     int pos = base + incl - n_sel;
@@ -152,6 +154,9 @@ struct ImageLds {
   int anchor[kMaxTopK];
   unsigned hist[256];
   int scalars[8];
+  int order[kMaxTopK];             // class-grouped position -> sorted row (class-wise NMS)
+  int keep[kMaxTopK];              // sorted row -> kept?
+  int cstart[66];                  // first class-grouped position of every class
 };
 
 __device__ void bitonic_sort_desc(u64* s, int n2, int tid, int nthreads) {
@@ -179,12 +184,12 @@ __device__ int topk_keys(const u64* __restrict__ keys, int m, int top_k, ImageLd
   const int tid = threadIdx.x;
   const int nth = blockDim.x;
   int n_sel;
-  if (m <= kSortCap) {
+  if (m <= kSelectCap) {
     for (int i = tid; i < m; i += nth) lds.sort[i] = keys[i];
     n_sel = m;
     __syncthreads();
   } else {
-    // radix select from the most significant byte down until the survivors fit in LDS
+    // radix select from the most significant byte down until few enough keys survive for a short LDS sort
     u64 prefix = 0, mask = 0;
     int need = top_k, above_total = 0;
     for (int shift = 56; shift >= 0; shift -= 8) {
@@ -195,16 +200,26 @@ __device__ int topk_keys(const u64* __restrict__ keys, int m, int top_k, ImageLd
         if ((k & mask) == prefix) atomicAdd(&lds.hist[(unsigned)(k >> shift) & 255u], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        int cum = 0, bin = 0;
-        for (int b = 255; b >= 0; --b) {
-          const int c = (int)lds.hist[b];
-          if (cum + c >= need) { bin = b; break; }
-          cum += c;
+      if (tid < 64) {
+        // wave 0: lane l owns bins 4l..4l+3; suffix sums over lanes by shuffles, then the crossing bin inside one lane
+        const int l = tid;
+        const int c0 = (int)lds.hist[4 * l], c1 = (int)lds.hist[4 * l + 1], c2 = (int)lds.hist[4 * l + 2], c3 = (int)lds.hist[4 * l + 3];
+        const int mine = c0 + c1 + c2 + c3;
+        int suf = mine;                                   // inclusive suffix: bins >= 4l
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int v = __shfl_down(suf, d, 64);
+          if (l + d < 64) suf += v;
         }
-        lds.scalars[0] = bin;
-        lds.scalars[1] = cum;
-        lds.scalars[2] = (int)lds.hist[bin];
+        const int above = suf - mine;                     // keys in bins > 4l+3
+        if (above < need && suf >= need) {                // the crossing bin is one of this lane's four (exactly one lane)
+          int cum = above, bin = 4 * l + 3;
+          if (cum + c3 >= need) { bin = 4 * l + 3; }
+          else { cum += c3; if (cum + c2 >= need) { bin = 4 * l + 2; } else { cum += c2; if (cum + c1 >= need) { bin = 4 * l + 1; } else { cum += c1; bin = 4 * l; } } }
+          lds.scalars[0] = bin;
+          lds.scalars[1] = cum;
+          lds.scalars[2] = (int)lds.hist[bin];
+        }
       }
       __syncthreads();
       const int bin = lds.scalars[0], cum = lds.scalars[1], bin_count = lds.scalars[2];
@@ -213,7 +228,7 @@ __device__ int topk_keys(const u64* __restrict__ keys, int m, int top_k, ImageLd
       need -= cum;
       prefix |= (u64)bin << shift;
       mask |= (u64)0xFF << shift;
-      if (above_total + bin_count <= kSortCap) break;
+      if (above_total + bin_count <= kSelectCap) break;
     }
     if (tid == 0) lds.scalars[3] = 0;
     __syncthreads();
@@ -286,12 +301,17 @@ __device__ void nms_scan(ImageLds& lds, int n, float nms_thr, int mode, int max_
     u64 removed = 0;
     u64 keep_bits = 0;     // lane w: kept rows of word w
     int n_kept = 0;
+    u64 row = (lane < words && n > 0) ? mask[lane] : 0;         // mask row i, fetched one iteration ahead
     for (int i = 0; i < n && n_kept < max_keep; ++i) {
+      const u64 cur = row;
+      if (i + 1 < n) row = (lane < words) ? mask[(i + 1) * kMaskWords + lane] : 0;
       const int wi = i >> 6;
-      const u64 rw = __shfl(removed, wi, 64);
+      const unsigned lo = __builtin_amdgcn_readlane((unsigned)(removed & 0xFFFFFFFFull), wi);
+      const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), wi);
+      const u64 rw = ((u64)hi << 32) | lo;
       const bool kept = ((rw >> (i & 63)) & 1ull) == 0;
       if (kept) {
-        if (lane < words) removed |= mask[i * kMaskWords + lane];
+        removed |= cur;
         if (lane == wi) keep_bits |= 1ull << (i & 63);
         ++n_kept;
       }
@@ -314,6 +334,93 @@ __device__ void nms_scan(ImageLds& lds, int n, float nms_thr, int mode, int max_
   __syncthreads();
 }
 
+// Class-wise form of the np_methods NMS (np_methods.py:229-242 suppresses only boxes of the SAME class): rows are
+// grouped by class (stable, so score order is kept inside a class), the suppression bits are built per class segment
+// (one wave per row, lanes = the later rows of the segment, __ballot -> word) and every class is scanned greedily by its
+// own wave in parallel.  Pairs examined: sum_c n_c^2 / 2 instead of n^2 / 2, serial depth max_c n_c instead of n.
+// Same outputs in lds.hist / lds.scalars[4] as nms_scan.
+__device__ void nms_scan_classwise(ImageLds& lds, int n, float nms_thr, int num_classes) {
+  const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
+  const int words = (n + 63) >> 6;
+  u64* mask = lds.sort;    // [n][kMaskWords], indexed by class-grouped position
+  for (int i = tid; i < 64; i += nth) lds.hist[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += nth) atomicAdd(&lds.hist[lds.cls[i] & 63], 1u);
+  __syncthreads();
+  if (tid < 64) {            // exclusive scan of the class counts
+    const int c = (int)lds.hist[tid];
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    lds.cstart[tid] = incl - c;
+    if (tid == 63) lds.cstart[64] = incl;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += nth) {       // stable rank inside the class
+    const int c = lds.cls[i];
+    int r = 0;
+    for (int j = 0; j < i; ++j) r += (lds.cls[j] == c) ? 1 : 0;
+    lds.order[lds.cstart[c & 63] + r] = i;
+    lds.keep[i] = 0;
+  }
+  __syncthreads();
+  for (int a = wave; a < n; a += nwaves) {   // suppression bits of grouped row a
+    const int ia = lds.order[a];
+    const int s1 = lds.cstart[(lds.cls[ia] & 63) + 1];
+    for (int w = 0; w < words; ++w) {
+      const int b = (w << 6) + lane;
+      u64 bits = 0;
+      if ((w << 6) + 63 > a && (w << 6) < s1) {           // wave-uniform: the word overlaps (a, s1)
+        bool sup = false;
+        if (b > a && b < s1) sup = nms_suppresses(lds.box[ia], lds.box[lds.order[b]], nms_thr);
+        bits = __ballot(sup);
+      }
+      if (lane == 0) mask[a * kMaskWords + w] = bits;
+    }
+  }
+  __syncthreads();
+  for (int c = wave; c < 64 && c < num_classes; c += nwaves) {   // one wave per class
+    const int s0 = lds.cstart[c], s1 = lds.cstart[c + 1];
+    u64 removed = 0;
+    for (int a = s0; a < s1; ++a) {
+      const int wi = a >> 6;
+      const unsigned lo = __builtin_amdgcn_readlane((unsigned)(removed & 0xFFFFFFFFull), wi);
+      const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), wi);
+      const u64 rw = ((u64)hi << 32) | lo;
+      if (((rw >> (a & 63)) & 1ull) == 0) {
+        if (lane < words) removed |= mask[a * kMaskWords + lane];
+        if (lane == 0) lds.keep[lds.order[a]] = 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {            // keep bits per 64-row word of the score order + exclusive counts
+    u64 kb = 0;
+    for (int w = 0; w < words; ++w) {
+      const int i = (w << 6) + lane;
+      const u64 bits = __ballot(i < n && lds.keep[i] != 0);
+      if (lane == w) kb = bits;
+    }
+    int cnt = (lane < words) ? __popcll(kb) : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    if (lane < kMaskWords) {
+      lds.hist[lane] = (unsigned)(kb & 0xFFFFFFFFull);
+      lds.hist[16 + lane] = (unsigned)(kb >> 32);
+      lds.hist[32 + lane] = (unsigned)(incl - cnt);
+    }
+    if (lane == 63) lds.scalars[4] = incl;
+  }
+  __syncthreads();
+}
+
 // output slot of sorted row i after the scan, or -1 when it was suppressed
 __device__ __forceinline__ int nms_slot(const ImageLds& lds, int i) {
   const int w = i >> 6, b = i & 63;
@@ -325,10 +432,11 @@ __device__ __forceinline__ int nms_slot(const ImageLds& lds, int i) {
 // Greedy scan over the n sorted boxes in lds (np_methods.py:229-242).  Writes kept rows,
 // compacted, to `out` (image `img`), after the resize by `ref` when do_resize.
 __device__ void nms_and_store(ImageLds& lds, int n, float nms_thr, const float* ref, bool do_resize,
-                              const DetDev& out, int img) {
+                              const DetDev& out, int img, int num_classes) {
   const int tid = threadIdx.x;
   const int nth = blockDim.x;
-  nms_scan(lds, n, nms_thr, 0, n);
+  if (num_classes > 0 && num_classes <= 64) nms_scan_classwise(lds, n, nms_thr, num_classes);
+  else nms_scan(lds, n, nms_thr, 0, n);       // class ids outside [0, 64): generic all-pairs form
   const int total = lds.scalars[4];
   const float sy = ref[2] - ref[0], sx = ref[3] - ref[1];
   for (int i = tid; i < out.capacity; i += nth) {
@@ -396,7 +504,7 @@ __global__ __launch_bounds__(kTopkThreads) void topk_nms_kernel(HeadsDev hd, Pos
   __shared__ ImageLds lds;
   const int img = blockIdx.x;
   const int tid = threadIdx.x;
-  const int m_raw = counts[img];
+  const int m_raw = counts[img * kCountStride];
   if (tid == 0 && n_candidates != nullptr) n_candidates[img] = m_raw;
   const int m = min(m_raw, cap);
   const int n = topk_keys(keys + (size_t)img * cap, m, pc.top_k, lds);
@@ -434,7 +542,7 @@ __global__ __launch_bounds__(kTopkThreads) void topk_nms_kernel(HeadsDev hd, Pos
   }
   __syncthreads();
   if (sorted_out.classes != nullptr) store_sorted(lds, n, sorted_out, img);
-  nms_and_store(lds, n, pc.nms_thr, pc.ref, true, out, img);
+  nms_and_store(lds, n, pc.nms_thr, pc.ref, true, out, img, hd.num_classes);
 }
 
 // Explicit lists (np_methods.bboxes_sort -> bboxes_nms), one workgroup per image.
@@ -464,7 +572,7 @@ __global__ __launch_bounds__(kTopkThreads) void list_sort_nms_kernel(const int* 
   __syncthreads();
   if (sorted_out.classes != nullptr) store_sorted(lds, n, sorted_out, img);
   const float ref[4] = {0.f, 0.f, 1.f, 1.f};
-  nms_and_store(lds, n, nms_thr, ref, false, out, img);
+  nms_and_store(lds, n, nms_thr, ref, false, out, img, 0);     // arbitrary class ids in explicit lists
 }
 
 __global__ void decode_layer_kernel(const float* loc, int n, int cells, int A, const float* ay, const float* ax,
@@ -551,7 +659,7 @@ extern "C" int64_t ron_post_np_workspace_bytes(const ron_heads* heads, int n) {
   HeadsDev hd;
   if (build_heads_dev(heads, &hd, false) != RON_OK || n <= 0) return -1;
   const int64_t cap = (int64_t)hd.anchor_base[RON_MAX_LAYERS] * (heads->num_classes - 1);
-  return ron::align_up((int64_t)n * 4, 256) + (int64_t)n * cap * 8;
+  return ron::align_up((int64_t)n * kCountStride * 4, 256) + (int64_t)n * cap * 8;
 }
 
 extern "C" int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cfg, void* workspace,
@@ -576,9 +684,9 @@ extern "C" int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cf
   for (int i = 0; i < 4; ++i) { pc.ref[i] = cfg->bbox_img[i]; pc.ps[i] = cfg->prior_scaling[i]; }
   hipStream_t s = (hipStream_t)stream;
   int* counts = (int*)workspace;
-  u64* keys = (u64*)((char*)workspace + ron::align_up((int64_t)n * 4, 256));
+  u64* keys = (u64*)((char*)workspace + ron::align_up((int64_t)n * kCountStride * 4, 256));
   const int cap = hd.anchor_base[RON_MAX_LAYERS] * (hd.num_classes - 1);
-  RON_HIP_CHECK(hipMemsetAsync(counts, 0, ron::align_up((int64_t)n * 4, 256), s));
+  RON_HIP_CHECK(hipMemsetAsync(counts, 0, ron::align_up((int64_t)n * kCountStride * 4, 256), s));
   dim3 grid(hd.block_base[RON_MAX_LAYERS], n);
   const size_t lds = (size_t)kSelectThreads * hd.num_classes * sizeof(float);
   hipLaunchKernelGGL(select_kernel, grid, dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
