@@ -42,7 +42,7 @@ def parse():
                     help="full = BASELINE configs 2/3 (default); reducedfc = config 4; ssd512 = config 5")
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=4, help='images in the bounded CPU-baseline sample')
+    ap.add_argument('--cpu-images', type=int, default=12, help='images in the bounded CPU-baseline sample')
     ap.add_argument('--multi-stream', action='store_true',
                     help='run the block7/6/5 head branches on side streams (RON_CFG_MULTI_STREAM): +5 %% images/s measured, but the '
                          'per-launch durations then overlap and no longer describe one kernel each, so it is off by default')
