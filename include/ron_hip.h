@@ -30,6 +30,7 @@ extern "C" {
 
 #define RON_MAX_LAYERS 8
 #define RON_MAX_ANCHORS_PER_CELL 16
+#define RON_MAX_GT 256             /* ground-truth boxes per image ron_bboxes_matching accepts */
 #define RON_MAX_TOPK 512           /* rows a detection list can hold (np_methods top_k = 400) */
 
 typedef enum {
@@ -184,6 +185,30 @@ int64_t ron_post_tfe_workspace_bytes(const ron_heads* heads, int n);
 int ron_post_tfe(const ron_heads* heads, int n, const ron_tfe_cfg* cfg,
                  void* workspace, int64_t workspace_bytes,
                  float* scores, float* bboxes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Evaluation preprocessing: preprocess_for_eval with Resize.WARP_RESIZE
+ * (preprocessing/ssd_vgg_preprocessing.py:358-425, tf_image.py:269-282): uint8 RGB -> float, minus the channel means,
+ * TF1 bilinear resize (align_corners=False, no half-pixel centres) to [out_h, out_w].
+ *   packed  : the n images' HWC uint8 bytes back to back (device)
+ *   offsets : [n] byte offset of image i in `packed` (device, int64)
+ *   hw      : [n, 2] height, width of image i (device)
+ *   means   : [3] host floats (123, 117, 104)
+ *   out     : [n, out_h, out_w, 3] float32 (device) -- the `images` argument of ron_forward
+ * ---------------------------------------------------------------------------------------- */
+int ron_preprocess_eval(const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
+                        int out_h, int out_w, const float* means, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Evaluation bookkeeping: tfe.bboxes_matching_batch (tf_extended/bboxes.py:316-450) on the dense output of
+ * ron_post_tfe.  List (i, c) holds class label c + 1 of image i:
+ *   scores [N, L, K] (unused by the matching itself, kept for the reference's argument list), bboxes [N, L, K, 4],
+ *   glabels [N, G] (0 = padding), gbboxes [N, G, 4], gdifficults [N, G] (non-zero = difficult), G <= RON_MAX_GT
+ *   -> n_gbboxes [N, L] (non-difficult ground truth of the class), tp / fp [N, L, K] (0 / 1).
+ * ---------------------------------------------------------------------------------------- */
+int ron_bboxes_matching(const float* scores, const float* bboxes, int n, int num_lists, int k,
+                        const int32_t* glabels, const float* gbboxes, const uint8_t* gdifficults, int g,
+                        float matching_threshold, int32_t* n_gbboxes, uint8_t* tp, uint8_t* fp, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Conv stack.  Replaces RONNet.net / ron_net / ron_net_reducedfc

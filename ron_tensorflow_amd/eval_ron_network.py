@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """eval_ron_network.py-style driver on the MI355X path.
 
-Makes exactly the calls of the reference driver (eval_ron_network.py:148-152, :204-210, :226-236) with the same
-flag names and defaults (:64-123), on synthetic pre-whitened tensors (or an .npy batch / .npz weights the user
-supplies), since the reference's dataset, checkpoint and metric plumbing is out of scope.
+Makes exactly the calls of the reference driver (eval_ron_network.py:148-158, :204-210, :226-257, :289-335) with the
+same flag names and defaults (:64-123): preprocess_for_eval -> net -> bboxes_decode -> objectness gate ->
+detected_bboxes -> bboxes_matching_batch -> streaming TP/FP -> AP VOC07 / VOC12 -> mAP.  Data is synthetic (decoded
+uint8 images of ragged sizes with random ground truth) or user supplied (.npy batch / .npz weights): the reference's
+TFRecord dataset and checkpoint plumbing are out of scope.
 Prints 'Time spent per BATCH' like the reference (:365-366)."""
 import argparse
 import time
@@ -11,7 +13,9 @@ import time
 import numpy as np
 import torch
 
+from ron_tensorflow_amd import metrics as tfe_metrics
 from ron_tensorflow_amd import weights as W
+from ron_tensorflow_amd.preprocessing import ssd_vgg_preprocessing
 from ron_tensorflow_amd.nets import nets_factory
 
 
@@ -22,6 +26,8 @@ def main():
     ap.add_argument('--select_top_k', type=int, default=200)             # :68-69
     ap.add_argument('--keep_top_k', type=int, default=100)               # :70-71
     ap.add_argument('--nms_threshold', type=float, default=0.4)          # :72-73
+    ap.add_argument('--matching_threshold', type=float, default=0.5)
+    ap.add_argument('--remove_difficult', type=int, default=0)
     ap.add_argument('--num_classes', type=int, default=21)               # :92
     ap.add_argument('--batch_size', type=int, default=1)                 # :93-94
     ap.add_argument('--max_num_batches', type=int, default=4)
@@ -40,13 +46,34 @@ def main():
     ron_anchors = ron_net.anchors(ron_shape)
     weights = W.load_npz(FLAGS.checkpoint_path) if FLAGS.checkpoint_path else W.synthetic_weights(FLAGS.variant, FLAGS.num_classes)
     ron_net.load_weights(weights)
-    data = np.load(FLAGS.images) if FLAGS.images else W.synthetic_images(FLAGS.batch_size * FLAGS.max_num_batches)
+    n_total = FLAGS.batch_size * FLAGS.max_num_batches
+    rs = np.random.RandomState(0)
+    if FLAGS.images:
+        data = np.load(FLAGS.images)
+    else:       # decoded "JPEGs": uint8 RGB, PASCAL-like ragged sizes
+        data = [rs.randint(0, 256, (int(rs.randint(200, 500)), int(rs.randint(200, 500)), 3)).astype(np.uint8) for _ in range(n_total)]
+    # synthetic ground truth, padded to a fixed count per image like the reference's batching (:160-170)
+    n_gt = 8
+    g_labels = rs.randint(0, FLAGS.num_classes, (n_total, n_gt)).astype(np.int64)
+    yx = rs.rand(n_total, n_gt, 2).astype(np.float32) * 0.6
+    g_bboxes = np.concatenate([yx, yx + 0.1 + 0.3 * rs.rand(n_total, n_gt, 2).astype(np.float32)], -1)
+    g_bboxes[g_labels == 0] = 0
+    g_difficults = (rs.rand(n_total, n_gt) < 0.1).astype(np.int64)
+    if FLAGS.remove_difficult:
+        g_difficults[:] = 0
+    labels = list(range(1, FLAGS.num_classes))
+    tp_fp_metric = tfe_metrics.StreamingTpFp(labels)
 
     times = []
-    for i in range(0, min(len(data), FLAGS.batch_size * FLAGS.max_num_batches), FLAGS.batch_size):
-        b_image = torch.from_numpy(np.ascontiguousarray(data[i:i + FLAGS.batch_size])).to(ron_net.device)
+    for i in range(0, min(len(data), n_total), FLAGS.batch_size):
         torch.cuda.synchronize()
         start = time.time()
+        if FLAGS.images:
+            b_image = torch.from_numpy(np.ascontiguousarray(data[i:i + FLAGS.batch_size])).to(ron_net.device)
+        else:                                                                                                  # :153-158
+            b_image = ssd_vgg_preprocessing.preprocess_for_eval_batch(data[i:i + FLAGS.batch_size], out_shape=ron_shape,
+                                                                      resize=ssd_vgg_preprocessing.Resize.WARP_RESIZE,
+                                                                      device=ron_net.device)
         with ron_net.arg_scope(weight_decay=0.0005, is_training=False, data_format='NHWC'):                  # :204-208
             predictions, logits, objness_pred, objness_logits, localisations, end_points = \
                 ron_net.net(b_image, is_training=False, end_points=())                                          # :209-210
@@ -58,10 +85,18 @@ def main():
                                                    nms_threshold=FLAGS.nms_threshold,
                                                    clipping_bbox=[0., 0., 1., 1.],
                                                    top_k=FLAGS.select_top_k, keep_top_k=FLAGS.keep_top_k)     # :230-236
+        sl = slice(i, i + FLAGS.batch_size)
+        num_gbboxes, tp, fp = tfe_metrics.bboxes_matching_batch(rscores.keys(), rscores, rbboxes, g_labels[sl], g_bboxes[sl],
+                                                                g_difficults[sl], matching_threshold=FLAGS.matching_threshold)  # :237-241
+        tp_fp_metric.update(torch.stack([num_gbboxes[c] for c in labels], 1), torch.stack([tp[c] for c in labels], 1),
+                            torch.stack([fp[c] for c in labels], 1), torch.stack([rscores[c] for c in labels], 1))  # :259-261
         torch.cuda.synchronize()
         times.append(time.time() - start)
         kept = sum(int((v > 0).sum().item()) for v in rscores.values())
         print('batch %d: %d detections over %d classes' % (i // FLAGS.batch_size, kept, len(rscores)))
+    res = tfe_metrics.evaluate(tp_fp_metric)                                                                  # :289-335
+    print('AP_VOC07/mAP %.6f  AP_VOC12/mAP %.6f  (synthetic weights and ground truth: plumbing check, not accuracy)'
+          % (res['AP_VOC07/mAP'], res['AP_VOC12/mAP']))
     print('Time spent per BATCH: %.3f seconds.' % (sum(times[1:]) / max(len(times) - 1, 1)))
 
 

@@ -81,6 +81,26 @@ def g5_anchors_ssd(ron_module):
     np.savez_compressed(os.path.join(HERE, 'g5_anchors_ssd512.npz'), **out)
 
 
+def g6_voc_ap():
+    """AP of seeded precision/recall curves through the reference's numpy voc_ap (datasets/voc_eval.py:130-162)."""
+    sys.modules.setdefault('cv2', mock.MagicMock(name='cv2'))
+    from datasets import voc_eval
+    out = {}
+    rs = np.random.RandomState(33)
+    for k in range(6):
+        n = [5, 40, 200, 1000, 3, 64][k]
+        n_gt = [4, 30, 120, 400, 10, 64][k]
+        tp = rs.rand(n) < [0.7, 0.5, 0.4, 0.3, 1.0, 0.0][k]
+        fp = ~tp
+        ctp, cfp = np.cumsum(tp.astype(np.float64)), np.cumsum(fp.astype(np.float64))
+        rec = ctp / n_gt
+        prec = ctp / np.maximum(ctp + cfp, np.finfo(np.float64).eps)
+        out['rec%d' % k], out['prec%d' % k] = rec, prec
+        out['ap07_%d' % k] = np.float64(voc_eval.DetectorEvalPascal.voc_ap(None, rec, prec, use_07_metric=True))
+        out['ap12_%d' % k] = np.float64(voc_eval.DetectorEvalPascal.voc_ap(None, rec, prec, use_07_metric=False))
+    np.savez_compressed(os.path.join(HERE, 'g6_voc_ap.npz'), **out)
+
+
 def g2_decode(npm, anchors):
     out = {'seed': np.int64(11)}
     rs = np.random.RandomState(11)
@@ -219,6 +239,7 @@ def main():
     ron = load_ref_ron()
     anchors = g1_anchors(ron)
     g5_anchors_ssd(ron)
+    g6_voc_ap()
     g2_decode(npm, anchors)
     g3_pipeline(npm, anchors)
     g4_edge(npm)

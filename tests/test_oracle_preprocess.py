@@ -1,0 +1,35 @@
+"""CPU: identities anchoring the restated TF1 bilinear resize (oracle/preprocess.py, parity unpinned by the reference)."""
+import numpy as np
+
+from oracle import preprocess as op
+
+
+def test_same_size_is_whitening_only():
+    rs = np.random.RandomState(0)
+    im = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    out = op.preprocess_for_eval(im, (37, 53))
+    assert np.array_equal(out, im.astype(np.float32) - np.array(op.MEANS, np.float32))
+
+
+def test_integer_downscale_samples_pixels():
+    rs = np.random.RandomState(1)
+    im = rs.randint(0, 256, (640, 960, 3)).astype(np.uint8)
+    out = op.preprocess_for_eval(im, (320, 320))                 # scale 2 x 3: legacy coordinates land on pixels
+    assert np.array_equal(out, im[::2, ::3].astype(np.float32) - np.array(op.MEANS, np.float32))
+
+
+def test_constant_image_and_upscale_bounds():
+    im = np.full((50, 70, 3), 200, np.uint8)
+    out = op.preprocess_for_eval(im, (320, 320))
+    assert np.array_equal(out, np.broadcast_to(np.float32(200) - np.array(op.MEANS, np.float32), out.shape))
+    rs = np.random.RandomState(2)
+    im = rs.randint(0, 256, (100, 120, 3)).astype(np.uint8)
+    out = op.preprocess_for_eval(im, (320, 320))
+    w = im.astype(np.float32) - np.array(op.MEANS, np.float32)
+    assert out.min() >= w.min() - 1e-3 and out.max() <= w.max() + 1e-3
+    assert np.array_equal(out[0, 0], w[0, 0])
+    # x2 upscale of a ramp: legacy (no half-pixel) coordinates give exact midpoints
+    ramp = np.tile(np.arange(0, 160, dtype=np.uint8)[None, :, None], (160, 1, 3))
+    out = op.preprocess_for_eval(ramp, (320, 320), means=(0, 0, 0))
+    assert np.array_equal(out[5, :319, 0], np.arange(319, dtype=np.float32) * np.float32(0.5))
+    assert out[5, 319, 0] == 159.0                                # clamped upper neighbour
