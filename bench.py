@@ -46,6 +46,10 @@ def parse():
     ap.add_argument('--multi-stream', action='store_true',
                     help='run the block7/6/5 head branches on side streams (RON_CFG_MULTI_STREAM): +5 %% images/s measured, but the '
                          'per-launch durations then overlap and no longer describe one kernel each, so it is off by default')
+    ap.add_argument('--in-flight', type=int, default=2,
+                    help='batches in flight per GPU (execution slots over one set of weights, one stream each; '
+                         'ron_tensorflow_amd/pipeline.py).  1 = strictly one launch at a time: per-launch durations are then '
+                         "each kernel's alone, which is what profiles/*/kernel_stats are taken with")
     ap.add_argument('--layers', default='', help='write the per-launch timing table to this file')
     return ap.parse_args()
 
@@ -135,36 +139,58 @@ def main():
     if world > 1:
         gathered = torch.empty((world, args.batch, top_k + 1, parallel.RECORD_WIDTH), dtype=torch.float32, device=dev)
 
-    def step():
-        if ssd:
-            det = net.detect(images, select_threshold=0.01, nms_threshold=0.45, top_k=top_k)
-        else:
-            det = net.detect(images, objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45, top_k=top_k)
+    # One step = one batch through ron_detect.  `--in-flight F` batches are kept in flight on F execution slots (shared
+    # weights, one stream each): a step is submitted as soon as its slot's previous batch has been consumed.
+    from ron_tensorflow_amd.pipeline import DetectPipeline
+    in_flight = max(1, args.in_flight)
+    pipe = DetectPipeline(net, slots=in_flight, top_k=top_k)
+    detect_args = dict(select_threshold=0.01, nms_threshold=0.45) if ssd else \
+        dict(objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45)
+    pending = []
+
+    last = [None]
+
+    def consume(ticket):
+        det = last[0] = ticket.wait()              # the current stream waits for that slot; the host does not
         if world > 1:
             rec = parallel.pack_records(det.classes, det.scores, det.bboxes, det.anchor_index, det.count)
             parallel.gather_detections(rec, out=gathered)
         return det
 
+    def step():
+        pending.append(pipe.submit(images, **detect_args))
+        return consume(pending.pop(0)) if len(pending) >= in_flight else None
+
+    def drain():
+        while pending:
+            consume(pending.pop(0))
+        return last[0]
+
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     lib = _lib.lib()
-    _lib.check(lib.ron_profile_reset(net._context()))
-    # HIP events around every launch for PROFILED_STEPS of the timed steps (each event costs ~3 us of host + queue time,
-    # so not on all of them)
-    _lib.check(lib.ron_profile_enable(net._context(), min(PROFILED_STEPS, args.steps)))
+    contexts = [slot._context() for slot in pipe.slots]
+    # HIP events around every launch for PROFILED_STEPS of each slot's timed steps (each event costs ~3 us of host +
+    # queue time, so not on all of them)
+    for ctx in contexts:
+        _lib.check(lib.ron_profile_reset(ctx))
+        _lib.check(lib.ron_profile_enable(ctx, min(PROFILED_STEPS, args.steps)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        det = step()
+        step()
+    det = drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    _lib.check(lib.ron_profile_enable(net._context(), 0))
+    for ctx in contexts:
+        _lib.check(lib.ron_profile_enable(ctx, 0))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -172,20 +198,37 @@ def main():
 
     # ---- per-launch timing of the timed region (HIP events on the launch stream, inside libron_hip)
     rows = []
-    nops = lib.ron_profile_num_ops(net._context())
+    nops = lib.ron_profile_num_ops(contexts[0])
     for i in range(nops):
-        name, is_conv, fl, ms, ln = C.c_char_p(), C.c_int(), C.c_double(), C.c_double(), C.c_int()
-        ab, wb = C.c_double(), C.c_double()
-        _lib.check(lib.ron_profile_get(net._context(), i, C.byref(name), C.byref(is_conv), C.byref(fl), C.byref(ms), C.byref(ln),
-                                       C.byref(ab), C.byref(wb)))
-        rows.append(dict(name=name.value.decode(), is_conv=bool(is_conv.value), gflop_per_image=fl.value / 1e9,
-                         total_ms=ms.value, launches=ln.value, bytes_per_launch=ab.value * args.batch + wb.value))
+        row = None
+        for ctx in contexts:                       # the same launch on every slot: durations and counts add up
+            name, is_conv, fl, ms, ln = C.c_char_p(), C.c_int(), C.c_double(), C.c_double(), C.c_int()
+            ab, wb = C.c_double(), C.c_double()
+            _lib.check(lib.ron_profile_get(ctx, i, C.byref(name), C.byref(is_conv), C.byref(fl), C.byref(ms), C.byref(ln),
+                                           C.byref(ab), C.byref(wb)))
+            if row is None:
+                row = dict(name=name.value.decode(), is_conv=bool(is_conv.value), gflop_per_image=fl.value / 1e9,
+                           total_ms=0.0, launches=0, bytes_per_launch=ab.value * args.batch + wb.value)
+            row['total_ms'] += ms.value
+            row['launches'] += ln.value
+        rows.append(row)
     conv = [r for r in rows if r['is_conv'] and r['launches'] > 0]
     conv_ms = sum(r['total_ms'] for r in conv)
     conv_launches = sum(r['launches'] for r in conv)
     conv_flop = sum(r['gflop_per_image'] * 1e9 * args.batch * r['launches'] for r in conv)
     profiled_steps = max((r['launches'] for r in conv), default=0)
-    achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    conv_gflop_per_image = sum(r['gflop_per_image'] for r in rows if r['is_conv'])
+    per_launch_tflops = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    if in_flight == 1:
+        # one launch at a time: algorithmic FLOPs per launch / that kernel's average launch duration
+        achieved = per_launch_tflops
+        basis = 'conv FLOPs per launch / HIP-event duration of the launch (launches do not overlap)'
+    else:
+        # launches of different slots share the GPU, so a launch's duration is no longer the kernel's alone (and the
+        # durations of a step add up to more than the step): charge the conv kernel with the WHOLE timed region instead
+        achieved = conv_gflop_per_image * 1e9 * args.batch * args.steps / dt / 1e12
+        basis = ('%d batches in flight: conv FLOPs of the timed region / timed wall time (the other kernels\' time is charged to '
+                 'the conv kernel too); per-launch durations overlap, see concurrency' % in_flight)
     algo_bytes = sum(r['bytes_per_launch'] * r['launches'] for r in conv) / max(conv_launches, 1)
     traffic = load_traffic(args)
     peak = {'bf16': PEAK_BF16_TFLOPS, 'fp16': PEAK_F16_TFLOPS, 'fp32': PEAK_F32_TFLOPS}[args.dtype]
@@ -210,12 +253,15 @@ def main():
                                    % ({'full': 'RON-320 VGG16 ron_net', 'reducedfc': 'RON-320 reducedfc', 'ssd512': 'SSD-VGG-512'}[args.variant],
                                       args.dtype, args.batch, ron_params.img_shape[0], ron_params.img_shape[1],
                                       ', RCCL all-gather of detection records' if world > 1 else ''),
+                       'batches_in_flight': in_flight,
                        'images_per_step': world * args.batch,
                        'gflop_per_image': net.flops_per_image() / 1e9,
                        'conv_stack_tflops_per_gpu': net.flops_per_image() * args.batch * args.steps / dt / 1e12,
                        'mean_detections_per_image': float(det.count.float().mean().item())},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel', 'achieved': achieved, 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
+                         'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'basis': basis,
+                         'per_launch_tflops': per_launch_tflops,
+                         'concurrency': conv_ms / max(profiled_steps, 1) / (dt / args.steps * 1e3) if in_flight > 1 else 1.0,
                          'algorithmic_bytes_per_launch': algo_bytes,
                          'avg_launch_us': conv_ms / max(conv_launches, 1) * 1e3,
                          'launches_per_step': conv_launches // max(profiled_steps, 1),

@@ -235,6 +235,10 @@ typedef struct {
 
 int ron_create(ron_ctx** out, const ron_config* cfg);
 int ron_destroy(ron_ctx* ctx);
+/* A second execution slot over the weights of `src` (finalized): own activations, head buffers, scratch and streams,
+ * so that several batches can be in flight on different streams (a serving loop keeps the GPU's 256 CUs busy across the
+ * partial last round of workgroups every launch ends with).  Destroy the slots before the context that owns the weights. */
+int ron_clone(ron_ctx* src, ron_ctx** out);
 
 /* Number of variables the graph expects and the i-th name/shape ("ron_320_vgg/conv1/conv1_1/weights",
  * HWIO for conv, [kh,kw,Cout,Cin] for deconv, as TF stores them). */

@@ -90,6 +90,7 @@ SIGNATURES = {
     'ron_post_tfe': (C.c_int, [C.POINTER(Heads), C.c_int, C.POINTER(TfeCfg), _P, C.c_int64, _P, _P, _P]),
     'ron_create': (C.c_int, [C.POINTER(_P), C.POINTER(Config)]),
     'ron_destroy': (C.c_int, [_P]),
+    'ron_clone': (C.c_int, [_P, C.POINTER(_P)]),
     'ron_num_variables': (C.c_int, [_P]),
     'ron_variable_info': (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     'ron_load_weight': (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),

@@ -32,19 +32,26 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // tile kt+S-1 is issued right after the barrier into the stage whose reads finished before it.
 // ABL (diagnostic builds only, outputs are wrong): 1 = no LDS-DMA (compute structure alone), 2 = no LDS reads / MFMA
 // (data movement alone).
-template <class Tr, int BM, int BN, int WM, int WN, int S, bool SPREAD, int ABL = 0>
-__global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
+// RB = bytes of one LDS row = K extent of one stage (128: 64 bf16; 64: 32 bf16).  The shorter row halves the stage, so
+// the same LDS holds twice the stages and the LDS-DMA of a tile gets S-1 compute periods of lead instead of one:
+// bytes in flight per CU, not L2 bandwidth, is what bounds the staging stream ("bytes in flight").
+template <class Tr, int BM, int BN, int WM, int WN, int S, bool SPREAD, int ABL = 0, int RB = 128>
+__global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
+  constexpr int kRowBytes = RB;                      // shadows the 128-byte default of conv_device.h
+  constexpr int kLanesPerRow = RB / 16;              // 16-byte chunks per row
+  constexpr int KS = RB / 32;                        // MFMA k-steps per stage (one u32x4 fragment per lane and step)
   constexpr int kThreads = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
   constexpr int MR = TM / 32, NR = TN / 32;          // 32x32 accumulators per wave: MR x NR
-  constexpr int kRowsPerIt = kThreads / 8;           // tile rows one LDS-DMA pass of the block covers
+  constexpr int kRowsPerIt = kThreads / kLanesPerRow; // tile rows one LDS-DMA pass of the block covers
   constexpr int A_IT = BM / kRowsPerIt, B_IT = BN / kRowsPerIt;
   constexpr int LPT = A_IT + B_IT;                   // LDS-DMA instructions per thread and K step
   constexpr int kABytes = BM * kRowBytes, kBBytes = BN * kRowBytes;
   constexpr int kStage = kABytes + kBBytes;
   constexpr int kChunkElems = kRowBytes / Tr::kEsz;
   static_assert(BM % kRowsPerIt == 0 && BN % kRowsPerIt == 0 && kRowsPerIt % 16 == 0, "tile / thread-count mismatch");
-  static_assert(TM % 32 == 0 && TN % 32 == 0 && S >= 2 && S <= 4, "bad wave tile / stage count");
+  static_assert(TM % 32 == 0 && TN % 32 == 0 && S >= 2 && S <= 5, "bad wave tile / stage count");
+  static_assert(RB == 128 || RB == 64, "row bytes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // layout: [stage 0 .. S-1: A | B][in_off: BM ints][out_off: BM ints]
   int* s_in_off = reinterpret_cast<int*>(smem + S * kStage);
@@ -103,8 +110,10 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
   __syncthreads();
 
   // LDS-DMA source offsets (bytes): thread -> (row = it*kRowsPerIt + tid/8, slot = tid%8), source chunk = slot ^ key(row)
-  const int ld_row = tid >> 3;
-  const int ld_chunk = (tid & 7) ^ ((tid >> 4) & 7);
+  // swizzle key of row r: (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3 for 64-byte rows (both conflict-free for the
+  // 16-lane groups of ds_read_b128: a group's rows differ in (r & 1 | r & 3) or in the key)
+  const int ld_row = tid / kLanesPerRow;
+  const int ld_chunk = RB == 128 ? (tid & 7) ^ ((tid >> 4) & 7) : (tid & 3) ^ ((tid >> 4) & 3);
   // fixed-size arrays on purpose: with a template-dependent bound the LDS-DMA builtin's voffset becomes a
   // type-dependent expression and hipcc (ROCm 7.2) silently drops the kernel's host stub.
   int a_voff[8], b_voff[8];
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, live_ ? p.wgt_bytes : 0u, 0x00020000);        \
     const int a_soff = ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz;                         \
     const int b_soff = (kt_) * kRowBytes;                                                                            \
-    char* dst = smem + (((kt_) - kt0) % S) * kStage + wave * (8 * kRowBytes);
+    char* dst = smem + (((kt_) - kt0) % S) * kStage + wave * 1024;
 #define RON_STAGE_PIECE(i_)                                                                                          \
     do {                                                                                                             \
       if (ABL == 1 || ABL == 3) break;                                                                                        \
@@ -167,9 +176,9 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
 
   // fragment read offsets: lane -> row r = lane & 31, K half h = lane >> 5; step s reads chunk 2s+h
   const int fr = lane & 31, fh = lane >> 5;
-  int rd_off[4];
+  int rd_off[KS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) rd_off[s] = fr * kRowBytes + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+  for (int s = 0; s < KS; ++s) rd_off[s] = fr * kRowBytes + (((2 * s + fh) ^ (RB == 128 ? (fr >> 1) & 7 : (fr >> 2) & 3)) << 4);
   const int a_base = wm * TM * kRowBytes;
   const int b_base = kABytes + wn * TN * kRowBytes;
 
@@ -210,19 +219,19 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
 #pragma unroll
     for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * 32 * kRowBytes + rd_off[0]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < 3) {
+    for (int s = 0; s < KS; ++s) {
+      if (s < KS - 1) {
 #pragma unroll
         for (int i = 0; i < MR; ++i)
-          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * 32 * kRowBytes + rd_off[(s + 1) & 3]);
+          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * 32 * kRowBytes + rd_off[(s + 1) % KS]);
 #pragma unroll
         for (int j = 0; j < NR; ++j)
-          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * 32 * kRowBytes + rd_off[(s + 1) & 3]);
+          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * 32 * kRowBytes + rd_off[(s + 1) % KS]);
       }
       if (SPREAD) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i)
-          if ((i * 4) / LPT == s) RON_STAGE_PIECE(i);
+          if ((i * KS) / LPT == s) RON_STAGE_PIECE(i);
       }
 #pragma unroll
       for (int i = 0; i < MR; ++i)
@@ -235,11 +244,8 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * 128 > 80 * 1024) ? (
       constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma, PAIR = RD < MM ? RD : MM;
       __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        constexpr int kAll = SPREAD ? 0 : LPT;
-        const int pieces = SPREAD ? ((s + 1) * LPT + 3) / 4 - (s * LPT + 3) / 4 : (s == 0 ? kAll : 0);
-        (void)pieces;
-        if (s < 3) {
+      for (int s = 0; s < KS; ++s) {
+        if (s < KS - 1) {
 #pragma unroll
           for (int q = 0; q < PAIR; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -383,7 +389,7 @@ __global__ void splitk_finalize_kernel(ConvArgs p) {
   }
 }
 
-struct TileCfg { int bm, bn, wm, wn, stages, spread; };
+struct TileCfg { int bm, bn, wm, wn, stages, spread, rb = 128; };
 // index = ConvLaunch.cfg
 constexpr TileCfg kCfgs[] = {
     {128, 128, 2, 2, 2, 0},   // 0: 64 KB LDS, 2 workgroups / CU (round-1 baseline structure)
@@ -406,21 +412,28 @@ constexpr TileCfg kCfgs[] = {
     {256, 256, 2, 2, 2, 1},   // 17: diagnostic, 16 without LDS-DMA
     {256, 256, 4, 2, 2, 1},   // 18: diagnostic, 11 without LDS-DMA, waits and barriers (free-running ds_read + MFMA)
     {256, 256, 4, 2, 2, 1},   // 19: diagnostic, 11 with zero-record descriptors (DMA instructions issue, nothing moves)
+    {256, 256, 4, 2, 4, 1, 64},   // 20: 11 with 64-byte rows: 4 stages of 32 KB, three tiles (96 KB) in flight
+    {256, 256, 2, 4, 4, 1, 64},   // 21: 10 likewise
+    {256, 128, 4, 2, 5, 1, 64},   // 22: 6 likewise: 5 stages of 24 KB
+    {128, 128, 2, 2, 4, 1, 64},   // 23: 4 likewise: 4 stages of 16 KB, 2 workgroups / CU
+    {128, 64, 2, 2, 4, 1, 64},    // 24: 5 likewise
+    {256, 256, 4, 2, 4, 1, 64},   // 25: diagnostic, 20 without LDS reads / MFMA (staging stream alone)
+    {128, 128, 2, 2, 4, 0, 64},   // 26: 23 with the pieces issued up front
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 // workgroups of configuration i the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
-inline int cfg_slots(int i) { return kCfgs[i].stages * (kCfgs[i].bm + kCfgs[i].bn) * 128 <= 80 * 1024 ? 512 : 256; }
+inline int cfg_slots(int i) { return kCfgs[i].stages * (kCfgs[i].bm + kCfgs[i].bn) * kCfgs[i].rb <= 80 * 1024 ? 512 : 256; }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, bool SPREAD, int ABL = 0>
+template <class Tr, int BM, int BN, int WM, int WN, int S, bool SPREAD, int ABL = 0, int RB = 128>
 int launch_t(const ConvArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)S * (BM + BN) * kRowBytes + 2 * BM * sizeof(int);
+  const size_t lds = (size_t)S * (BM + BN) * RB + 2 * BM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL>),
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -448,6 +461,13 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 17: return launch_t<Tr, 256, 256, 2, 2, 2, true, 1>(a, s);
     case 18: return launch_t<Tr, 256, 256, 4, 2, 2, true, 3>(a, s);
     case 19: return launch_t<Tr, 256, 256, 4, 2, 2, true, 4>(a, s);
+    case 20: return launch_t<Tr, 256, 256, 4, 2, 4, true, 0, 64>(a, s);
+    case 21: return launch_t<Tr, 256, 256, 2, 4, 4, true, 0, 64>(a, s);
+    case 22: return launch_t<Tr, 256, 128, 4, 2, 5, true, 0, 64>(a, s);
+    case 23: return launch_t<Tr, 128, 128, 2, 2, 4, true, 0, 64>(a, s);
+    case 24: return launch_t<Tr, 128, 64, 2, 2, 4, true, 0, 64>(a, s);
+    case 25: return launch_t<Tr, 256, 256, 4, 2, 4, true, 2, 64>(a, s);
+    case 26: return launch_t<Tr, 128, 128, 2, 2, 4, false, 0, 64>(a, s);
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;
@@ -494,7 +514,7 @@ int conv_pick_cfg(int M, int Npad, int K) {
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   if (c.cfg == kCfgPatch) return launch_conv_patch(c, stream);
   const int esz = (int)dtype_size(c.dtype);
-  const int chunk = conv_k_chunk(c.dtype);
+  int chunk = conv_k_chunk(c.dtype);
   RON_REQUIRE(c.in.C % chunk == 0, "conv: Cin %d is not a multiple of the K chunk %d", c.in.C, chunk);
   RON_REQUIRE(c.in.pad >= c.cpad, "conv: input halo %d < conv padding %d", c.in.pad, c.cpad);
   RON_REQUIRE(c.in.bytes > 0 && c.in.bytes < (int64_t)1 << 32, "conv: input allocation must be < 4 GiB for buffer addressing");
@@ -505,6 +525,8 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg(M, c.Npad, K);
   RON_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "conv: tile config %d out of range", cfg);
   const int BN = kCfgs[cfg].bn;
+  const int kt_heur = K / chunk;                    // the split-K heuristic counts 128-byte K steps
+  chunk = kCfgs[cfg].rb / esz;
   RON_REQUIRE(c.Npad % BN == 0, "conv: Npad %d not a multiple of the N tile %d", c.Npad, BN);
   if (c.up > 0) RON_REQUIRE(c.up_cout % BN == 0, "transposed conv: channels per tap %d not a multiple of %d", c.up_cout, BN);
   ConvArgs a;
@@ -531,7 +553,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
                 "conv + fused pool: plain stride-1 conv on an even map only");
     RON_REQUIRE(c.out.H == c.Ho / 2 && c.out.W == c.Wo / 2, "conv + fused pool: output view must be the pooled map");
   }
-  const int sk = c.splitk >= 0 ? c.splitk : conv_pick_splitk(a.tiles_total, a.KT, cfg_slots(cfg));
+  const int sk = c.splitk >= 0 ? c.splitk : conv_pick_splitk(a.tiles_total, kt_heur, cfg_slots(cfg));
   if (sk > 1 && c.up == 0 && !c.pool && c.scratch != nullptr && (int64_t)sk * M * c.Npad * 4 <= c.scratch_bytes) {
     a.kt_split = (a.KT + sk - 1) / sk;
     a.splitk = (a.KT + a.kt_split - 1) / a.kt_split;      // no empty split

@@ -120,6 +120,9 @@ struct ron_ctx {
   std::vector<std::vector<int>> pending_ops;          // ... and what it marks: op index (its start), -1 = end of a lane,
                                                       //     -2 / -3 = start / end of the post-processing stage
   std::vector<hipEvent_t> event_pool;
+  // ron_clone: an execution slot that borrows the packed weights of `weights_owner` (its own activations, scratch, streams)
+  ron_ctx* weights_owner = nullptr;
+  int clones = 0;                       // live slots that borrow this context's weights
 
   int esz() const { return (int)dtype_size(cfg.dtype); }
   int add_tensor(const std::string& name, int H, int W, int C, int pad) {
@@ -506,6 +509,13 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
 
 extern "C" int ron_destroy(ron_ctx* c) {
   if (!c) return RON_OK;
+  if (c->clones > 0) { ron::set_error("ron_destroy: %d execution slot(s) still borrow this context's weights", c->clones); return RON_ERR_STATE; }
+  const bool borrowed = c->weights_owner != nullptr;
+  if (borrowed) {                        // the weights belong to the owner
+    --c->weights_owner->clones;
+    c->packed.clear();
+    c->d_l2_gamma = nullptr; c->d_stem_w = nullptr; c->d_stem_b = nullptr;
+  }
   for (auto& t : c->tensors) if (t.d) (void)hipFree(t.d);
   for (auto& p : c->packed) { if (p.d_w) (void)hipFree(p.d_w); if (p.d_bias) (void)hipFree(p.d_bias); }
   for (int i = 0; i < RON_MAX_LAYERS; ++i) for (int k = 0; k < 4; ++k) if (c->d_anchor[i][k]) (void)hipFree(c->d_anchor[i][k]);
@@ -549,6 +559,8 @@ extern "C" int ron_load_weight(ron_ctx* c, const char* tf_name, const float* hos
   v.loaded = true;
   return RON_OK;
 }
+
+static int slot_resources(ron_ctx* c);
 
 extern "C" int ron_finalize_weights(ron_ctx* c) {
   RON_REQUIRE(c, "NULL ctx");
@@ -752,6 +764,28 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
             o.name.find("_deconv_right") == std::string::npos)
           o.lane = i + 1;
       }
+  }
+  for (Op& o : c->ops) {
+    if (o.kind != OP_CONV) continue;
+    const PackedConv& pk = c->packed[o.packed];
+    const Tensor& ti = c->tensors[o.in];
+    const int cin = o.in_C > 0 ? o.in_C : ti.C;
+    const double out_esz = o.out == -2 ? 4.0 : (double)c->esz();
+    const int os = o.up > 0 ? o.up * o.up : 1;
+    const double out_px = o.pool ? (double)o.Ho * o.Wo / 4 : (double)o.Ho * o.Wo * os;
+    const double out_ch = o.up > 0 ? (double)o.up_cout : (double)pk.Cout;
+    o.act_bytes = (double)ti.H * ti.W * cin * c->esz() + out_px * out_ch * out_esz + (o.res >= 0 ? out_px * out_ch * c->esz() : 0.0);
+    o.wgt_bytes = (double)pk.w_bytes;
+  }
+  for (auto& v : c->vars) { v.data.clear(); v.data.shrink_to_fit(); }
+  if ((rc = slot_resources(c))) return rc;
+  c->finalized = true;
+  return RON_OK;
+}
+
+// Streams, events, split-K scratch and timing slots of one execution slot (after c->ops / c->packed are in place).
+static int slot_resources(ron_ctx* c) {
+  if ((c->cfg.flags & RON_CFG_MULTI_STREAM) && !c->is_ssd()) {
     for (int l = 1; l < 4; ++l) {
       RON_HIP_CHECK(hipStreamCreateWithFlags(&c->side[l], hipStreamNonBlocking));
       RON_HIP_CHECK(hipEventCreateWithFlags(&c->lane_ready[l], hipEventDisableTiming));
@@ -770,21 +804,29 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
   }
   for (int l = 0; l < 4; ++l)
     if (c->splitk_bytes[l] > 0) RON_HIP_CHECK(hipMalloc(&c->d_splitk[l], (size_t)c->splitk_bytes[l]));
-  for (Op& o : c->ops) {
-    if (o.kind != OP_CONV) continue;
-    const PackedConv& pk = c->packed[o.packed];
-    const Tensor& ti = c->tensors[o.in];
-    const int cin = o.in_C > 0 ? o.in_C : ti.C;
-    const double out_esz = o.out == -2 ? 4.0 : (double)c->esz();
-    const int os = o.up > 0 ? o.up * o.up : 1;
-    const double out_px = o.pool ? (double)o.Ho * o.Wo / 4 : (double)o.Ho * o.Wo * os;
-    const double out_ch = o.up > 0 ? (double)o.up_cout : (double)pk.Cout;
-    o.act_bytes = (double)ti.H * ti.W * cin * c->esz() + out_px * out_ch * out_esz + (o.res >= 0 ? out_px * out_ch * c->esz() : 0.0);
-    o.wgt_bytes = (double)pk.w_bytes;
-  }
   c->timing.assign(c->ops.size() + 1, OpTiming());
-  for (auto& v : c->vars) { v.data.clear(); v.data.shrink_to_fit(); }
+  return RON_OK;
+}
+
+// A second execution slot over the same weights: own activations, head buffers, scratch and streams, so that two
+// (or more) batches can be in flight on different streams; the packed weights stay with `src`.
+extern "C" int ron_clone(ron_ctx* src, ron_ctx** out) {
+  RON_REQUIRE(src && out, "NULL argument");
+  if (!src->finalized) { ron::set_error("ron_clone before ron_finalize_weights"); return RON_ERR_STATE; }
+  ron_ctx* owner = src->weights_owner ? src->weights_owner : src;
+  ron_ctx* c = nullptr;
+  int rc = ron_create(&c, &src->cfg);
+  if (rc) return rc;
+  c->packed = owner->packed;
+  c->ops = owner->ops;
+  c->d_l2_gamma = owner->d_l2_gamma; c->d_stem_w = owner->d_stem_w; c->d_stem_b = owner->d_stem_b;
+  c->flops_per_image = owner->flops_per_image;
+  c->weights_owner = owner;
+  ++owner->clones;
+  for (auto& v : c->vars) v.loaded = true;
+  if ((rc = slot_resources(c))) { (void)ron_destroy(c); return rc; }
   c->finalized = true;
+  *out = c;
   return RON_OK;
 }
 

@@ -96,9 +96,26 @@ class RONNet(object):
     def flops_per_image(self):
         return lib().ron_flops_per_image(self._context())
 
+    def clone(self):
+        """A second execution slot over the same device weights (ron_clone): its own activations, scratch and
+        streams, so that another batch can be in flight on another stream.  The slot keeps this network alive."""
+        import copy
+        other = copy.copy(self)
+        h = C.c_void_p()
+        check(lib().ron_clone(self._context(), C.byref(h)))
+        other._ctx = h
+        other._weights_from = self
+        other._slots = []
+        self._slots = getattr(self, '_slots', [])
+        self._slots.append(other)
+        return other
+
     def close(self):
+        for slot in getattr(self, '_slots', []):       # slots borrow this network's weights: they go first
+            slot.close()
+        self._slots = []
         if self._ctx is not None:
-            lib().ron_destroy(self._ctx)
+            check(lib().ron_destroy(self._ctx))
             self._ctx = None
 
     def __del__(self):
@@ -187,8 +204,9 @@ class RONNet(object):
 
     # ------------------------------------------------------------------ fused graded path
     def detect(self, inputs, objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45, top_k=400,
-               bbox_img=(0., 0., 1., 1.)):
-        """forward + np_methods post-processing in one enqueue (ron_detect).  Returns DetectionBuffers."""
+               bbox_img=(0., 0., 1., 1.), out=None):
+        """forward + np_methods post-processing in one enqueue (ron_detect).  Returns DetectionBuffers
+        (`out`, when given, is reused: n and capacity must match)."""
         inputs = inputs.to(self.device, torch.float32).contiguous()
         n = inputs.shape[0]
         cfg = _lib.PostCfg()
@@ -197,7 +215,9 @@ class RONNet(object):
         for i in range(4):
             cfg.bbox_img[i] = bbox_img[i]
             cfg.prior_scaling[i] = self.params.prior_scaling[i]
-        out = ops.DetectionBuffers(n, top_k, self.device)
+        if out is None:
+            out = ops.DetectionBuffers(n, top_k, self.device)
+        assert out.n == n and out.capacity == top_k
         oc = out.c_struct()
         check(lib().ron_detect(self._context(), ptr(inputs), n, C.byref(cfg), C.byref(oc), current_stream()))
         return out
