@@ -42,6 +42,7 @@ struct ConvLaunch {
   int splitk = -1;               // split-K factor; -1 = pick by grid size, 1 = off
   void* scratch = nullptr;       // fp32 slabs for split-K (conv_scratch_bytes); null disables split-K
   int64_t scratch_bytes = 0;
+  unsigned long long* dbg = nullptr;   // stamp builds (tile cfgs 27-29): 4 x u64 per wave of the grid
 };
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream);

@@ -39,10 +39,13 @@ template <class Tr, int BM, int BN, int WM, int WN, int S, bool SPREAD, int ABL 
 __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
   constexpr int kRowBytes = RB;                      // shadows the 128-byte default of conv_device.h
   constexpr int kLanesPerRow = RB / 16;              // 16-byte chunks per row
-  constexpr int KS = RB / 32;                        // MFMA k-steps per stage (one u32x4 fragment per lane and step)
+  constexpr int MT = Tr::kMT;                        // MFMA output tile: 32 (32x32x16) or 16 (16x16x32)
+  constexpr int kGroups = 64 / MT;                   // 16-byte K groups one instruction consumes per row (2 or 4)
+  constexpr int KS = kLanesPerRow / kGroups;         // MFMA k-steps per stage (one u32x4 fragment per lane and step)
+  constexpr int EPA = MT * MT / 64;                  // accumulator registers per MFMA tile
   constexpr int kThreads = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;          // wave tile
-  constexpr int MR = TM / 32, NR = TN / 32;          // 32x32 accumulators per wave: MR x NR
+  constexpr int MR = TM / MT, NR = TN / MT;          // MT x MT accumulators per wave: MR x NR
   constexpr int kRowsPerIt = kThreads / kLanesPerRow; // tile rows one LDS-DMA pass of the block covers
   constexpr int A_IT = BM / kRowsPerIt, B_IT = BN / kRowsPerIt;
   constexpr int LPT = A_IT + B_IT;                   // LDS-DMA instructions per thread and K step
@@ -51,6 +54,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
   constexpr int kChunkElems = kRowBytes / Tr::kEsz;
   static_assert(BM % kRowsPerIt == 0 && BN % kRowsPerIt == 0 && kRowsPerIt % 16 == 0, "tile / thread-count mismatch");
   static_assert(TM % 32 == 0 && TN % 32 == 0 && S >= 2 && S <= 5, "bad wave tile / stage count");
+  static_assert(NR <= 8, "vector epilogue: at most 8 channels per lane");
   static_assert(RB == 128 || RB == 64, "row bytes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // layout: [stage 0 .. S-1: A | B][in_off: BM ints][out_off: BM ints]
@@ -120,14 +124,14 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
   static_assert(A_IT <= 8 && B_IT <= 8, "tile too large");
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) a_voff[it] = s_in_off[it * kRowsPerIt + ld_row] + ld_chunk * 16;
-  // B rows are permuted on the way in: LDS row (j*32 + r) of a wave's TN-wide group holds weight row (r*NR + j), so
-  // that MFMA column r of the wave's j-th 32-column tile is output channel r*NR + j: a lane's NR accumulators are NR
+  // B rows are permuted on the way in: LDS row (j*MT + r) of a wave's TN-wide group holds weight row (r*NR + j), so
+  // that MFMA column r of the wave's j-th MT-column tile is output channel r*NR + j: a lane's NR accumulators are NR
   // adjacent channels and the epilogue stores them as one contiguous NR-element vector (full 128-B lines per row).
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
     const int lrow = it * kRowsPerIt + ld_row;
     const int grp = lrow / TN, loc = lrow % TN;
-    const int nrow = grp * TN + (loc & 31) * NR + (loc >> 5);
+    const int nrow = grp * TN + (loc % MT) * NR + (loc / MT);
     b_voff[it] = (n0 + nrow) * p.K * Tr::kEsz + ld_chunk * 16;
   }
 
@@ -166,19 +170,19 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
       }                                                                                                              \
     } while (0)
 
-  f32x16 acc[MR][NR];
+  typename Tr::acc_t acc[MR][NR];
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < NR; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < EPA; ++e) acc[i][j][e] = 0.f;
 
-  // fragment read offsets: lane -> row r = lane & 31, K half h = lane >> 5; step s reads chunk 2s+h
-  const int fr = lane & 31, fh = lane >> 5;
+  // fragment read offsets: lane -> row r = lane % MT, K group h = lane / MT; step s reads chunk kGroups*s + h
+  const int fr = lane & (MT - 1), fh = lane / MT;
   int rd_off[KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) rd_off[s] = fr * kRowBytes + (((2 * s + fh) ^ (RB == 128 ? (fr >> 1) & 7 : (fr >> 2) & 3)) << 4);
+  for (int s = 0; s < KS; ++s) rd_off[s] = fr * kRowBytes + (((kGroups * s + fh) ^ (RB == 128 ? (fr >> 1) & 7 : (fr >> 2) & 3)) << 4);
   const int a_base = wm * TM * kRowBytes;
   const int b_base = kABytes + wn * TN * kRowBytes;
 
@@ -191,10 +195,23 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
     RON_STAGE_END();
   }
 
+  // ABL 5: s_memtime stamps around the wait, the barrier and the rest of the K step (shares, not run time)
+  unsigned long long t_wait = 0, t_bar = 0, t_comp = 0, t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+#define RON_STAMP(t_)                                                                      \
+    do {                                                                                   \
+      if (ABL == 5) {                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+      }                                                                                    \
+    } while (0)
   for (int kt = kt0; kt < kt1; ++kt) {
+    RON_STAMP(t_a);
     if (ABL != 3) {
     wait_vmcnt<(S - 2) * LPT>();            // this wave's share of tile kt has landed
+    RON_STAMP(t_b);
     __builtin_amdgcn_s_barrier();           // ... everyone's has, and everyone is done reading tile kt-1
+    RON_STAMP(t_c);
     }
     // refill the stage tile kt-1 occupied; the LPT pieces are spread over the four k-steps below so that
     // their issue slots fall into the MFMA shadow instead of ahead of it (SPREAD) or are issued up front
@@ -215,18 +232,18 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
       continue;
     }
 #pragma unroll
-    for (int i = 0; i < MR; ++i) fa[0][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * 32 * kRowBytes + rd_off[0]);
+    for (int i = 0; i < MR; ++i) fa[0][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * MT * kRowBytes + rd_off[0]);
 #pragma unroll
-    for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * 32 * kRowBytes + rd_off[0]);
+    for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * MT * kRowBytes + rd_off[0]);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (s < KS - 1) {
 #pragma unroll
         for (int i = 0; i < MR; ++i)
-          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * 32 * kRowBytes + rd_off[(s + 1) % KS]);
+          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * MT * kRowBytes + rd_off[(s + 1) % KS]);
 #pragma unroll
         for (int j = 0; j < NR; ++j)
-          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * 32 * kRowBytes + rd_off[(s + 1) % KS]);
+          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * MT * kRowBytes + rd_off[(s + 1) % KS]);
       }
       if (SPREAD) {
 #pragma unroll
@@ -261,12 +278,20 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
       }
     }
     RON_STAGE_END();
+    RON_STAMP(t_d);
+    if (ABL == 5) { t_wait += t_b - t_a; t_bar += t_c - t_b; t_comp += t_d - t_c; }
   }
+  if (ABL == 5 && p.dbg != nullptr && lane == 0) {
+    unsigned long long* d = p.dbg + ((size_t)blockIdx.x * (kThreads / 64) + wave) * 4;
+    d[0] = t_wait; d[1] = t_bar; d[2] = t_comp; d[3] = (unsigned long long)(kt1 - kt0);
+  }
+#undef RON_STAMP
 #undef RON_STAGE_BEGIN
 #undef RON_STAGE_PIECE
 #undef RON_STAGE_END
 
-  // epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  // epilogue.  C/D layout of the MFMA: column = lane % MT, row = (e & 3) + 8 * (e >> 2) + 4 * (lane / MT)
+  // (32x32: e < 16; 16x16: e < 4, the e >> 2 term vanishes)
   int tap_off = 0, n_base = n0;
   if (p.up > 0) {
     const int tap = n0 / p.up_cout;                       // BN divides up_cout: uniform per tile
@@ -280,8 +305,8 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int rt = wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+      for (int e = 0; e < EPA; ++e) {
+        const int rt = wm * TM + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (s_out_off[rt] < 0) continue;
         float v[NR];
 #pragma unroll
@@ -301,8 +326,8 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int ooff = s_out_off[wm * TM + i * 32 + 8 * t + 4 * fh];
+      for (int t = 0; t < EPA / 4; ++t) {
+        const int ooff = s_out_off[wm * TM + i * MT + 8 * t + 4 * fh];
         if (ooff < 0 || n_valid <= 0) continue;
         float v[NR];
 #pragma unroll
@@ -325,8 +350,8 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int rt = wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+    for (int e = 0; e < EPA; ++e) {
+      const int rt = wm * TM + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh;
       const int ooff = s_out_off[rt];
       if (ooff < 0 || n_valid <= 0) continue;
       const int o = ooff + tap_off + ncol0;
@@ -389,7 +414,7 @@ __global__ void splitk_finalize_kernel(ConvArgs p) {
   }
 }
 
-struct TileCfg { int bm, bn, wm, wn, stages, spread, rb = 128; };
+struct TileCfg { int bm, bn, wm, wn, stages, spread, rb = 128, mt = 32; };
 // index = ConvLaunch.cfg
 constexpr TileCfg kCfgs[] = {
     {128, 128, 2, 2, 2, 0},   // 0: 64 KB LDS, 2 workgroups / CU (round-1 baseline structure)
@@ -419,6 +444,14 @@ constexpr TileCfg kCfgs[] = {
     {128, 64, 2, 2, 4, 1, 64},    // 24: 5 likewise
     {256, 256, 4, 2, 4, 1, 64},   // 25: diagnostic, 20 without LDS reads / MFMA (staging stream alone)
     {128, 128, 2, 2, 4, 0, 64},   // 26: 23 with the pieces issued up front
+    {256, 256, 4, 2, 2, 1},       // 27: diagnostic, 11 with s_memtime stamps (ConvLaunch.dbg)
+    {128, 128, 2, 2, 2, 1},       // 28: diagnostic, 4 with stamps
+    {256, 128, 4, 2, 3, 1},       // 29: diagnostic, 6 with stamps
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 30: 11 on 16x16x32 MFMAs
+    {256, 256, 2, 4, 2, 1, 128, 16},   // 31: 10 likewise
+    {256, 128, 4, 2, 3, 1, 128, 16},   // 32: 6 likewise
+    {128, 128, 2, 2, 2, 1, 128, 16},   // 33: 4 likewise
+    {128, 64, 2, 2, 2, 1, 128, 16},    // 34: 5 likewise
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 // workgroups of configuration i the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
@@ -468,6 +501,14 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 24: return launch_t<Tr, 128, 64, 2, 2, 4, true, 0, 64>(a, s);
     case 25: return launch_t<Tr, 256, 256, 4, 2, 4, true, 2, 64>(a, s);
     case 26: return launch_t<Tr, 128, 128, 2, 2, 4, false, 0, 64>(a, s);
+    case 27: return launch_t<Tr, 256, 256, 4, 2, 2, true, 5>(a, s);
+    case 28: return launch_t<Tr, 128, 128, 2, 2, 2, true, 5>(a, s);
+    case 29: return launch_t<Tr, 256, 128, 4, 2, 3, true, 5>(a, s);
+    case 30: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, true>(a, s);
+    case 31: return launch_t<typename SmallShape<Tr>::type, 256, 256, 2, 4, 2, true>(a, s);
+    case 32: return launch_t<typename SmallShape<Tr>::type, 256, 128, 4, 2, 3, true>(a, s);
+    case 33: return launch_t<typename SmallShape<Tr>::type, 128, 128, 2, 2, 2, true>(a, s);
+    case 34: return launch_t<typename SmallShape<Tr>::type, 128, 64, 2, 2, 2, true>(a, s);
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;
@@ -499,16 +540,16 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
   return sk < 1 ? 1 : sk;
 }
 
-// Default tile choice, from tools/sweep_conv.py on MI355X at batch 32 (profiles/r01/sweep_*.txt):
-// the 256x256 tile wins once it yields >= ~160 workgroups, 256x128 (3 stages) down to ~190 workgroups, below that
-// the grid is the problem and the 128x128 / 2-workgroups-per-CU form keeps more CUs busy.
+// Default tile choice, from tools/sweep_conv.py on MI355X at batch 32 (profiles/r01/sweep_*.txt).  All defaults are
+// the 16x16x32-MFMA forms (5-19 % over the 32x32x16 forms of the same tile: the chip holds a higher clock on them).
+// The 256x256 tile wins once it yields >= ~160 workgroups; below that the grid is the problem and the 128x128 /
+// 2-workgroups-per-CU form keeps more CUs busy (it also beats the 3-stage 256x128 tile wherever that used to win).
 int conv_pick_cfg(int M, int Npad, int K) {
   (void)K;
   const int tm256 = (M + 255) / 256;
-  if (Npad % 128 != 0) return 5;                                    // N tile 64
-  if (Npad % 256 == 0 && tm256 * (Npad / 256) >= 160) return 11;
-  if (tm256 * (Npad / 128) >= 190) return 6;
-  return 0;
+  if (Npad % 128 != 0) return 34;                                   // N tile 64
+  if (Npad % 256 == 0 && tm256 * (Npad / 256) >= 160) return 30;
+  return 33;
 }
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
@@ -548,6 +589,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   a.Npad = c.Npad;
   a.splitk = 1; a.kt_split = a.KT; a.partial = nullptr;
   a.pool = c.pool;
+  a.dbg = c.dbg;
   if (c.pool) {
     RON_REQUIRE(c.up == 0 && c.res == nullptr && !c.out_f32 && c.Ho % 2 == 0 && c.Wo % 2 == 0 && c.stride == 1,
                 "conv + fused pool: plain stride-1 conv on an even map only");

@@ -18,8 +18,9 @@
 namespace ron {
 namespace detail {
 
-constexpr int kPatchPieces = 7;                  // LDS-DMA pieces per thread and chunk (512 threads x 16 B)
-constexpr int kPatchRows = kPatchPieces * 64;    // 448 patch rows of 128 B
+constexpr int kPatchPieces = 6;                  // LDS-DMA pieces per thread and chunk (512 threads x 16 B)
+constexpr int kPatchRows = kPatchPieces * 64;    // 384 patch rows of 128 B
+constexpr int kPatchBStages = 3;                 // weight stages: two steps of lead for the per-tap weight tiles
 
 struct PatchArgs {
   ConvArgs c;
@@ -31,6 +32,7 @@ struct PatchArgs {
 
 template <class Tr, int BN, int WN>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
+  constexpr int SB = kPatchBStages;
   const ConvArgs& p = pa.c;
   constexpr int BM = 256, WM = 8 / WN, kThreads = 512;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -39,10 +41,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
   constexpr int kPatchBytes = kPatchRows * kRowBytes;
   constexpr int kBBytes = BN * kRowBytes;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // layout: [patch 0][patch 1][B stage 0][B stage 1][pp: BM ints][out_off: BM ints]
+  // layout: [patch 0][patch 1][B stage 0 .. SB-1][pp: BM ints][out_off: BM ints]
   char* s_b = smem + 2 * kPatchBytes;
-  int* s_pp = reinterpret_cast<int*>(s_b + 2 * kBBytes);
+  int* s_pp = reinterpret_cast<int*>(s_b + SB * kBBytes);
   int* s_out_off = s_pp + BM;
+  // a zero-record LDS-DMA still writes (zeros): the placeholder pieces that keep the vmcnt groups uniform land here
+  char* s_sink = reinterpret_cast<char*>(s_out_off + BM);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -118,6 +122,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(live_),                                                              \
                                            (lds_void*)(smem + (buf_) * kPatchBytes + ((k_) * kThreads + wave * 64) * 16), 16, \
                                            p_voff[k_], (cc_) * kRowBytes, 0, 0)
+#define SINK_PIECE()                                                                                                 \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(false), (lds_void*)(s_sink + wave * 1024), 16, p_voff[0], 0, 0, 0)
 #define B_PIECES(stage_, tap_, cc_, live_)                                                                           \
   do {                                                                                                               \
     const int soff_ = ((tap_) * pa.chunks + (cc_)) * kRowBytes;                                                      \
@@ -135,21 +141,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // prologue: whole patch of chunk 0 and the weights of step 0
+  // Every step issues one group of 1 + B_IT LDS-DMA instructions: one piece of the NEXT chunk's patch (a zero-record
+  // descriptor when there is none to fetch) and the weights of step + SB - 1.  The prologue is shaped the same way, so one
+  // counted vmcnt serves every step: all but the newest (SB-2) groups have landed = the weights of this step, and - at a
+  // chunk boundary - the patch whose last piece went out three steps earlier.
+  const int n_steps = pa.chunks * 9;
 #pragma unroll
   for (int k = 0; k < kPatchPieces; ++k) PATCH_PIECE(k, 0, 0, true);
   B_PIECES(0, 0, 0, true);
+#pragma unroll
+  for (int t = 1; t < SB - 1; ++t) {
+    SINK_PIECE();
+    B_PIECES(t, t % 9, t / 9, t < n_steps);
+  }
 
-  const int n_steps = pa.chunks * 9;
   int tap = 0, cc = 0, ky = 0, kx = 0;
+  int ntap = (SB - 1) % 9, ncc = (SB - 1) / 9;      // tap / chunk of step + SB - 1
+  int st_rd = 0, st_wr = SB - 1;
   for (int step = 0; step < n_steps; ++step) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((SB - 2) * (B_IT + 1)) : "memory");
     __builtin_amdgcn_s_barrier();
-    // next step's weights; one piece of the next chunk's patch per tap step (taps 0..6)
     {
-      int ntap = tap + 1, ncc = cc;
-      if (ntap == 9) { ntap = 0; ncc = cc + 1; }
-      B_PIECES((step + 1) & 1, ntap, ncc, step + 1 < n_steps);
       const bool more = cc + 1 < pa.chunks;
       switch (tap) {
         case 0: PATCH_PIECE(0, (cc + 1) & 1, cc + 1, more); break;
@@ -158,12 +170,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
         case 3: PATCH_PIECE(3, (cc + 1) & 1, cc + 1, more); break;
         case 4: PATCH_PIECE(4, (cc + 1) & 1, cc + 1, more); break;
         case 5: PATCH_PIECE(5, (cc + 1) & 1, cc + 1, more); break;
-        case 6: PATCH_PIECE(6, (cc + 1) & 1, cc + 1, more); break;
-        default: break;
+        default: SINK_PIECE(); break;
       }
+      B_PIECES(st_wr, ntap, ncc, step + SB - 1 < n_steps);
+      if (++ntap == 9) { ntap = 0; ++ncc; }
+      if (++st_wr == SB) st_wr = 0;
     }
     const char* sa = smem + (cc & 1) * kPatchBytes;
-    const char* sb = s_b + (step & 1) * kBBytes + b_base;
+    const char* sb = s_b + st_rd * kBBytes + b_base;
+    if (++st_rd == SB) st_rd = 0;
     const int tapoff = ky * pa.PW + kx;
     int a_row[MR], a_key[MR];
 #pragma unroll
@@ -172,22 +187,51 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
       a_row[i] = row * kRowBytes;
       a_key[i] = (row >> 1) & 7;
     }
+    // fragments of k-step s+1 are read while the MFMAs of k-step s run (two register sets), issue order pinned as in
+    // conv_mfma.hip: hipcc otherwise reads, waits and multiplies k-step by k-step
+    u32x4 fa[2][MR], fb[2][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) fa[0][i] = *reinterpret_cast<const u32x4*>(sa + a_row[i] + ((fh ^ a_key[i]) << 4));
+#pragma unroll
+    for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * kRowBytes + rd_off_b[0]);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      u32x4 fa[MR], fb[NR];
+      if (s < 3) {
 #pragma unroll
-      for (int i = 0; i < MR; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sa + a_row[i] + (((2 * s + fh) ^ a_key[i]) << 4));
+        for (int i = 0; i < MR; ++i)
+          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sa + a_row[i] + (((2 * (s + 1) + fh) ^ a_key[i]) << 4));
 #pragma unroll
-      for (int j = 0; j < NR; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * kRowBytes + rd_off_b[s]);
+        for (int j = 0; j < NR; ++j)
+          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * kRowBytes + rd_off_b[(s + 1) & 3]);
+      }
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
-        for (int j = 0; j < NR; ++j) Tr::mma(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < NR; ++j) Tr::mma(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
+    }
+    {
+      constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma, PAIR = RD < MM ? RD : MM;
+      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < 3) {
+#pragma unroll
+          for (int q = 0; q < PAIR; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          if (RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+          if (MM > RD) __builtin_amdgcn_sched_group_barrier(0x008, MM - RD, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
+        }
+      }
     }
     if (++tap == 9) { tap = 0; ++cc; ky = 0; kx = 0; }
     else if (++kx == 3) { kx = 0; ++ky; }
   }
 #undef PATCH_PIECE
+#undef SINK_PIECE
 #undef B_PIECES
 #undef RS_A
 #undef RS_B
@@ -263,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
 
 template <class Tr, int BN, int WN>
 int launch_patch_t(const PatchArgs& a, int grid, hipStream_t s) {
-  const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + 2 * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int);
+  const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + kPatchBStages * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 8192;
   static bool attr_set = false;
   if (!attr_set) {
     RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN>),
@@ -282,8 +326,7 @@ using namespace detail;
 static bool pick_tile(int H, int W, bool pool, int* TH, int* TW) {
   (void)H;
   int tw;
-  if (W % 64 == 0) tw = 64;
-  else if (W % 32 == 0) tw = 32;
+  if (W % 32 == 0) tw = 32;
   else if (W <= 64 && W >= 40) tw = W;           // 40-wide maps: six full rows per tile
   else if (W % 40 == 0) tw = 40;
   else return false;

@@ -2,6 +2,7 @@
 // graph launches, wrapped with dense-fp32 <-> halo-tensor conversion so that the parity tests
 // can pin each kernel against the oracle.  They allocate scratch and synchronise: test/tool use.
 #include <math.h>
+#include <stdio.h>
 
 #include <vector>
 
@@ -189,6 +190,30 @@ extern "C" int ron_conv2d_bench(const ron_conv_desc* d, int warmup, int iters, f
   float ms = 0.f;
   RON_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   *ms_per_launch = ms / iters;
+  if (d->tile_cfg >= 27 && d->tile_cfg <= 29) {
+    // stamp build: one more launch with a debug buffer, shares of the K step to stderr
+    const size_t waves = (size_t)1 << 20;
+    unsigned long long* dbg = nullptr;
+    RON_HIP_CHECK(hipMalloc((void**)&dbg, waves * 4 * sizeof(unsigned long long)));
+    RON_HIP_CHECK(hipMemset(dbg, 0, waves * 4 * sizeof(unsigned long long)));
+    S.c.dbg = dbg;
+    if ((rc = launch_conv(S.c, nullptr))) return rc;
+    RON_HIP_CHECK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(waves * 4);
+    RON_HIP_CHECK(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sw = 0, sb = 0, sc = 0, steps = 0;
+    size_t n = 0;
+    for (size_t i = 0; i < waves; ++i) {
+      if (h[4 * i + 3] == 0) continue;
+      sw += (double)h[4 * i]; sb += (double)h[4 * i + 1]; sc += (double)h[4 * i + 2]; steps += (double)h[4 * i + 3];
+      ++n;
+    }
+    if (steps > 0)
+      fprintf(stderr, "[stamps cfg %d] waves %zu, per K step (s_memtime ticks, 100 MHz): wait %.1f  barrier %.1f  rest %.1f\n",
+              d->tile_cfg, n, sw / steps, sb / steps, sc / steps);
+    S.c.dbg = nullptr;
+    (void)hipFree(dbg);
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return RON_OK;
