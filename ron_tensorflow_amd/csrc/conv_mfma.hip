@@ -35,7 +35,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // RB = bytes of one LDS row = K extent of one stage (128: 64 bf16; 64: 32 bf16).  The shorter row halves the stage, so
 // the same LDS holds twice the stages and the LDS-DMA of a tile gets S-1 compute periods of lead instead of one:
 // bytes in flight per CU, not L2 bandwidth, is what bounds the staging stream ("bytes in flight").
-template <class Tr, int BM, int BN, int WM, int WN, int S, bool SPREAD, int ABL = 0, int RB = 128>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int ABL = 0, int RB = 128>
 __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
   constexpr int kRowBytes = RB;                      // shadows the 128-byte default of conv_device.h
   constexpr int kLanesPerRow = RB / 16;              // 16-byte chunks per row
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
       if (SPREAD) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i)
-          if ((i * KS) / LPT == s) RON_STAGE_PIECE(i);
+          if ((SPREAD == 2 ? 0 : (i * KS) / LPT) == s) RON_STAGE_PIECE(i);
       }
 #pragma unroll
       for (int i = 0; i < MR; ++i)
@@ -256,25 +256,28 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
         for (int j = 0; j < NR; ++j) Tr::mma(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
     }
     // Pin the issue order (hipcc otherwise sinks the next k-step's fragment reads below the MFMAs to save
-    // registers): R0 | (MFMA, read)* of k-steps 0..2 with the LDS-DMA pieces in the MFMA shadow | MFMAs of step 3.
+    // registers): R0 | per k-step: MFMAs with the next k-step's reads one per MFMA gap and this k-step's LDS-DMA pieces
+    // spaced evenly between them (SPREAD 1: a tile's pieces are shared out over the k-steps; SPREAD 2: all of them go
+    // out during k-step 0, so the last one has most of a stage period to land) | MFMAs of the last k-step.
     {
-      constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma, PAIR = RD < MM ? RD : MM;
+      constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma;
       __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+      if (SPREAD == 0) __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        if (s < KS - 1) {
+        const int first = SPREAD == 2 ? 0 : (s * LPT + KS - 1) / KS;                       // pieces [first, last) go out in k-step s
+        const int last = SPREAD == 2 ? (s == 0 ? LPT : 0) : ((s + 1) * LPT + KS - 1) / KS;
+        const int ps = SPREAD ? last - first : 0;
 #pragma unroll
-          for (int q = 0; q < PAIR; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          }
-          if (RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);      // up to LPT DMA pieces that belong here
-          if (MM > RD) __builtin_amdgcn_sched_group_barrier(0x008, MM - RD, 0);
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
+        for (int q = 0; q < MM; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (s < KS - 1 && q < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (((q + 1) * ps) / MM > (q * ps) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
+        if (s < KS - 1 && RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+          if (x < ps - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     }
     RON_STAGE_END();
@@ -444,20 +447,24 @@ constexpr TileCfg kCfgs[] = {
     {128, 64, 2, 2, 4, 1, 64},    // 24: 5 likewise
     {256, 256, 4, 2, 4, 1, 64},   // 25: diagnostic, 20 without LDS reads / MFMA (staging stream alone)
     {128, 128, 2, 2, 4, 0, 64},   // 26: 23 with the pieces issued up front
-    {256, 256, 4, 2, 2, 1},       // 27: diagnostic, 11 with s_memtime stamps (ConvLaunch.dbg)
-    {128, 128, 2, 2, 2, 1},       // 28: diagnostic, 4 with stamps
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 27: diagnostic, 30 with s_memtime stamps (ConvLaunch.dbg)
+    {128, 128, 2, 2, 2, 1, 128, 16},   // 28: diagnostic, 33 with stamps
     {256, 128, 4, 2, 3, 1},       // 29: diagnostic, 6 with stamps
     {256, 256, 4, 2, 2, 1, 128, 16},   // 30: 11 on 16x16x32 MFMAs
     {256, 256, 2, 4, 2, 1, 128, 16},   // 31: 10 likewise
     {256, 128, 4, 2, 3, 1, 128, 16},   // 32: 6 likewise
     {128, 128, 2, 2, 2, 1, 128, 16},   // 33: 4 likewise
     {128, 64, 2, 2, 2, 1, 128, 16},    // 34: 5 likewise
+    {256, 256, 4, 2, 2, 2, 128, 16},   // 35: 30 with all LDS-DMA pieces of a tile issued during k-step 0
+    {128, 128, 2, 2, 2, 2, 128, 16},   // 36: 33 likewise
+    {128, 64, 2, 2, 2, 2, 128, 16},    // 37: 34 likewise
+    {256, 256, 2, 4, 2, 2, 128, 16},   // 38: 31 likewise
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 // workgroups of configuration i the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
 inline int cfg_slots(int i) { return kCfgs[i].stages * (kCfgs[i].bm + kCfgs[i].bn) * kCfgs[i].rb <= 80 * 1024 ? 512 : 256; }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, bool SPREAD, int ABL = 0, int RB = 128>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int ABL = 0, int RB = 128>
 int launch_t(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)S * (BM + BN) * RB + 2 * BM * sizeof(int);
   static bool attr_set = false;
@@ -501,14 +508,18 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 24: return launch_t<Tr, 128, 64, 2, 2, 4, true, 0, 64>(a, s);
     case 25: return launch_t<Tr, 256, 256, 4, 2, 4, true, 2, 64>(a, s);
     case 26: return launch_t<Tr, 128, 128, 2, 2, 4, false, 0, 64>(a, s);
-    case 27: return launch_t<Tr, 256, 256, 4, 2, 2, true, 5>(a, s);
-    case 28: return launch_t<Tr, 128, 128, 2, 2, 2, true, 5>(a, s);
+    case 27: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, true, 5>(a, s);
+    case 28: return launch_t<typename SmallShape<Tr>::type, 128, 128, 2, 2, 2, true, 5>(a, s);
     case 29: return launch_t<Tr, 256, 128, 4, 2, 3, true, 5>(a, s);
     case 30: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, true>(a, s);
     case 31: return launch_t<typename SmallShape<Tr>::type, 256, 256, 2, 4, 2, true>(a, s);
     case 32: return launch_t<typename SmallShape<Tr>::type, 256, 128, 4, 2, 3, true>(a, s);
     case 33: return launch_t<typename SmallShape<Tr>::type, 128, 128, 2, 2, 2, true>(a, s);
     case 34: return launch_t<typename SmallShape<Tr>::type, 128, 64, 2, 2, 2, true>(a, s);
+    case 35: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 2>(a, s);
+    case 36: return launch_t<typename SmallShape<Tr>::type, 128, 128, 2, 2, 2, 2>(a, s);
+    case 37: return launch_t<typename SmallShape<Tr>::type, 128, 64, 2, 2, 2, 2>(a, s);
+    case 38: return launch_t<typename SmallShape<Tr>::type, 256, 256, 2, 4, 2, 2>(a, s);
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;
@@ -547,9 +558,10 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
 int conv_pick_cfg(int M, int Npad, int K) {
   (void)K;
   const int tm256 = (M + 255) / 256;
-  if (Npad % 128 != 0) return 34;                                   // N tile 64
+  if (Npad % 128 != 0) return 37;                                   // N tile 64
   if (Npad % 256 == 0 && tm256 * (Npad / 256) >= 160) return 30;
-  return 33;
+  // many rounds of small tiles (conv2_x): issuing a tile's LDS-DMA pieces early in the stage wins a few per cent
+  return ((M + 127) / 128) * (Npad / 128) >= 2048 ? 36 : 33;
 }
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {

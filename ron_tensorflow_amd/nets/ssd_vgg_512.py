@@ -107,7 +107,7 @@ class SSDNet(RONNet):
                                    select_threshold=select_threshold, nms_threshold=nms_threshold, clipping_bbox=None,
                                    top_k=top_k, keep_top_k=keep_top_k, nms_mode=nms_mode, min_size=None)
 
-    def detect(self, inputs, select_threshold=0.01, nms_threshold=0.45, top_k=400, bbox_img=(0., 0., 1., 1.)):
+    def detect(self, inputs, select_threshold=0.01, nms_threshold=0.45, top_k=400, bbox_img=(0., 0., 1., 1.), out=None):
         """forward + np_methods post-processing (no objectness gate for SSD)."""
         return RONNet.detect(self, inputs, objectness_thres=0.0, select_threshold=select_threshold,
-                             nms_threshold=nms_threshold, top_k=top_k, bbox_img=bbox_img)
+                             nms_threshold=nms_threshold, top_k=top_k, bbox_img=bbox_img, out=out)
