@@ -35,7 +35,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // RB = bytes of one LDS row = K extent of one stage (128: 64 bf16; 64: 32 bf16).  The shorter row halves the stage, so
 // the same LDS holds twice the stages and the LDS-DMA of a tile gets S-1 compute periods of lead instead of one:
 // bytes in flight per CU, not L2 bandwidth, is what bounds the staging stream ("bytes in flight").
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int ABL = 0, int RB = 128>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int ABL = 0, int RB = 128, int ROT = 0>
 __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
   constexpr int kRowBytes = RB;                      // shadows the 128-byte default of conv_device.h
   constexpr int kLanesPerRow = RB / 16;              // 16-byte chunks per row
@@ -145,9 +145,9 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
     /* past the last tile: zero-record descriptors, the DMA moves nothing but keeps the vmcnt bookkeeping uniform */  \
     const bool live_ = ABL != 4 && (kt_) < kt1;                                                                               \
     const __amdgpu_buffer_rsrc_t rs_a =                                                                              \
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, live_ ? p.in_bytes : 0u, 0x00020000);          \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (live_ && ABL != 6) ? p.in_bytes : 0u, 0x00020000); \
     const __amdgpu_buffer_rsrc_t rs_b =                                                                              \
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, live_ ? p.wgt_bytes : 0u, 0x00020000);        \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (live_ && ABL != 7) ? p.wgt_bytes : 0u, 0x00020000); \
     const int a_soff = ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz;                         \
     const int b_soff = (kt_) * kRowBytes;                                                                            \
     char* dst = smem + (((kt_) - kt0) % S) * kStage + wave * 1024;
@@ -205,6 +205,81 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
         __builtin_amdgcn_sched_barrier(0);                                                 \
       }                                                                                    \
     } while (0)
+  if (ROT) {
+    // Rotated K loop: the wait + barrier of tile kt+1 sit in front of the LAST k-step of tile kt, whose fragments are
+    // already in registers.  After the barrier the MFMAs of that k-step restart at once, and in their shadow go (a) the
+    // first fragment reads of tile kt+1 (the un-rotated loop pays them as an LDS burst with idle matrix cores at the top
+    // of every tile) and (b) the LDS-DMA of tile kt+S into the stage tile kt just vacated.  All S stages hold tiles.
+    {
+      RON_STAGE_BEGIN(kt0 + S - 1)
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) RON_STAGE_PIECE(i);
+      RON_STAGE_END();
+    }
+    wait_vmcnt<(S - 1) * LPT>();
+    __builtin_amdgcn_s_barrier();
+    u32x4 fa[2][MR], fb[2][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) fa[0][i] = *reinterpret_cast<const u32x4*>(smem + a_base + i * MT * kRowBytes + rd_off[0]);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(smem + b_base + j * MT * kRowBytes + rd_off[0]);
+    constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const char* sbuf = smem + ((kt - kt0) % S) * kStage;
+      const char* snext = smem + ((kt + 1 - kt0) % S) * kStage;
+#pragma unroll
+      for (int s = 0; s < KS - 1; ++s) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * MT * kRowBytes + rd_off[s + 1]);
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * MT * kRowBytes + rd_off[s + 1]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) Tr::mma(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
+      }
+#pragma unroll
+      for (int s = 0; s < KS - 1; ++s) {
+#pragma unroll
+        for (int q = 0; q < MM; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (q < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+      }
+      RON_STAMP(t_a);
+      wait_vmcnt<(S - 2) * LPT>();          // tile kt+1 has landed; this wave's reads of tile kt are in registers
+      RON_STAMP(t_b);
+      __builtin_amdgcn_s_barrier();
+      RON_STAMP(t_c);
+      RON_STAGE_BEGIN(kt + S)
+#pragma unroll
+      for (int i = 0; i < MR; ++i) fa[KS & 1][i] = *reinterpret_cast<const u32x4*>(snext + a_base + i * MT * kRowBytes + rd_off[0]);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) fb[KS & 1][j] = *reinterpret_cast<const u32x4*>(snext + b_base + j * MT * kRowBytes + rd_off[0]);
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) RON_STAGE_PIECE(i);
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) Tr::mma(fa[(KS - 1) & 1][i], fb[(KS - 1) & 1][j], acc[i][j]);
+#pragma unroll
+      for (int q = 0; q < MM; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (q < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (((q + 1) * LPT) / MM > (q * LPT) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      if (RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+#pragma unroll
+      for (int x = 0; x < 16; ++x)
+        if (x < LPT - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      RON_STAGE_END();
+      RON_STAMP(t_d);
+      if (ABL == 5) { t_wait += t_b - t_a; t_bar += t_c - t_b; t_comp += t_d - t_c; }
+    }
+  } else
   for (int kt = kt0; kt < kt1; ++kt) {
     RON_STAMP(t_a);
     if (ABL != 3) {
@@ -459,21 +534,33 @@ constexpr TileCfg kCfgs[] = {
     {128, 128, 2, 2, 2, 2, 128, 16},   // 36: 33 likewise
     {128, 64, 2, 2, 2, 2, 128, 16},    // 37: 34 likewise
     {256, 256, 2, 4, 2, 2, 128, 16},   // 38: 31 likewise
+    {256, 256, 4, 2, 2, 2, 128, 16},   // 39: 35 with the rotated K loop
+    {128, 128, 2, 2, 2, 2, 128, 16},   // 40: 36 likewise
+    {128, 64, 2, 2, 2, 2, 128, 16},    // 41: 37 likewise
+    {256, 256, 2, 4, 2, 2, 128, 16},   // 42: 38 likewise
+    {256, 256, 4, 2, 2, 2, 128, 32},   // 43: rotated loop on 32x32x16 MFMAs (four k-steps per stage)
+    {256, 256, 4, 2, 2, 2, 128, 16},   // 44: diagnostic, 39 with stamps
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 45: diagnostic, 30 without LDS-DMA
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 46: diagnostic, 30 without LDS-DMA, waits and barriers
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 47: diagnostic, 30 without LDS reads / MFMA
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 48: diagnostic, 30 with zero-record descriptors
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 49: diagnostic, 30 with a zero-record A descriptor (only the weights move)
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 50: diagnostic, 30 with a zero-record B descriptor (only the activations move)
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 // workgroups of configuration i the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
 inline int cfg_slots(int i) { return kCfgs[i].stages * (kCfgs[i].bm + kCfgs[i].bn) * kCfgs[i].rb <= 80 * 1024 ? 512 : 256; }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int ABL = 0, int RB = 128>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int ABL = 0, int RB = 128, int ROT = 0>
 int launch_t(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)S * (BM + BN) * RB + 2 * BM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB>),
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB, ROT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB, ROT>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -520,6 +607,18 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 36: return launch_t<typename SmallShape<Tr>::type, 128, 128, 2, 2, 2, 2>(a, s);
     case 37: return launch_t<typename SmallShape<Tr>::type, 128, 64, 2, 2, 2, 2>(a, s);
     case 38: return launch_t<typename SmallShape<Tr>::type, 256, 256, 2, 4, 2, 2>(a, s);
+    case 39: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 2, 0, 128, 1>(a, s);
+    case 40: return launch_t<typename SmallShape<Tr>::type, 128, 128, 2, 2, 2, 2, 0, 128, 1>(a, s);
+    case 41: return launch_t<typename SmallShape<Tr>::type, 128, 64, 2, 2, 2, 2, 0, 128, 1>(a, s);
+    case 42: return launch_t<typename SmallShape<Tr>::type, 256, 256, 2, 4, 2, 2, 0, 128, 1>(a, s);
+    case 43: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0, 128, 1>(a, s);
+    case 44: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 2, 5, 128, 1>(a, s);
+    case 45: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 1>(a, s);
+    case 46: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 3>(a, s);
+    case 47: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 2>(a, s);
+    case 48: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 4>(a, s);
+    case 49: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 6>(a, s);
+    case 50: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 7>(a, s);
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;
@@ -565,7 +664,7 @@ int conv_pick_cfg(int M, int Npad, int K) {
 }
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
-  if (c.cfg == kCfgPatch) return launch_conv_patch(c, stream);
+  if (c.cfg == kCfgPatch || c.cfg == kCfgPatch + 1) return launch_conv_patch(c, stream);
   const int esz = (int)dtype_size(c.dtype);
   int chunk = conv_k_chunk(c.dtype);
   RON_REQUIRE(c.in.C % chunk == 0, "conv: Cin %d is not a multiple of the K chunk %d", c.in.C, chunk);
@@ -627,7 +726,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
 }
 
 int64_t conv_scratch_bytes(int M, int Npad, int K, int dtype, int cfg, int splitk) {
-  if (cfg == kCfgPatch) return 0;                       // the halo-patch kernel never splits K
+  if (cfg == kCfgPatch || cfg == kCfgPatch + 1) return 0;                       // the halo-patch kernel never splits K
   const int KT = K / conv_k_chunk(dtype);
   const int c = cfg >= 0 ? cfg : conv_pick_cfg(M, Npad, K);
   const int tiles = ((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * (Npad / kCfgs[c].bn);

@@ -1,26 +1,25 @@
 // 3x3 / stride-1 / pad-1 convolution with an LDS-staged input halo patch (gfx950).
 //
-// The generic kernel (conv_mfma.hip) re-stages the A operand for every filter tap: the same input pixels travel
-// L2 -> LDS nine times, which is what bounds the 3x3 layers (PMC: 3.2x the algorithmic HBM bytes; ablation: the DMA
-// stream alone costs 60 % of the kernel).  Here a workgroup owns a TH x TW spatial tile of one image (256 GEMM rows) and
-// BN output channels.  Per 128-byte channel chunk it stages the (TH+2) x (TW+2) input patch ONCE (LDS-DMA, double
-// buffered across chunks, its pieces issued one per tap step so they ride in the MFMA shadow), then runs the 9 taps
-// against it: the A fragment of tile row r for tap (ky,kx) is patch row pp(r) + ky*(TW+2) + kx, an LDS address shift.
-// Only the weights (BN x 128 B per step) are staged per tap.  L2->LDS bytes per MFLOP drop from 11.4 (256x128 tile of the
-// generic kernel) / 7.6 (256x256) to ~5.2.
+// The generic kernel (conv_mfma.hip) re-stages the A operand for every filter tap, so the same input pixels travel
+// L2 -> LDS nine times.  Under MFMA load the chip holds ~1.4-1.6 GHz and the staging stream, which runs on that clock,
+// becomes the bound (ablation, b4_trio 256x256 tile: nothing staged 636 us; only the weights staged 699 us; only the
+// activations 692 us; both 854 us).  Here a workgroup owns a TH x TW spatial tile of one image (<= 256 GEMM rows) and BN
+// output channels.  Per 128-byte channel chunk it stages the (TH+2) x (TW+2) input patch ONCE (LDS-DMA, double buffered
+// across chunks, one piece per tap step) and runs the 9 taps against it: the A fragment of tile row r for tap (ky,kx) is
+// patch row pp(r) + ky*(TW+2) + kx, an LDS address shift.  Only the weights (BN x 128 B per step) are staged per tap:
+// L2 -> LDS bytes per MFLOP drop from 7.6 (256x256 tile of the generic kernel) to 4.4 at BN = 256.
 //
 // Patch rows are 128 B; the 16-B chunk c of patch row i sits in slot c ^ ((i>>1)&7) (applied on the DMA source address
 // and on the read side, as in the generic kernel; a tap shift changes i, so the key is recomputed per tap).
-// Everything after the K loop (vector epilogue with bias / ReLU / residual / fused 2x2 max-pool / fp32 heads) is the
-// generic kernel's, as is the B-row permutation that makes it coalesced.
+// MFMA shape (Tr::kMT), fragment double buffering, pinned issue order and everything after the K loop (vector epilogue with
+// bias / ReLU / residual / fused 2x2 max-pool / fp32 heads, the B-row permutation behind it) are the generic kernel's.
 #include "conv_device.h"
 
 namespace ron {
 namespace detail {
 
-constexpr int kPatchPieces = 6;                  // LDS-DMA pieces per thread and chunk (512 threads x 16 B)
-constexpr int kPatchRows = kPatchPieces * 64;    // 384 patch rows of 128 B
-constexpr int kPatchBStages = 3;                 // weight stages: two steps of lead for the per-tap weight tiles
+constexpr int kPatchPieces = 6;                  // LDS-DMA pieces per thread and chunk (512 threads x 16 B = 64 rows each)
+constexpr int kPatchRows = 344;                  // rows a patch buffer holds (43 KB): 8 x 42, 10 x 34, 14 x 22 patches fit
 
 struct PatchArgs {
   ConvArgs c;
@@ -30,18 +29,21 @@ struct PatchArgs {
   int chunks;                 // Cin / chunk elements
 };
 
-template <class Tr, int BN, int WN>
+// SB weight stages: SB-1 steps of lead for the per-tap weight tiles.
+template <class Tr, int BN, int WN, int SB>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
-  constexpr int SB = kPatchBStages;
   const ConvArgs& p = pa.c;
   constexpr int BM = 256, WM = 8 / WN, kThreads = 512;
+  constexpr int MT = Tr::kMT, kGroups = 64 / MT, KS = 8 / kGroups, EPA = MT * MT / 64;
   constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int MR = TM / 32, NR = TN / 32;
+  constexpr int MR = TM / MT, NR = TN / MT;
   constexpr int B_IT = BN / 64;                   // B pieces per thread and step
+  constexpr int G = B_IT + 1;                     // LDS-DMA instructions per thread and step (one patch piece + the weights)
   constexpr int kPatchBytes = kPatchRows * kRowBytes;
   constexpr int kBBytes = BN * kRowBytes;
+  static_assert(TM % MT == 0 && TN % MT == 0 && NR <= 8 && SB >= 2, "bad wave tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // layout: [patch 0][patch 1][B stage 0 .. SB-1][pp: BM ints][out_off: BM ints]
+  // layout: [patch 0][patch 1][B stage 0 .. SB-1][pp: BM ints][out_off: BM ints][sink 1 KB]
   char* s_b = smem + 2 * kPatchBytes;
   int* s_pp = reinterpret_cast<int*>(s_b + SB * kBBytes);
   int* s_out_off = s_pp + BM;
@@ -94,88 +96,70 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
     p_voff[k] = (int)((((unsigned)(img * p.in_Hp + gy) * p.in_Wp + gx) * p.in_cstride + p.in_coff) * Tr::kEsz) +
                 ((slot ^ ((i >> 1) & 7)) << 4);
   }
-  // B pieces: LDS row (j*32 + r) of a wave's TN-wide group <- weight row (r*NR + j)   (coalesced epilogue, see conv_mfma.hip)
+  // B pieces: LDS row (j*MT + r) of a wave's TN-wide group <- weight row (r*NR + j)   (coalesced epilogue, see conv_mfma.hip)
   int b_voff[4];
+  static_assert(B_IT <= 4, "BN <= 256");
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
     const int lrow = it * 64 + (tid >> 3);
     const int grp = lrow / TN, loc = lrow % TN;
-    const int nrow = grp * TN + (loc & 31) * NR + (loc >> 5);
+    const int nrow = grp * TN + (loc % MT) * NR + (loc / MT);
     b_voff[it] = (n0 + nrow) * p.K * Tr::kEsz + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
   }
   __syncthreads();
 
-  const int fr = lane & 31, fh = lane >> 5;
+  const int fr = lane & (MT - 1), fh = lane / MT;
   int pp[MR];
 #pragma unroll
-  for (int i = 0; i < MR; ++i) pp[i] = s_pp[wm * TM + i * 32 + fr];
-  int rd_off_b[4];
+  for (int i = 0; i < MR; ++i) pp[i] = s_pp[wm * TM + i * MT + fr];
+  int rd_off_b[KS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) rd_off_b[s] = fr * kRowBytes + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+  for (int s = 0; s < KS; ++s) rd_off_b[s] = fr * kRowBytes + (((kGroups * s + fh) ^ ((fr >> 1) & 7)) << 4);
   const int b_base = wn * TN * kRowBytes;
 
-  // descriptors are rebuilt at the use site with 0 records for pieces past the end (the DMA then moves nothing)
+  // descriptors are rebuilt at the use site with 0 records for pieces that have nothing to fetch
 #define RS_A(live_) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (live_) ? p.in_bytes : 0u, 0x00020000)
 #define RS_B(live_) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (live_) ? p.wgt_bytes : 0u, 0x00020000)
-
+  // piece k_ (compile time) of the patch of chunk cc_ into buffer buf_; a wave whose 8 rows lie past the buffer sinks it
 #define PATCH_PIECE(k_, buf_, cc_, live_)                                                                            \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(live_),                                                              \
-                                           (lds_void*)(smem + (buf_) * kPatchBytes + ((k_) * kThreads + wave * 64) * 16), 16, \
-                                           p_voff[k_], (cc_) * kRowBytes, 0, 0)
-#define SINK_PIECE()                                                                                                 \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(false), (lds_void*)(s_sink + wave * 1024), 16, p_voff[0], 0, 0, 0)
-#define B_PIECES(stage_, tap_, cc_, live_)                                                                           \
   do {                                                                                                               \
-    const int soff_ = ((tap_) * pa.chunks + (cc_)) * kRowBytes;                                                      \
-    _Pragma("unroll") for (int it = 0; it < B_IT; ++it)                                                              \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_B(live_),                                                        \
-                                                 (lds_void*)(s_b + (stage_) * kBBytes + (it * 64 + wave * 8) * kRowBytes), 16, \
-                                                 b_voff[it], soff_, 0, 0);                                           \
+    const bool in_ = (k_) * 64 + wave * 8 + 8 <= kPatchRows;                                                         \
+    char* d_ = in_ ? smem + (buf_) * kPatchBytes + ((k_) * kThreads + wave * 64) * 16 : s_sink;                      \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A((live_) && in_), (lds_void*)d_, 16, p_voff[k_], (cc_) * kRowBytes, 0, 0); \
   } while (0)
+#define B_PIECE(it_, stage_, soff_, live_)                                                                           \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_B(live_), (lds_void*)(s_b + (stage_) * kBBytes + ((it_) * 64 + wave * 8) * kRowBytes), \
+                                           16, b_voff[it_], soff_, 0, 0)
 
-  f32x16 acc[MR][NR];
+  typename Tr::acc_t acc[MR][NR];
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < NR; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < EPA; ++e) acc[i][j][e] = 0.f;
 
-  // Every step issues one group of 1 + B_IT LDS-DMA instructions: one piece of the NEXT chunk's patch (a zero-record
-  // descriptor when there is none to fetch) and the weights of step + SB - 1.  The prologue is shaped the same way, so one
-  // counted vmcnt serves every step: all but the newest (SB-2) groups have landed = the weights of this step, and - at a
-  // chunk boundary - the patch whose last piece went out three steps earlier.
+  // Every step issues one group of G = 1 + B_IT LDS-DMA instructions: one piece of the NEXT chunk's patch (a placeholder
+  // into the sink when there is none to fetch) and the weights of step + SB - 1.  The prologue is shaped the same way, so
+  // one counted vmcnt serves every step: all but the newest (SB-2) groups have landed = the weights of this step, and - at
+  // a chunk boundary - the patch whose last piece went out three steps earlier.
   const int n_steps = pa.chunks * 9;
 #pragma unroll
   for (int k = 0; k < kPatchPieces; ++k) PATCH_PIECE(k, 0, 0, true);
-  B_PIECES(0, 0, 0, true);
 #pragma unroll
-  for (int t = 1; t < SB - 1; ++t) {
-    SINK_PIECE();
-    B_PIECES(t, t % 9, t / 9, t < n_steps);
+  for (int t = 0; t < SB - 1; ++t) {
+    if (t > 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(false), (lds_void*)s_sink, 16, p_voff[0], 0, 0, 0);
+    const int soff = ((t % 9) * pa.chunks + t / 9) * kRowBytes;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) B_PIECE(it, t, soff, t < n_steps);
   }
 
   int tap = 0, cc = 0, ky = 0, kx = 0;
   int ntap = (SB - 1) % 9, ncc = (SB - 1) / 9;      // tap / chunk of step + SB - 1
   int st_rd = 0, st_wr = SB - 1;
   for (int step = 0; step < n_steps; ++step) {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((SB - 2) * (B_IT + 1)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((SB - 2) * G) : "memory");
     __builtin_amdgcn_s_barrier();
-    {
-      const bool more = cc + 1 < pa.chunks;
-      switch (tap) {
-        case 0: PATCH_PIECE(0, (cc + 1) & 1, cc + 1, more); break;
-        case 1: PATCH_PIECE(1, (cc + 1) & 1, cc + 1, more); break;
-        case 2: PATCH_PIECE(2, (cc + 1) & 1, cc + 1, more); break;
-        case 3: PATCH_PIECE(3, (cc + 1) & 1, cc + 1, more); break;
-        case 4: PATCH_PIECE(4, (cc + 1) & 1, cc + 1, more); break;
-        case 5: PATCH_PIECE(5, (cc + 1) & 1, cc + 1, more); break;
-        default: SINK_PIECE(); break;
-      }
-      B_PIECES(st_wr, ntap, ncc, step + SB - 1 < n_steps);
-      if (++ntap == 9) { ntap = 0; ++ncc; }
-      if (++st_wr == SB) st_wr = 0;
-    }
     const char* sa = smem + (cc & 1) * kPatchBytes;
     const char* sb = s_b + st_rd * kBBytes + b_base;
     if (++st_rd == SB) st_rd = 0;
@@ -187,52 +171,67 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
       a_row[i] = row * kRowBytes;
       a_key[i] = (row >> 1) & 7;
     }
-    // fragments of k-step s+1 are read while the MFMAs of k-step s run (two register sets), issue order pinned as in
-    // conv_mfma.hip: hipcc otherwise reads, waits and multiplies k-step by k-step
     u32x4 fa[2][MR], fb[2][NR];
 #pragma unroll
     for (int i = 0; i < MR; ++i) fa[0][i] = *reinterpret_cast<const u32x4*>(sa + a_row[i] + ((fh ^ a_key[i]) << 4));
 #pragma unroll
-    for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * kRowBytes + rd_off_b[0]);
+    for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(sb + j * MT * kRowBytes + rd_off_b[0]);
+    // this step's LDS-DMA group (branch free: the patch piece index is the tap, selected with v_cndmask)
+    {
+      const bool more = cc + 1 < pa.chunks && tap < kPatchPieces;
+      int voff = p_voff[0];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < 3) {
+      for (int k = 1; k < kPatchPieces; ++k) voff = tap == k ? p_voff[k] : voff;
+      const bool in_ = tap * 64 + wave * 8 + 8 <= kPatchRows;
+      char* d_ = (more && in_) ? smem + ((cc + 1) & 1) * kPatchBytes + (tap * kThreads + wave * 64) * 16 : s_sink;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(more && in_), (lds_void*)d_, 16, voff, (cc + 1) * kRowBytes, 0, 0);
+      const int soff = (ntap * pa.chunks + ncc) * kRowBytes;
+      const bool live = step + SB - 1 < n_steps;
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it) B_PIECE(it, st_wr, soff, live);
+      if (++ntap == 9) { ntap = 0; ++ncc; }
+      if (++st_wr == SB) st_wr = 0;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s < KS - 1) {
 #pragma unroll
         for (int i = 0; i < MR; ++i)
-          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sa + a_row[i] + (((2 * (s + 1) + fh) ^ a_key[i]) << 4));
+          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sa + a_row[i] + (((kGroups * (s + 1) + fh) ^ a_key[i]) << 4));
 #pragma unroll
         for (int j = 0; j < NR; ++j)
-          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * kRowBytes + rd_off_b[(s + 1) & 3]);
+          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sb + j * MT * kRowBytes + rd_off_b[s + 1]);
       }
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < NR; ++j) Tr::mma(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
     }
+    // issue order: first fragments | k-step 0: MFMAs with the next reads and the G DMA instructions spaced between them |
+    // ... | MFMAs of the last k-step
     {
-      constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma, PAIR = RD < MM ? RD : MM;
+      constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma;
       __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (s < 3) {
+      for (int s = 0; s < KS; ++s) {
+        const int ps = s == 0 ? G : 0;
 #pragma unroll
-          for (int q = 0; q < PAIR; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          }
-          if (RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
-          if (MM > RD) __builtin_amdgcn_sched_group_barrier(0x008, MM - RD, 0);
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
+        for (int q = 0; q < MM; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (s < KS - 1 && q < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (((q + 1) * ps) / MM > (q * ps) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
+        if (s < KS - 1 && RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+          if (x < ps - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     }
     if (++tap == 9) { tap = 0; ++cc; ky = 0; kx = 0; }
     else if (++kx == 3) { kx = 0; ++ky; }
   }
 #undef PATCH_PIECE
-#undef SINK_PIECE
-#undef B_PIECES
+#undef B_PIECE
 #undef RS_A
 #undef RS_B
 
@@ -248,8 +247,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int ooff = s_out_off[wm * TM + i * 32 + 8 * t + 4 * fh];
+      for (int t = 0; t < EPA / 4; ++t) {
+        const int ooff = s_out_off[wm * TM + i * MT + 8 * t + 4 * fh];
         if (ooff < 0) continue;
         float v[NR];
 #pragma unroll
@@ -271,8 +270,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int rt = wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+    for (int e = 0; e < EPA; ++e) {
+      const int rt = wm * TM + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh;
       const int ooff = s_out_off[rt];
       if (ooff < 0) continue;
       const int o = ooff + ncol0;
@@ -305,16 +304,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
   }
 }
 
-template <class Tr, int BN, int WN>
+template <class Tr, int BN, int WN, int SB>
 int launch_patch_t(const PatchArgs& a, int grid, hipStream_t s) {
-  const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + kPatchBStages * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 8192;
+  const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN>),
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN, SB>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_patch_kernel<Tr, BN, WN>), dim3(grid), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_patch_kernel<Tr, BN, WN, SB>), dim3(grid), dim3(512), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -322,13 +321,13 @@ int launch_patch_t(const PatchArgs& a, int grid, hipStream_t s) {
 }  // namespace detail
 using namespace detail;
 
-// Spatial tile for an H x W map: TW | 64 wide strips where the map is wide, the whole row where it is narrow.
+// Spatial tile for an H x W map: <= 256 pixels, patch (TH+2) x (TW+2) <= kPatchRows rows.
 static bool pick_tile(int H, int W, bool pool, int* TH, int* TW) {
   (void)H;
   int tw;
-  if (W % 32 == 0) tw = 32;
-  else if (W <= 64 && W >= 40) tw = W;           // 40-wide maps: six full rows per tile
-  else if (W % 40 == 0) tw = 40;
+  if (W % 32 == 0) tw = 32;                      // 160 / 320-wide maps: 32 x 8
+  else if (W % 40 == 0) tw = 40;                 // 40 / 80-wide maps: six rows of 40 (240 of 256 tile rows in use)
+  else if (W == 20) tw = 20;                     // 20 x 12
   else return false;
   int th = 256 / tw;
   if (pool) { if (tw % 2) return false; th &= ~1; }
@@ -340,7 +339,7 @@ static bool pick_tile(int H, int W, bool pool, int* TH, int* TW) {
 bool conv_patch_applicable(const ConvLaunch& c) {
   int th, tw;
   return c.kh == 3 && c.kw == 3 && c.stride == 1 && c.dil == 1 && c.cpad == 1 && c.up == 0 && c.in.H == c.Ho && c.in.W == c.Wo &&
-         c.in.W >= 40 && c.in.pad >= 1 && c.Npad % 64 == 0 && pick_tile(c.in.H, c.in.W, c.pool != 0, &th, &tw);
+         c.in.pad >= 1 && c.Npad % 64 == 0 && pick_tile(c.in.H, c.in.W, c.pool != 0, &th, &tw);
 }
 
 int launch_conv_patch(const ConvLaunch& c, hipStream_t stream) {
@@ -364,13 +363,19 @@ int launch_conv_patch(const ConvLaunch& c, hipStream_t stream) {
   a.PW = a.TW + 2; a.R = (a.TH + 2) * a.PW;
   a.tiles_x = (c.in.W + a.TW - 1) / a.TW; a.tiles_y = (c.in.H + a.TH - 1) / a.TH;
   a.H = c.in.H; a.W = c.in.W; a.chunks = c.in.C / chunk;
-  const int BN = c.Npad % 128 == 0 ? 128 : 64;
+  const int BN = c.Npad % 256 == 0 ? 256 : (c.Npad % 128 == 0 ? 128 : 64);
   g.tiles_n = c.Npad / BN;
   const int grid = c.in.N * a.tiles_y * a.tiles_x * g.tiles_n;
-#define RON_PATCH_DISPATCH(Tr)                                                        \
-  return BN == 128 ? launch_patch_t<Tr, 128, 2>(a, grid, stream) : launch_patch_t<Tr, 64, 2>(a, grid, stream)
-  if (c.dtype == RON_DTYPE_BF16) { RON_PATCH_DISPATCH(TraitsBF16); }
-  if (c.dtype == RON_DTYPE_F16) { RON_PATCH_DISPATCH(TraitsF16); }
+#define RON_PATCH_DISPATCH(Tr)                                                                   \
+  do {                                                                                           \
+    typedef typename SmallShape<Tr>::type TS;                                                    \
+    if (BN == 256 && c.cfg == kCfgPatch + 1) return launch_patch_t<Tr, 256, 2, 2>(a, grid, stream); \
+    if (BN == 256) return launch_patch_t<TS, 256, 2, 2>(a, grid, stream);                        \
+    if (BN == 128) return launch_patch_t<TS, 128, 2, 3>(a, grid, stream);                        \
+    return launch_patch_t<TS, 64, 2, 3>(a, grid, stream);                                        \
+  } while (0)
+  if (c.dtype == RON_DTYPE_BF16) RON_PATCH_DISPATCH(TraitsBF16);
+  if (c.dtype == RON_DTYPE_F16) RON_PATCH_DISPATCH(TraitsF16);
   RON_PATCH_DISPATCH(TraitsF32);
 #undef RON_PATCH_DISPATCH
 }

@@ -190,7 +190,7 @@ extern "C" int ron_conv2d_bench(const ron_conv_desc* d, int warmup, int iters, f
   float ms = 0.f;
   RON_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   *ms_per_launch = ms / iters;
-  if (d->tile_cfg >= 27 && d->tile_cfg <= 29) {
+  if ((d->tile_cfg >= 27 && d->tile_cfg <= 29) || d->tile_cfg == 44) {
     // stamp build: one more launch with a debug buffer, shares of the K step to stderr
     const size_t waves = (size_t)1 << 20;
     unsigned long long* dbg = nullptr;
