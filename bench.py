@@ -110,7 +110,10 @@ def main():
                          '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...' % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # under torch.distributed.run the process group (RCCL) exists even for one rank, so that `--nproc-per-node 1` exercises
+    # the same gather path as N > 1
+    use_dist = world > 1 or 'RANK' in os.environ
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
@@ -136,7 +139,7 @@ def main():
 
     from ron_tensorflow_amd import parallel
     gathered = None
-    if world > 1:
+    if use_dist:
         gathered = torch.empty((world, args.batch, top_k + 1, parallel.RECORD_WIDTH), dtype=torch.float32, device=dev)
 
     # One step = one batch through ron_detect.  `--in-flight F` batches are kept in flight on F execution slots (shared
@@ -150,10 +153,16 @@ def main():
 
     last = [None]
 
+    io_stream = torch.cuda.Stream(device=dev)      # the consumer (record packing + RCCL gather) has its own stream
+
     def consume(ticket):
-        det = last[0] = ticket.wait()              # the current stream waits for that slot; the host does not
-        if world > 1:
-            rec = parallel.pack_records(det.classes, det.scores, det.bboxes, det.anchor_index, det.count)
+        if not use_dist:
+            last[0] = ticket.wait()                # the current stream waits for that slot; the host does not
+            return last[0]
+        with torch.cuda.stream(io_stream):
+            det = last[0] = ticket.wait()
+            rec = parallel.pack_detections(det)
+            ticket.release()                       # the slot may overwrite this output set from here on
             parallel.gather_detections(rec, out=gathered)
         return det
 
@@ -170,7 +179,7 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     lib = _lib.lib()
     contexts = [slot._context() for slot in pipe.slots]
@@ -185,13 +194,13 @@ def main():
         step()
     det = drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     for ctx in contexts:
         _lib.check(lib.ron_profile_enable(ctx, 0))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -282,7 +291,7 @@ def main():
                     tf = r['gflop_per_image'] * args.batch / (us * 1e-6) / 1e3 if us > 0 else 0
                     f.write('%-28s %9.3f %10.1f %9.1f %9.2f\n' % (r['name'], r['gflop_per_image'], us, tf, 100 * r['total_ms'] / tot))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -159,6 +159,11 @@ int ron_bboxes_decode_layer(const float* loc, int n, int feat_h, int feat_w, int
  * With pick >= 0 only channel `pick` is written: y [rows, 1] (objness_pred, :576). */
 int ron_softmax_last(const float* x, int64_t rows, int c, int pick, float* y, void* stream);
 
+/* Detection records for the multi-GPU exchange: one float32 tensor [n, capacity + 1, 7] per rank, rows
+ * 0..capacity-1 = (class, score, ymin, xmin, ymax, xmax, anchor_index), zero padded past `count`; row `capacity` = the
+ * count replicated.  The only thing that crosses xGMI: one RCCL all-gather of these. */
+int ron_pack_records(const ron_detections* det, int n, float* records, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * TF evaluation variant of the post-processing (what eval_ron_network.py:226-236 runs):
  *   tf_ssd_bboxes_select (ssd_common.py:504-589) -> tfe.bboxes_clip (bboxes.py:105-144)

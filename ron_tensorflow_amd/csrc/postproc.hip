@@ -734,6 +734,34 @@ extern "C" int ron_bboxes_decode_layer(const float* loc, int n, int feat_h, int 
   return RON_OK;
 }
 
+namespace {
+__global__ void pack_records_kernel(DetDev d, float* __restrict__ rec) {
+  const int img = blockIdx.x, cap = d.capacity;
+  const int cnt = d.count[img];
+  float* r = rec + (size_t)img * (cap + 1) * 7;
+  for (int i = threadIdx.x; i < (cap + 1) * 7; i += blockDim.x) {
+    const int row = i / 7, col = i - row * 7;
+    float v = 0.f;
+    if (row == cap) v = (float)cnt;
+    else if (row < cnt) {
+      const size_t k = (size_t)img * cap + row;
+      v = col == 0 ? (float)d.classes[k] : col == 1 ? d.scores[k] : col == 6 ? (float)d.anchor_index[k] : d.bboxes[k * 4 + col - 2];
+    }
+    r[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int ron_pack_records(const ron_detections* det, int n, float* records, void* stream) {
+  RON_REQUIRE(det != nullptr && records != nullptr && n > 0, "bad argument");
+  RON_REQUIRE(det->capacity >= 1, "ron_pack_records: empty detection buffers");
+  DetDev d{det->capacity, det->classes, det->scores, det->bboxes, det->anchor_index, det->count};
+  RON_REQUIRE(d.classes && d.scores && d.bboxes && d.anchor_index && d.count, "ron_pack_records: every detection array is needed");
+  hipLaunchKernelGGL(pack_records_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, d, records);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
 extern "C" int ron_softmax_last(const float* x, int64_t rows, int c, int pick, float* y, void* stream) {
   RON_REQUIRE(x && y && rows > 0 && c > 0 && pick < c, "bad argument");
   const int blocks = (int)std::min<int64_t>((rows + 255) / 256, 4096);

@@ -33,6 +33,17 @@ def pack_records(classes, scores, bboxes, anchor_index, count):
     return rec
 
 
+def pack_detections(det, out=None):
+    """DetectionBuffers -> records [N, top_k + 1, 7] in ONE launch (ron_pack_records); same result as pack_records."""
+    import ctypes as C
+    from ._lib import check, current_stream, lib, ptr
+    if out is None:
+        out = torch.empty((det.n, det.capacity + 1, RECORD_WIDTH), dtype=torch.float32, device=det.scores.device)
+    d = det.c_struct()
+    check(lib().ron_pack_records(C.byref(d), det.n, ptr(out), current_stream()))
+    return out
+
+
 def unpack_records(rec):
     """Inverse of pack_records: (classes int32, scores, bboxes, anchor_index int32, count int32)."""
     k = rec.shape[-2] - 1

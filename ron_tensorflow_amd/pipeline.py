@@ -11,48 +11,68 @@ from . import ops
 
 
 class Ticket(object):
-    """One submitted batch: ``wait()`` makes the caller's current stream wait for it, then returns the detections."""
+    """One submitted batch: ``wait()`` makes the caller's current stream wait for it, then returns the detections;
+    ``release()`` (optional) marks, on the current stream, the point after which the detections are no longer read -
+    without it the buffers are simply assumed free by the time they come round again."""
 
-    def __init__(self, detections, done):
-        self.detections, self._done = detections, done
+    def __init__(self, detections, done, consumed):
+        self.detections, self._done, self._consumed = detections, done, consumed
 
     def wait(self):
         torch.cuda.current_stream().wait_event(self._done)
         return self.detections
 
+    def release(self):
+        self._consumed.record(torch.cuda.current_stream())
+
 
 class DetectPipeline(object):
     """Round-robin submission of batches to ``slots`` execution slots of ``net``.
 
-    ``submit(images)`` returns a Ticket; the detections it carries live in the slot's buffers and stay valid until
-    that slot is used again, i.e. for the next ``slots - 1`` submissions."""
+    ``submit(images)`` returns a Ticket; the detections it carries live in one of the slot's ``buffers_per_slot``
+    output sets and stay valid for the next ``slots * buffers_per_slot - 1`` submissions, so a consumer (host copy,
+    RCCL gather) can run on its own stream without holding the slot's next batch back."""
 
-    def __init__(self, net, slots=2, top_k=400):
-        assert slots >= 1
-        self.net, self.top_k = net, top_k
+    def __init__(self, net, slots=2, top_k=400, buffers_per_slot=2):
+        assert slots >= 1 and buffers_per_slot >= 1
+        self.net, self.top_k, self.buffers_per_slot = net, top_k, buffers_per_slot
         self.slots = [net] + [net.clone() for _ in range(slots - 1)]
         with torch.cuda.device(net.device):
             self.streams = [torch.cuda.Stream(device=net.device) for _ in self.slots]
         self.ready = [torch.cuda.Event() for _ in self.slots]
-        self.done = [torch.cuda.Event() for _ in self.slots]
-        self.consumed = [None for _ in self.slots]
-        self.buffers = [None for _ in self.slots]
+        n_sets = len(self.slots) * buffers_per_slot
+        self.buffers = [None] * n_sets
+        self.consumed = [torch.cuda.Event() for _ in range(n_sets)]
+        self._released = [False] * n_sets
         self._next = 0
 
     def submit(self, images, **detect_args):
-        i = self._next
-        self._next = (i + 1) % len(self.slots)
+        b = self._next                                # output set; slot = b % slots
+        self._next = (b + 1) % len(self.buffers)
+        i = b % len(self.slots)
         n = images.shape[0]
-        if self.buffers[i] is None or self.buffers[i].n != n:
-            self.buffers[i] = ops.DetectionBuffers(n, self.top_k, self.net.device)
+        if self.buffers[b] is None or self.buffers[b].n != n:
+            self.buffers[b] = ops.DetectionBuffers(n, self.top_k, self.net.device)
         cur = torch.cuda.current_stream()
-        self.ready[i].record(cur)                     # `images` (and the slot's previous results) are settled on the caller's stream
+        self.ready[i].record(cur)                     # `images` are settled on the caller's stream
         s = self.streams[i]
         s.wait_event(self.ready[i])
+        if self._released[b]:                         # whoever read this output set last has said when it was done
+            s.wait_event(self.consumed[b])
         with torch.cuda.stream(s):
-            self.slots[i].detect(images, top_k=self.top_k, out=self.buffers[i], **detect_args)
-            self.done[i].record(s)
-        return Ticket(self.buffers[i], self.done[i])
+            self.slots[i].detect(images, top_k=self.top_k, out=self.buffers[b], **detect_args)
+            done = torch.cuda.Event()
+            done.record(s)
+        self._released[b] = False
+        t = Ticket(self.buffers[b], done, self.consumed[b])
+        t.release = self._release_fn(b, t)
+        return t
+
+    def _release_fn(self, b, ticket):
+        def release():
+            ticket._consumed.record(torch.cuda.current_stream())
+            self._released[b] = True
+        return release
 
     def synchronize(self):
         for s in self.streams:

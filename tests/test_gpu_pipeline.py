@@ -65,3 +65,16 @@ def test_pipeline_three_slots_many_batches():
         j += 1
     pipe.close()
     net.close()
+
+
+def test_pack_detections_matches_torch_packing():
+    from ron_tensorflow_amd import parallel
+    from ron_tensorflow_amd import weights as W
+    net = _net()
+    det = net.detect(torch.from_numpy(W.synthetic_images(4, seed=31)).cuda())
+    ref = parallel.pack_records(det.classes, det.scores, det.bboxes, det.anchor_index, det.count)
+    got = parallel.pack_detections(det)
+    assert torch.equal(ref, got)
+    cl, sc, bb, ai, cnt = parallel.unpack_records(got)
+    assert torch.equal(cnt, det.count) and torch.equal(cl, det.classes) and torch.equal(bb, det.bboxes)
+    net.close()
