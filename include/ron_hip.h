@@ -49,6 +49,9 @@ typedef enum { RON_DTYPE_F32 = 0, RON_DTYPE_BF16 = 1, RON_DTYPE_F16 = 2 } ron_dt
 const char* ron_last_error(void);
 /* ABI version of the library (bumped on any signature change). */
 int ron_abi_version(void);
+/* Host utility: CRC32C of a buffer (chain with `crc`, 0 first) -- the checksum of TensorFlow V2 checkpoint files
+ * (tf.train.Saver(write_version=2), ron_net.py:395-398), used by ron_tensorflow_amd/checkpoint.py. */
+uint32_t ron_crc32c(const void* data, uint64_t nbytes, uint32_t crc);
 
 /* ------------------------------------------------------------------------------------------
  * Anchors.  Replaces ron_anchor_one_layer / ron_anchors_all_layers / RONNet.anchors

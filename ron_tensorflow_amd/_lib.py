@@ -71,6 +71,7 @@ _P = C.c_void_p
 SIGNATURES = {
     'ron_last_error': (C.c_char_p, []),
     'ron_abi_version': (C.c_int, []),
+    'ron_crc32c': (C.c_uint32, [_P, C.c_uint64, C.c_uint32]),
     'ron_anchor_one_layer': (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
                                                        C.c_double, C.c_double, _P, _P, _P, _P]),
     'ron_ssd_anchor_one_layer': (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,

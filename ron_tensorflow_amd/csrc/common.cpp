@@ -1,3 +1,4 @@
+#include <string.h>
 #include "common.h"
 
 namespace ron {
@@ -13,3 +14,34 @@ const char* get_error() { return g_err; }
 
 extern "C" const char* ron_last_error(void) { return ron::get_error(); }
 extern "C" int ron_abi_version(void) { return 1; }
+
+// CRC32C (Castagnoli, reflected 0x82F63B78), slicing-by-8 on the host: the checksum of TensorFlow's tensor-bundle files
+// (ron_tensorflow_amd/checkpoint.py); `crc` chains calls (0 for the first).
+extern "C" uint32_t ron_crc32c(const void* data, uint64_t nbytes, uint32_t crc) {
+  static uint32_t tab[8][256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      tab[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xFF];
+    ready = true;
+  }
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  crc = ~crc;
+  while (nbytes >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= crc;
+    crc = tab[7][lo & 0xFF] ^ tab[6][(lo >> 8) & 0xFF] ^ tab[5][(lo >> 16) & 0xFF] ^ tab[4][lo >> 24] ^
+          tab[3][hi & 0xFF] ^ tab[2][(hi >> 8) & 0xFF] ^ tab[1][(hi >> 16) & 0xFF] ^ tab[0][hi >> 24];
+    p += 8;
+    nbytes -= 8;
+  }
+  while (nbytes--) crc = tab[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+  return ~crc;
+}

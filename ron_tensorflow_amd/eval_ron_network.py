@@ -32,7 +32,11 @@ def main():
     ap.add_argument('--batch_size', type=int, default=1)                 # :93-94
     ap.add_argument('--max_num_batches', type=int, default=4)
     ap.add_argument('--model_name', default='ron_320_vgg')               # :116-117
-    ap.add_argument('--checkpoint_path', default='', help='.npz of TF variables (weights.save_npz); synthetic if empty')
+    ap.add_argument('--checkpoint_path', default='',
+                    help='TF V2 checkpoint prefix / directory, or .npz of TF variables (weights.save_npz); synthetic if empty')
+    ap.add_argument('--checkpoint_model_scope', default=None)            # ron_eval.py:98-100
+    ap.add_argument('--checkpoint_exclude_scopes', default=None)         # ron_eval.py:101-104
+    ap.add_argument('--ignore_missing_vars', type=int, default=0)        # ron_eval.py:105-107
     ap.add_argument('--images', default='', help='.npy [N,320,320,3] pre-whitened float32; synthetic if empty')
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--variant', default='reducedfc', help="what RONNet.net builds in the reference (nets/ron_vgg_320.py:144)")
@@ -44,8 +48,12 @@ def main():
     ron_net = ron_class(ron_params, variant=FLAGS.variant, dtype=FLAGS.dtype, max_batch=FLAGS.batch_size)
     ron_shape = ron_net.params.img_shape
     ron_anchors = ron_net.anchors(ron_shape)
-    weights = W.load_npz(FLAGS.checkpoint_path) if FLAGS.checkpoint_path else W.synthetic_weights(FLAGS.variant, FLAGS.num_classes)
-    ron_net.load_weights(weights)
+    if FLAGS.checkpoint_path:                                              # eval_ron_network.py:346-361
+        ron_net.load_checkpoint(FLAGS.checkpoint_path, checkpoint_model_scope=FLAGS.checkpoint_model_scope,
+                                checkpoint_exclude_scopes=FLAGS.checkpoint_exclude_scopes,
+                                ignore_missing_vars=bool(FLAGS.ignore_missing_vars))
+    else:
+        ron_net.load_weights(W.synthetic_weights(FLAGS.variant, FLAGS.num_classes))
     n_total = FLAGS.batch_size * FLAGS.max_num_batches
     rs = np.random.RandomState(0)
     if FLAGS.images:

@@ -93,6 +93,25 @@ class RONNet(object):
         check(lib().ron_finalize_weights(ctx))
         return self
 
+    def load_checkpoint(self, checkpoint_path, checkpoint_model_scope=None, checkpoint_exclude_scopes=None,
+                        ignore_missing_vars=False, extra=None):
+        """Restore from a TensorFlow V2 checkpoint (prefix or directory) with the reference's rules
+        (tf_utils.py:184-243; eval_ron_network.py:346-361), or from an ``.npz`` of ``weights.save_npz``.
+        Every variable of the graph is needed to run it: excluded / missing ones must come from ``extra``
+        (dict name -> ndarray), otherwise ``load_weights`` raises KeyError."""
+        from .. import checkpoint, weights as W
+        if str(checkpoint_path).endswith('.npz'):
+            found = W.load_npz(checkpoint_path)
+        else:
+            model_name = self.variables()[0][0].split('/')[0]
+            found = checkpoint.load_checkpoint(checkpoint_path, self.variables(), model_name=model_name,
+                                               checkpoint_model_scope=checkpoint_model_scope,
+                                               checkpoint_exclude_scopes=checkpoint_exclude_scopes,
+                                               ignore_missing_vars=ignore_missing_vars)
+        if extra:
+            found = dict(extra, **found)
+        return self.load_weights(found)
+
     def flops_per_image(self):
         return lib().ron_flops_per_image(self._context())
 

@@ -78,3 +78,22 @@ def test_pack_detections_matches_torch_packing():
     cl, sc, bb, ai, cnt = parallel.unpack_records(got)
     assert torch.equal(cnt, det.count) and torch.equal(cl, det.classes) and torch.equal(bb, det.bboxes)
     net.close()
+
+
+def test_load_from_tf_checkpoint(tmp_path):
+    """synthetic weights -> TensorFlow V2 checkpoint files -> RONNet.load_checkpoint: identical detections."""
+    from ron_tensorflow_amd import checkpoint
+    from ron_tensorflow_amd import weights as W
+    from ron_tensorflow_amd.nets import nets_factory
+    w = W.synthetic_weights('reducedfc', seed=1)
+    checkpoint.write_checkpoint(str(tmp_path / 'model.ckpt-7'), w)
+    x = torch.from_numpy(W.synthetic_images(2, seed=4)).cuda()
+    a = _net(2)
+    ref = a.detect(x)
+    b = nets_factory.get_network('ron_320_vgg')(variant='reducedfc', dtype='bf16', max_batch=2, fuse_pools=True)
+    b.load_checkpoint(str(tmp_path))                       # directory: resolved through the `checkpoint` state file
+    got = b.detect(x)
+    torch.cuda.synchronize()
+    _same(ref, got)
+    a.close()
+    b.close()
