@@ -163,6 +163,10 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
     } while (0)
 #define RON_STAGE_END()                                                                                              \
     do {                                                                                                             \
+      if (ABL == 8) { /* timing-only: taps innermost, channel chunk outermost (weights are not in that order) */     \
+        if (++kx == p.kw) { kx = 0; if (++ky * p.kw >= p.KT * kChunkElems / p.Cin) { ky = 0; cc += kChunkElems; } }  \
+        break;                                                                                                       \
+      }                                                                                                              \
       cc += kChunkElems;                                                                                             \
       if (cc >= p.Cin) {                                                                                             \
         cc = 0;                                                                                                      \
@@ -546,6 +550,10 @@ constexpr TileCfg kCfgs[] = {
     {256, 256, 4, 2, 2, 1, 128, 16},   // 48: diagnostic, 30 with zero-record descriptors
     {256, 256, 4, 2, 2, 1, 128, 16},   // 49: diagnostic, 30 with a zero-record A descriptor (only the weights move)
     {256, 256, 4, 2, 2, 1, 128, 16},   // 50: diagnostic, 30 with a zero-record B descriptor (only the activations move)
+    {256, 64, 4, 2, 3, 2, 128, 16},    // 51: 256 x 64, three stages, 16x16 MFMAs (Cout 64)
+    {256, 64, 8, 1, 3, 2, 128, 16},    // 52: likewise, wave tile 32 x 64
+    {256, 128, 4, 2, 2, 2, 128, 16},   // 53: 256 x 128, two stages (96 KB)
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 54: diagnostic (timing only), 30 with the taps innermost in the K order
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 // workgroups of configuration i the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
@@ -619,6 +627,10 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 48: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 4>(a, s);
     case 49: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 6>(a, s);
     case 50: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 7>(a, s);
+    case 51: return launch_t<typename SmallShape<Tr>::type, 256, 64, 4, 2, 3, 2>(a, s);
+    case 52: return launch_t<typename SmallShape<Tr>::type, 256, 64, 8, 1, 3, 2>(a, s);
+    case 53: return launch_t<typename SmallShape<Tr>::type, 256, 128, 4, 2, 2, 2>(a, s);
+    case 54: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 8>(a, s);
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;
