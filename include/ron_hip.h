@@ -240,6 +240,9 @@ typedef struct {
 /* Run the head branches of the three coarse scales (block7/6/5: small grids) on internal side streams beside the
  * main chain; ron_forward / ron_detect fork after each reference map and join before returning control to `stream`. */
 #define RON_CFG_MULTI_STREAM 2u
+/* With RON_CFG_FUSE_POOLS (bf16 / f16) conv1_1 + conv1_2 + pool1 run as ONE kernel that goes from the fp32 image to pool1
+ * (neither 64-channel full-resolution map touches HBM).  This flag keeps them as separate launches (A/B tests). */
+#define RON_CFG_NO_STEM2 4u
 
 int ron_create(ron_ctx** out, const ron_config* cfg);
 int ron_destroy(ron_ctx* ctx);

@@ -64,6 +64,11 @@ void stem_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* frag
 int launch_stem_conv(const float* x, int n, int h, int w, int dtype, const void* d_wfrag, const float* d_bias,
                      const TensorView& out, hipStream_t s);
 
+// conv1_1 + conv1_2 + pool1 fused (stem.hip): image -> pool1, bf16 / f16 only
+void stem2_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* lds_image);
+int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w1frag, const float* d_bias1,
+                 const void* d_w2img, const float* d_bias2, const TensorView& out, hipStream_t s);
+
 // helpers (elementwise.hip)
 int launch_im2col_c3(const float* x, int n, int h, int w, int dtype, void* out, int kchunk, hipStream_t s);
 int launch_maxpool2x2(const TensorView& in, const TensorView& out, int dtype, hipStream_t s);

@@ -55,7 +55,7 @@ struct PackedConv {
   int Npad = 0, Cout = 0;
 };
 
-enum OpKind { OP_IM2COL, OP_CONV, OP_POOL, OP_STEM, OP_POOL3, OP_L2NORM };
+enum OpKind { OP_IM2COL, OP_CONV, OP_POOL, OP_STEM, OP_POOL3, OP_L2NORM, OP_STEM2 };
 
 struct Op {
   OpKind kind;
@@ -108,6 +108,8 @@ struct ron_ctx {
   int64_t post_ws_bytes = 0;
   void* d_stem_w = nullptr;             // conv1_1 fragments + bias for the dedicated stem kernel (bf16 / f16)
   float* d_stem_b = nullptr;
+  void* d_stem2_w = nullptr;            // conv1_2 weights as the LDS image of stem2_kernel (conv1_1 + conv1_2 + pool1 fused)
+  float* d_stem2_b = nullptr;
   void* d_splitk[4] = {};               // fp32 slabs of the split-K launches, one set per stream lane
   int64_t splitk_bytes[4] = {};
   // RON_CFG_MULTI_STREAM: the heads of the three coarse scales run on side streams beside the main chain
@@ -472,6 +474,8 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
   for (auto& t : c->tensors) {
     if (t.name == "im2col" && cfg->dtype != RON_DTYPE_F32) continue;      // bf16 / f16 use the stem kernel
     if ((cfg->flags & RON_CFG_FUSE_POOLS) && (t.name == "conv1_2" || t.name == "conv2_2" || t.name == "conv3_3")) continue;
+    if ((cfg->flags & RON_CFG_FUSE_POOLS) && !(cfg->flags & RON_CFG_NO_STEM2) && cfg->dtype != RON_DTYPE_F32 && H % 8 == 0 &&
+        W % 32 == 0 && t.name == "conv1_1") continue;         // conv1_1 + conv1_2 + pool1 run fused (stem2_kernel)
     t.bytes = (int64_t)cfg->max_batch * (t.H + 2 * t.pad) * (t.W + 2 * t.pad) * t.cstride * c->esz();
     if (t.bytes >= ((int64_t)1 << 32)) {
       ron::set_error("tensor %s needs %lld bytes for max_batch %d: above the 4 GiB buffer-addressing limit; lower max_batch",
@@ -514,7 +518,7 @@ extern "C" int ron_destroy(ron_ctx* c) {
   if (borrowed) {                        // the weights belong to the owner
     --c->weights_owner->clones;
     c->packed.clear();
-    c->d_l2_gamma = nullptr; c->d_stem_w = nullptr; c->d_stem_b = nullptr;
+    c->d_l2_gamma = nullptr; c->d_stem_w = nullptr; c->d_stem_b = nullptr; c->d_stem2_w = nullptr; c->d_stem2_b = nullptr;
   }
   for (auto& t : c->tensors) if (t.d) (void)hipFree(t.d);
   for (auto& p : c->packed) { if (p.d_w) (void)hipFree(p.d_w); if (p.d_bias) (void)hipFree(p.d_bias); }
@@ -532,6 +536,8 @@ extern "C" int ron_destroy(ron_ctx* c) {
   }
   if (c->d_stem_w) (void)hipFree(c->d_stem_w);
   if (c->d_stem_b) (void)hipFree(c->d_stem_b);
+  if (c->d_stem2_w) (void)hipFree(c->d_stem2_w);
+  if (c->d_stem2_b) (void)hipFree(c->d_stem2_b);
   delete c;
   return RON_OK;
 }
@@ -614,6 +620,21 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       c->ops.back().pool = 1;                 // block1..3 feed nothing but their pool: never written at full size
       c->ops.back().out = T(pname);
       c->ops.back().name += "+" + pname;
+      const size_t n_ops = c->ops.size();
+      if (b == 0 && use_stem && n_ops >= 2 && c->ops[n_ops - 2].kind == OP_STEM && H % 8 == 0 && W % 32 == 0 &&
+          !(c->cfg.flags & RON_CFG_NO_STEM2)) {
+        // conv1_1 + conv1_2 + pool1 as one kernel (stem.hip): neither full-resolution 64-channel map touches HBM
+        std::vector<uint16_t> img;
+        stem2_pack_weights(c->var("conv1/conv1_2/weights").data.data(), c->cfg.dtype, &img);
+        RON_HIP_CHECK(hipMalloc(&c->d_stem2_w, img.size() * 2));
+        RON_HIP_CHECK(hipMemcpy(c->d_stem2_w, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+        RON_HIP_CHECK(hipMalloc((void**)&c->d_stem2_b, 64 * sizeof(float)));
+        RON_HIP_CHECK(hipMemcpy(c->d_stem2_b, c->var("conv1/conv1_2/biases").data.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
+        Op f; f.kind = OP_STEM2; f.name = "conv1_1+conv1_2+pool1"; f.out = T(pname);
+        f.flops = c->ops[n_ops - 2].flops + c->ops[n_ops - 1].flops;
+        c->ops.pop_back(); c->ops.pop_back();
+        c->ops.push_back(f);
+      }
     } else {
       Op p; p.kind = OP_POOL; p.name = pname; p.in = prev; p.out = T(p.name);
       c->ops.push_back(p);
@@ -820,6 +841,7 @@ extern "C" int ron_clone(ron_ctx* src, ron_ctx** out) {
   c->packed = owner->packed;
   c->ops = owner->ops;
   c->d_l2_gamma = owner->d_l2_gamma; c->d_stem_w = owner->d_stem_w; c->d_stem_b = owner->d_stem_b;
+  c->d_stem2_w = owner->d_stem2_w; c->d_stem2_b = owner->d_stem2_b;
   c->flops_per_image = owner->flops_per_image;
   c->weights_owner = owner;
   ++owner->clones;
@@ -890,6 +912,10 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
     } else if (o.kind == OP_STEM) {
       const Tensor& t = c->tensors[o.out];
       if ((rc = launch_stem_conv(d_images, n, t.H, t.W, c->cfg.dtype, c->d_stem_w, c->d_stem_b, c->view(o.out, n), s))) return rc;
+    } else if (o.kind == OP_STEM2) {
+      const Tensor& t = c->tensors[o.out];
+      if ((rc = launch_stem2(d_images, n, 2 * t.H, 2 * t.W, c->cfg.dtype, c->d_stem_w, c->d_stem_b, c->d_stem2_w, c->d_stem2_b,
+                             c->view(o.out, n), s))) return rc;
     } else if (o.kind == OP_POOL) {
       if ((rc = launch_maxpool2x2(c->view(o.in, n), c->view(o.out, n), c->cfg.dtype, s))) return rc;
     } else if (o.kind == OP_POOL3) {

@@ -26,12 +26,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct StemBF16 {
   static __device__ __forceinline__ unsigned short cvt(float v) { return __builtin_bit_cast(unsigned short, __float2bfloat16(v)); }
+  static __device__ __forceinline__ float tof(unsigned v) { return __uint_as_float(v << 16); }
   static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
   }
 };
 struct StemF16 {
   static __device__ __forceinline__ unsigned short cvt(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+  static __device__ __forceinline__ float tof(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)v); }
   static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
   }
@@ -113,6 +115,189 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv1_1 + conv1_2 + pool1 in one kernel (RON_CFG_FUSE_POOLS, bf16 / f16).
+//
+// As separate launches the stem writes the 64-channel conv1_1 map (13 MB per image) and conv1_2 stages it back nine
+// times: 9 % of the step at batch 32.  Here a workgroup owns an 8 x 32 pixel tile of conv1_2's output:
+//   A. the 12 x 36 x 3 fp32 image patch goes to LDS (zero outside the image);
+//   B. conv1_1 (+bias, ReLU) of the 10 x 34 halo patch is computed with MFMAs (K = 27 -> 32) and stored as bf16 rows of
+//      128 B (64 channels) in LDS, swizzled like the generic kernel's stages, zero outside the image (= conv1_2's padding);
+//   C. conv1_2 runs its 9 taps straight from that patch: wave w owns tile row w (32 consecutive pixels, so a fragment's
+//      rows are consecutive patch rows: conflict-free ds_read_b128 for any tap shift with the 32x32 MFMA), the weights
+//      of all 9 taps (72 KB) stay resident in LDS for the life of the (persistent) workgroup -- no staging in the loop;
+//   D. + bias, ReLU, 2x2 max-pool (horizontal pairs are adjacent accumulator registers, vertical pairs meet in LDS),
+//      16-byte stores of the pooled 4 x 16 tile.
+// HBM traffic: image in (1.2 MB / image), pool1 out (3.3 MB / image).
+constexpr int kS2TH = 8, kS2TW = 32;
+constexpr int kS2PW = kS2TW + 2, kS2PH = kS2TH + 2, kS2Rows = kS2PW * kS2PH;       // 34 x 10 = 340 patch rows
+constexpr int kS2IW = kS2TW + 4, kS2IH = kS2TH + 4;                                 // 36 x 12 image patch
+constexpr int kS2W2Bytes = 9 * 64 * 128;                                            // 72 KB
+constexpr int kS2PatchBytes = kS2Rows * 128;
+constexpr int kS2ImgFloats = kS2IH * kS2IW * 3;
+constexpr int kS2PoolBytes = 8 * 16 * 128;
+constexpr int kS2Lds = kS2W2Bytes + kS2PatchBytes + kS2ImgFloats * 4 + kS2PoolBytes;
+
+template <class Tr>
+__global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x, int n_img, int H, int W,
+                                                    const u32x4* __restrict__ w1frag, const float* __restrict__ bias1,
+                                                    const u32x4* __restrict__ w2img, const float* __restrict__ bias2,
+                                                    unsigned short* __restrict__ out, int out_Hp, int out_Wp, int out_pad) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_w2 = smem;
+  char* s_p = s_w2 + kS2W2Bytes;
+  float* s_img = reinterpret_cast<float*>(s_p + kS2PatchBytes);
+  char* s_pool = reinterpret_cast<char*>(s_img + kS2ImgFloats);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  // conv1_2 weights: the host packed the exact LDS image (tap, permuted output row, swizzled 16-byte chunks)
+  for (int i = tid; i < kS2W2Bytes / 16; i += 512) reinterpret_cast<u32x4*>(s_w2)[i] = w2img[i];
+  // conv1_1 weights in registers, as in stem_conv_kernel
+  u32x4 wb[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) wb[t][s] = w1frag[(t * 2 + s) * 64 + lane];
+  const float b1_0 = bias1[2 * r], b1_1 = bias1[2 * r + 1];
+  const float b2_0 = bias2[2 * r], b2_1 = bias2[2 * r + 1];
+  int a_off[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * s + 8 * h + j;
+      const int ty = k / 9, rem = k - ty * 9;
+      a_off[s][j] = k < 27 ? ty * (kS2IW * 3) + rem : -1;           // rem = tx*3 + c
+    }
+  const int tiles_x = W / kS2TW, tiles_y = H / kS2TH;
+  const int n_tiles = n_img * tiles_y * tiles_x;
+  // ---- A: image patch (rows y0-2 .. y0+9, columns x0-2 .. x0+33) of a tile: 1296 floats, <= 3 per thread.  The patch of
+  // tile t+1 is fetched into registers while tile t computes and dropped into LDS once phase B of tile t has read its own.
+  constexpr int kImgPer = (kS2ImgFloats + 511) / 512;
+  int i_iy[kImgPer], i_ix[kImgPer];
+#pragma unroll
+  for (int k = 0; k < kImgPer; ++k) {
+    const int i = min(tid + k * 512, kS2ImgFloats - 1);
+    i_iy[k] = i / (kS2IW * 3);
+    i_ix[k] = i - i_iy[k] * (kS2IW * 3);                             // ix * 3 + c
+  }
+  float pre[kImgPer];
+#define RON_S2_FETCH(tile_)                                                                                   \
+  do {                                                                                                        \
+    const int t_ = (tile_);                                                                                   \
+    const int fx = t_ % tiles_x, fy = (t_ / tiles_x) % tiles_y, fimg = t_ / (tiles_x * tiles_y);              \
+    _Pragma("unroll") for (int k = 0; k < kImgPer; ++k) {                                                     \
+      const int yy = fy * kS2TH - 2 + i_iy[k], xc = (fx * kS2TW - 2) * 3 + i_ix[k];                           \
+      pre[k] = (t_ < n_tiles && yy >= 0 && yy < H && xc >= 0 && xc < W * 3)                                   \
+                   ? x[((long long)fimg * H + yy) * W * 3 + xc] : 0.f;                                        \
+    }                                                                                                         \
+  } while (0)
+#define RON_S2_STORE()                                                                                        \
+  do {                                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < kImgPer; ++k)                                                       \
+      if (tid + k * 512 < kS2ImgFloats) s_img[tid + k * 512] = pre[k];                                        \
+  } while (0)
+  RON_S2_FETCH(blockIdx.x);
+  RON_S2_STORE();
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x;
+    const int ty_ = (tile / tiles_x) % tiles_y;
+    const int img = tile / (tiles_x * tiles_y);
+    const int y0 = ty_ * kS2TH, x0 = tx * kS2TW;
+    RON_S2_FETCH(tile + gridDim.x);                   // in flight during phase B
+    // ---- B: conv1_1 of the 340 patch pixels, 32 at a time
+    for (int g = wave; g * 32 < kS2Rows; g += 8) {
+      const int q = min(g * 32 + r, kS2Rows - 1);
+      const int py = q / kS2PW, px = q - py * kS2PW;
+      const float* base = s_img + (py * kS2IW + px) * 3;
+      u32x4 fa[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = Tr::cvt(a_off[s][j] >= 0 ? base[a_off[s][j]] : 0.f);
+        fa[s] = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                      (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+      }
+      f32x16 acc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        Tr::mma(fa[0], wb[t][0], acc[t]);
+        Tr::mma(fa[1], wb[t][1], acc[t]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int qq = g * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (qq >= kS2Rows) continue;
+        const int qy = qq / kS2PW, qx = qq - qy * kS2PW;
+        const int iy = y0 - 1 + qy, ix = x0 - 1 + qx;
+        const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const unsigned lo = Tr::cvt(inside ? fmaxf(acc[0][e] + b1_0, 0.f) : 0.f);
+        const unsigned hi = Tr::cvt(inside ? fmaxf(acc[1][e] + b1_1, 0.f) : 0.f);
+        *reinterpret_cast<unsigned*>(s_p + qq * 128 + ((((r >> 2) ^ ((qq >> 1) & 7))) << 4) + (r & 3) * 4) = lo | (hi << 16);
+      }
+    }
+    __syncthreads();
+    RON_S2_STORE();                                   // s_img is free: the next tile's patch (read after two more barriers)
+    // ---- C: conv1_2, wave = tile row, 9 taps x 4 k-steps x 2 column tiles
+    f32x16 acc2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[t][e] = 0.f;
+    const int key_b = (r >> 1) & 7;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int prow = (wave + tap / 3) * kS2PW + r + tap % 3;
+      const char* pa = s_p + prow * 128;
+      const int key_a = (prow >> 1) & 7;
+      const char* pb = s_w2 + tap * 8192 + r * 128;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const u32x4 fa = *reinterpret_cast<const u32x4*>(pa + (((2 * s + h) ^ key_a) << 4));
+        const u32x4 fb0 = *reinterpret_cast<const u32x4*>(pb + (((2 * s + h) ^ key_b) << 4));
+        const u32x4 fb1 = *reinterpret_cast<const u32x4*>(pb + 32 * 128 + (((2 * s + h) ^ key_b) << 4));
+        Tr::mma(fa, fb0, acc2[0]);
+        Tr::mma(fa, fb1, acc2[1]);
+      }
+    }
+    // ---- D: bias, ReLU, horizontal pool in registers -> LDS; vertical pool + store
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int e0 = 4 * qd + 2 * half;
+        const float m0 = fmaxf(fmaxf(acc2[0][e0], acc2[0][e0 + 1]) + b2_0, 0.f);
+        const float m1 = fmaxf(fmaxf(acc2[1][e0], acc2[1][e0 + 1]) + b2_1, 0.f);
+        const int m = 4 * qd + 2 * h + half;                          // pooled column 0..15
+        *reinterpret_cast<unsigned*>(s_pool + (wave * 16 + m) * 128 + r * 4) = (unsigned)Tr::cvt(m0) | ((unsigned)Tr::cvt(m1) << 16);
+      }
+    __syncthreads();
+    {
+      const int yp = tid >> 7, m = (tid >> 3) & 15, c8 = tid & 7;     // 4 pooled rows x 16 columns x 8 chunks of 8 channels
+      const u32x4 a = *reinterpret_cast<const u32x4*>(s_pool + ((2 * yp) * 16 + m) * 128 + c8 * 16);
+      const u32x4 b = *reinterpret_cast<const u32x4*>(s_pool + ((2 * yp + 1) * 16 + m) * 128 + c8 * 16);
+      u32x4 o;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned lo = Tr::cvt(fmaxf(Tr::tof(a[d] & 0xFFFFu), Tr::tof(b[d] & 0xFFFFu)));
+        const unsigned hi = Tr::cvt(fmaxf(Tr::tof(a[d] >> 16), Tr::tof(b[d] >> 16)));
+        o[d] = lo | (hi << 16);
+      }
+      const long long opix = ((long long)img * out_Hp + (y0 >> 1) + yp + out_pad) * out_Wp + (x0 >> 1) + m + out_pad;
+      *reinterpret_cast<u32x4*>(out + opix * 64 + c8 * 8) = o;
+    }
+    // the next tile's phase B writes s_p (all reads of this tile's patch are behind the barrier above); its phase D
+    // writes s_pool two barriers from here
+  }
+#undef RON_S2_FETCH
+#undef RON_S2_STORE
+}
 }  // namespace
 
 // Weight fragments for stem_conv_kernel from the HWIO [3,3,3,64] filter: fragment (t, s), lane (r, h), element j holds
@@ -142,6 +327,49 @@ int launch_stem_conv(const float* x, int n, int h, int w, int dtype, const void*
   else
     hipLaunchKernelGGL(stem_conv_kernel<StemF16>, dim3(grid), dim3(256), 0, s, x, n, h, w, (const u32x4*)d_wfrag, d_bias,
                        (unsigned*)out.base, out.Hp(), out.Wp(), out.pad);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+}  // namespace ron
+
+namespace ron {
+
+// LDS image of the conv1_2 weights for stem2_kernel from the HWIO [3,3,64,64] filter: tap-major, row (j*32 + r) of a tap
+// holds output channel 2r + j, 64 input channels = 8 chunks of 16 B, chunk c in slot c ^ ((row >> 1) & 7).
+void stem2_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* img) {
+  img->assign(9 * 64 * 64, 0);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int row = 0; row < 64; ++row) {
+      const int j = row / 32, r = row % 32, ch = 2 * r + j;
+      for (int cin = 0; cin < 64; ++cin) {
+        const float v = hwio[((size_t)tap * 64 + cin) * 64 + ch];
+        const int chunk = cin / 8, slot = chunk ^ ((row >> 1) & 7);
+        (*img)[((size_t)tap * 64 + row) * 64 + slot * 8 + cin % 8] = dtype == RON_DTYPE_BF16 ? f32_to_bf16_rne(v) : f32_to_f16_rne(v);
+      }
+    }
+}
+
+int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w1frag, const float* d_bias1,
+                 const void* d_w2img, const float* d_bias2, const TensorView& out, hipStream_t s) {
+  RON_REQUIRE(dtype == RON_DTYPE_BF16 || dtype == RON_DTYPE_F16, "stem2 kernel: bf16 / f16 only");
+  RON_REQUIRE(w % kS2TW == 0 && h % kS2TH == 0 && out.C == 64 && out.cstride == 64 && out.coff == 0 && out.H == h / 2 && out.W == w / 2,
+              "stem2 kernel: bad shape");
+  const int tiles = n * (h / kS2TH) * (w / kS2TW);
+  const int grid = std::min(tiles, 256);
+  static bool attr_set[2] = {false, false};
+  const int which = dtype == RON_DTYPE_BF16 ? 0 : 1;
+  if (!attr_set[which]) {
+    if (which == 0) RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem2_kernel<StemBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kS2Lds));
+    else RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem2_kernel<StemF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kS2Lds));
+    attr_set[which] = true;
+  }
+  if (which == 0)
+    hipLaunchKernelGGL(stem2_kernel<StemBF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
+                       (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad);
+  else
+    hipLaunchKernelGGL(stem2_kernel<StemF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
+                       (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }

@@ -220,3 +220,26 @@ def test_network_fn_uses_full_variant(pkg, dev, weights_full, images):
     assert len(out) == 6
     assert tuple(out[5]['block6'].shape) == (1, 10, 10, 4096)       # ron_net: fc6 7x7 -> 4096 (nets/ron_vgg_320.py:478)
     assert tuple(out[0][3].shape) == (1, 40, 40, 10, 21)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_fused_stem_matches_separate_launches(pkg, dev, weights_reduced, dtype):
+    """conv1_1 + conv1_2 + pool1 as one kernel (stem2_kernel) vs stem kernel -> conv kernel with fused pool: pool1 agrees to
+    one storage-type ulp (different fp32 accumulation order inside conv1_2), heads to the reduced-precision tolerance."""
+    cls = pkg['factory'].get_network('ron_320_vgg')
+    x = torch.from_numpy(pkg['W'].synthetic_images(3, seed=12)).to(dev)
+    outs = []
+    for no_stem2 in (False, True):
+        net = cls(variant='reducedfc', dtype=dtype, max_batch=3, device=dev, fuse_pools=True)
+        net.no_stem2 = no_stem2
+        net.load_weights(weights_reduced)
+        lg, _, _ = net.forward_heads(x)
+        outs.append((net.end_point('pool1', 3).cpu().numpy(), [t.cpu().numpy() for t in lg]))
+        net.close()
+    p_a, p_b = outs[0][0], outs[1][0]
+    assert p_a.shape == (3, 160, 160, 64) and np.abs(p_b).max() > 0
+    ulp = 2.0 ** (-7 if dtype == 'bf16' else -10)
+    assert np.abs(p_a - p_b).max() <= 1.01 * ulp * np.abs(p_b).max()
+    assert np.mean(p_a != p_b) < 0.05                               # and nearly everywhere bit-identical
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert _rel_err(a, b) < (3e-2 if dtype == 'bf16' else 5e-3)
