@@ -60,6 +60,12 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
   // layout: [stage 0 .. S-1: A | B][in_off: BM ints][out_off: BM ints]
   int* s_in_off = reinterpret_cast<int*>(smem + S * kStage);
   int* s_out_off = s_in_off + BM;
+  // ROT == 2 ("PF"): one more LDS-DMA per wave and K step that touches (4 bytes per lane) the 128-byte lines of the tile AFTER
+  // the one being staged.  Its bytes land in a sink; what it buys is that the fabric round trip of lines that miss L2 happens a
+  // whole stage period earlier, so the real pieces - which have one stage period to land, all LDS leaves room for - find them in L2.
+  constexpr int PF = ROT == 2 ? 1 : 0;
+  char* s_sink = reinterpret_cast<char*>(s_out_off + BM);
+  (void)s_sink;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,6 +127,8 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
   // fixed-size arrays on purpose: with a template-dependent bound the LDS-DMA builtin's voffset becomes a
   // type-dependent expression and hipcc (ROCm 7.2) silently drops the kernel's host stub.
   int a_voff[8], b_voff[8];
+  const int hot_voff = (tid & 63) * 16;
+  (void)hot_voff;
   static_assert(A_IT <= 8 && B_IT <= 8, "tile too large");
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) a_voff[it] = s_in_off[it * kRowsPerIt + ld_row] + ld_chunk * 16;
@@ -135,6 +143,10 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
     b_voff[it] = (n0 + nrow) * p.K * Tr::kEsz + ld_chunk * 16;
   }
 
+  // prefetch line of this lane: tile row `tid` of A (waves below BM / 64) or of B (the next BN / 64 waves)
+  const bool pf_a = wave * 64 < BM, pf_any = wave * 64 < BM + BN;
+  int pf_voff = 0;
+  if (PF) pf_voff = pf_a ? s_in_off[min(tid, BM - 1)] : (n0 + min(tid - BM, BN - 1)) * p.K * Tr::kEsz;
   // K-step bookkeeping (wave-uniform): tap (ky, kx) and channel chunk cc of the NEXT tile to stage
   const int chunks_per_tap = p.Cin / kChunkElems;
   const int tap0 = kt0 / chunks_per_tap;
@@ -154,6 +166,10 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
 #define RON_STAGE_PIECE(i_)                                                                                          \
     do {                                                                                                             \
       if (ABL == 1 || ABL == 3) break;                                                                                        \
+      if (ABL == 9) { /* timing-only: every piece re-reads the same 1 KB (L1 hits): the LDS side of the stream alone */ \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst + (i_) * kRowsPerIt * kRowBytes), 16, hot_voff, 0, 0, 0); \
+        break;                                                                                                       \
+      }                                                                                                              \
       if ((i_) < A_IT)                                                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst + (i_) * kRowsPerIt * kRowBytes), 16,         \
                                                  a_voff[(i_) < A_IT ? (i_) : 0], a_soff, 0, 0);                      \
@@ -172,6 +188,17 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
         cc = 0;                                                                                                      \
         if (++kx == p.kw) { kx = 0; ++ky; }                                                                          \
       }                                                                                                              \
+    } while (0)
+
+  // after RON_STAGE_END the state (ky, kx, cc) describes tile tpf_ = the one after the tile just staged
+#define RON_PREFETCH(tpf_)                                                                                           \
+    do {                                                                                                             \
+      if (!PF) break;                                                                                                \
+      const bool lv_ = (tpf_) < kt1 && pf_any;                                                                       \
+      const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                          \
+          const_cast<void*>(pf_a ? p.in : p.wgt), 0, lv_ ? (pf_a ? p.in_bytes : p.wgt_bytes) : 0u, 0x00020000);      \
+      const int so_ = pf_a ? ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz : (tpf_) * kRowBytes; \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void*)(s_sink + wave * 256), 4, pf_voff, so_, 0, 0);        \
     } while (0)
 
   typename Tr::acc_t acc[MR][NR];
@@ -197,6 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
 #pragma unroll
     for (int i = 0; i < LPT; ++i) RON_STAGE_PIECE(i);
     RON_STAGE_END();
+    RON_PREFETCH(kt0 + t + 1);
   }
 
   // ABL 5: s_memtime stamps around the wait, the barrier and the rest of the K step (shares, not run time)
@@ -209,7 +237,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
         __builtin_amdgcn_sched_barrier(0);                                                 \
       }                                                                                    \
     } while (0)
-  if (ROT) {
+  if (ROT == 1) {
     // Rotated K loop: the wait + barrier of tile kt+1 sit in front of the LAST k-step of tile kt, whose fragments are
     // already in registers.  After the barrier the MFMAs of that k-step restart at once, and in their shadow go (a) the
     // first fragment reads of tile kt+1 (the un-rotated loop pays them as an LDS burst with idle matrix cores at the top
@@ -287,7 +315,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
   for (int kt = kt0; kt < kt1; ++kt) {
     RON_STAMP(t_a);
     if (ABL != 3) {
-    wait_vmcnt<(S - 2) * LPT>();            // this wave's share of tile kt has landed
+    wait_vmcnt<(S - 2) * (LPT + PF) + PF>();   // this wave's share of tile kt has landed (a younger prefetch may be out)
     RON_STAMP(t_b);
     __builtin_amdgcn_s_barrier();           // ... everyone's has, and everyone is done reading tile kt-1
     RON_STAMP(t_c);
@@ -360,6 +388,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
       }
     }
     RON_STAGE_END();
+    RON_PREFETCH(kt + S);
     RON_STAMP(t_d);
     if (ABL == 5) { t_wait += t_b - t_a; t_bar += t_c - t_b; t_comp += t_d - t_c; }
   }
@@ -368,6 +397,7 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
     d[0] = t_wait; d[1] = t_bar; d[2] = t_comp; d[3] = (unsigned long long)(kt1 - kt0);
   }
 #undef RON_STAMP
+#undef RON_PREFETCH
 #undef RON_STAGE_BEGIN
 #undef RON_STAGE_PIECE
 #undef RON_STAGE_END
@@ -554,6 +584,12 @@ constexpr TileCfg kCfgs[] = {
     {256, 64, 8, 1, 3, 2, 128, 16},    // 52: likewise, wave tile 32 x 64
     {256, 128, 4, 2, 2, 2, 128, 16},   // 53: 256 x 128, two stages (96 KB)
     {256, 256, 4, 2, 2, 1, 128, 16},   // 54: diagnostic (timing only), 30 with the taps innermost in the K order
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 55: diagnostic (timing only), 30 with every LDS-DMA piece reading the same 1 KB
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 56: 30 + L2 prefetch of the tile after next (ROT 2)
+    {128, 128, 2, 2, 2, 1, 128, 16},   // 57: 33 likewise
+    {128, 128, 2, 2, 2, 2, 128, 16},   // 58: 36 likewise
+    {128, 64, 2, 2, 2, 2, 128, 16},    // 59: 37 likewise
+    {256, 256, 4, 2, 2, 2, 128, 16},   // 60: 35 likewise
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 // workgroups of configuration i the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
@@ -561,7 +597,7 @@ inline int cfg_slots(int i) { return kCfgs[i].stages * (kCfgs[i].bm + kCfgs[i].b
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int ABL = 0, int RB = 128, int ROT = 0>
 int launch_t(const ConvArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)S * (BM + BN) * RB + 2 * BM * sizeof(int);
+  const size_t lds = (size_t)S * (BM + BN) * RB + 2 * BM * sizeof(int) + (ROT == 2 ? WM * WN * 256 : 0);
   static bool attr_set = false;
   if (!attr_set) {
     RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB, ROT>),
@@ -631,6 +667,12 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 52: return launch_t<typename SmallShape<Tr>::type, 256, 64, 8, 1, 3, 2>(a, s);
     case 53: return launch_t<typename SmallShape<Tr>::type, 256, 128, 4, 2, 2, 2>(a, s);
     case 54: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 8>(a, s);
+    case 55: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 9>(a, s);
+    case 56: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 0, 128, 2>(a, s);
+    case 57: return launch_t<typename SmallShape<Tr>::type, 128, 128, 2, 2, 2, 1, 0, 128, 2>(a, s);
+    case 58: return launch_t<typename SmallShape<Tr>::type, 128, 128, 2, 2, 2, 2, 0, 128, 2>(a, s);
+    case 59: return launch_t<typename SmallShape<Tr>::type, 128, 64, 2, 2, 2, 2, 0, 128, 2>(a, s);
+    case 60: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 2, 0, 128, 2>(a, s);
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;

@@ -21,6 +21,12 @@ namespace detail {
 constexpr int kPatchPieces = 6;                  // LDS-DMA pieces per thread and chunk (512 threads x 16 B = 64 rows each)
 constexpr int kPatchRows = 344;                  // rows a patch buffer holds (43 KB): 8 x 42, 10 x 34, 14 x 22 patches fit
 
+// Swizzle key of patch row i (slot = chunk ^ key).  A tap shift moves a fragment's 16 or 32 rows to an arbitrary start row, so the
+// key has to be conflict-free for every start (brute-forced over the ds_read_b128 lane groups): (i >> 1) & 7 is for the 32-row
+// fragments of the 32x32 MFMA but 2-way conflicted for most starts with the 16-row fragments of the 16x16 MFMA, whose K-group
+// bit is the chunk's bit 0; a key that leaves bit 0 alone, ((i >> 1) & 3) << 1, is conflict-free there for every start.
+template <int MT> __device__ __forceinline__ int patch_key(int i) { return MT == 16 ? ((i >> 1) & 3) << 1 : (i >> 1) & 7; }
+
 struct PatchArgs {
   ConvArgs c;
   int TH, TW, PW, R;          // tile, patch width (TW + 2), patch rows in use ((TH + 2) * PW <= kPatchRows)
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
     // patch origin = output (y0-1, x0-1) = padded (y0 - 1 + in_pad, x0 - 1 + in_pad); clamp inside the padded image
     const int gy = min(y0 + py + p.in_org, p.in_Hp - 1), gx = min(x0 + px + p.in_org, p.in_Wp - 1);
     p_voff[k] = (int)((((unsigned)(img * p.in_Hp + gy) * p.in_Wp + gx) * p.in_cstride + p.in_coff) * Tr::kEsz) +
-                ((slot ^ ((i >> 1) & 7)) << 4);
+                ((slot ^ patch_key<MT>(i)) << 4);
   }
   // B pieces: LDS row (j*MT + r) of a wave's TN-wide group <- weight row (r*NR + j)   (coalesced epilogue, see conv_mfma.hip)
   int b_voff[4];
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
     for (int i = 0; i < MR; ++i) {
       const int row = pp[i] + tapoff;
       a_row[i] = row * kRowBytes;
-      a_key[i] = (row >> 1) & 7;
+      a_key[i] = patch_key<MT>(row);
     }
     u32x4 fa[2][MR], fb[2][NR];
 #pragma unroll
