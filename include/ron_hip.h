@@ -206,6 +206,12 @@ int ron_post_tfe(const ron_heads* heads, int n, const ron_tfe_cfg* cfg,
  * ---------------------------------------------------------------------------------------- */
 int ron_preprocess_eval(const uint8_t* packed, const int64_t* offsets, const int32_t* hw, int n,
                         int out_h, int out_w, const float* means, float* out, void* stream);
+/* The other resize modes of preprocess_for_eval (CENTRAL_CROP: tf_image.resize_image_bboxes_with_crop_or_pad,
+ * tf_image.py:141-254; PAD_AND_RESIZE: ssd_vgg_preprocessing.py:392-405) as one geometry table (device, int32 [n, 8]):
+ *   {crop_y, crop_x, crop_h, crop_w, pad_y, pad_x, resized_h, resized_w}: the crop window of the whitened image is resized to
+ *   resized_h x resized_w (TF1 bilinear) and placed at (pad_y, pad_x) of the output; the rest of the output is 0. */
+int ron_preprocess_eval_geom(const uint8_t* packed, const int64_t* offsets, const int32_t* hw, const int32_t* geom, int n,
+                             int out_h, int out_w, const float* means, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Evaluation bookkeeping: tfe.bboxes_matching_batch (tf_extended/bboxes.py:316-450) on the dense output of

@@ -29,8 +29,8 @@ def test_other_out_shape_and_none():
     out = pp.preprocess_for_eval_batch(ims, resize=pp.Resize.NONE).cpu().numpy()
     for i, im in enumerate(ims):
         assert np.array_equal(out[i], im.astype(np.float32) - np.array([123., 117., 104.], np.float32))
-    with pytest.raises(NotImplementedError):
-        pp.preprocess_for_eval_batch(ims, resize=pp.Resize.CENTRAL_CROP)
+    with pytest.raises(ValueError):
+        pp.preprocess_for_eval_batch(ims, resize=17)
     with pytest.raises(ValueError):
         pp.preprocess_for_eval_batch([np.zeros((4, 4), np.uint8)])
 
@@ -52,3 +52,20 @@ def test_reference_signature_and_feeds_the_net():
     dets = net.detect(img[None])
     assert dets.count.shape[0] == 1
     net.close()
+
+
+@pytest.mark.parametrize('mode', ['CENTRAL_CROP', 'PAD_AND_RESIZE'])
+def test_crop_and_pad_modes_bit_exact(mode):
+    """The two other modes of preprocess_for_eval: images larger, smaller and mixed relative to 320 x 320, with bboxes."""
+    from ron_tensorflow_amd.preprocessing import ssd_vgg_preprocessing as pp
+    rs = np.random.RandomState(8)
+    shapes = [(375, 500), (200, 250), (500, 200), (320, 320), (321, 319), (97, 1024), (640, 960)]
+    ims = [rs.randint(0, 256, s + (3,)).astype(np.uint8) for s in shapes]
+    out = pp.preprocess_for_eval_batch(ims, resize=getattr(pp.Resize, mode)).cpu().numpy()
+    bb = rs.rand(3, 4).astype(np.float32)
+    for i, im in enumerate(ims):
+        ref, ref_b, ref_rect = op.preprocess_for_eval_mode(im, bb, (320, 320), mode)
+        assert np.array_equal(out[i], ref), 'image %d %r' % (i, shapes[i])
+        img, _, b2, rect = pp.preprocess_for_eval(im, None, bb, resize=getattr(pp.Resize, mode))
+        assert np.array_equal(img.cpu().numpy(), ref)
+        assert np.abs(b2 - ref_b).max() <= 1e-6 and np.abs(rect - ref_rect).max() <= 1e-6

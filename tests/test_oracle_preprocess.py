@@ -33,3 +33,21 @@ def test_constant_image_and_upscale_bounds():
     out = op.preprocess_for_eval(ramp, (320, 320), means=(0, 0, 0))
     assert np.array_equal(out[5, :319, 0], np.arange(319, dtype=np.float32) * np.float32(0.5))
     assert out[5, 319, 0] == 159.0                                # clamped upper neighbour
+
+
+def test_crop_or_pad_and_modes():
+    rs = np.random.RandomState(3)
+    im = rs.randint(0, 256, (400, 200, 3)).astype(np.uint8)        # taller (cropped) and narrower (padded) than 320 x 320
+    w = im.astype(np.float32) - np.array(op.MEANS, np.float32)
+    out, b, rect = op.preprocess_for_eval_mode(im, [[0., 0., 1., 1.], [.25, .5, .75, 1.]], (320, 320), 'CENTRAL_CROP')
+    assert np.array_equal(out[:, 60:260], w[40:360]) and not out[:, :60].any() and not out[:, 260:].any()
+    assert np.allclose(rect, [-40 / 320., 60 / 320., 360 / 320., 260 / 320.])
+    assert np.allclose(b[1], [(100 - 40) / 320., (100 + 60) / 320., (300 - 40) / 320., (200 + 60) / 320.])
+    out, b, rect = op.preprocess_for_eval_mode(im, [], (320, 320), 'PAD_AND_RESIZE')     # factor 0.8 -> 320 x 160, padded to 320 wide
+    assert np.array_equal(out[:, 80:240], op.resize_bilinear(w, (320, 160))) and not out[:, :80].any()
+    assert np.allclose(rect, [0., .25, 1., .75])
+    small = rs.randint(0, 256, (100, 120, 3)).astype(np.uint8)     # smaller than the target: factor 1, only padded
+    out, _, _ = op.preprocess_for_eval_mode(small, [], (320, 320), 'PAD_AND_RESIZE')
+    assert np.array_equal(out[110:210, 100:220], small.astype(np.float32) - np.array(op.MEANS, np.float32))
+    out, _, rect = op.preprocess_for_eval_mode(small, [], (320, 320), 'NONE')
+    assert out.shape == (100, 120, 3) and rect.tolist() == [0., 0., 1., 1.]
