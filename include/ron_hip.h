@@ -195,6 +195,31 @@ int ron_post_tfe(const ron_heads* heads, int n, const ron_tfe_cfg* cfg,
                  float* scores, float* bboxes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ron_eval.py variant of the post-processing (the reference's per-image harness, ron_eval.py:111-206, :369-392, :466-477):
+ *   flaten_predict: score[c] = objectness * class probability, label = argmax over all classes, kept when label > 0 and
+ *   objectness > objectness_thres -> tfe.bboxes_clip(bbox_img) -> filter_boxes (sides > min_size, centre inside the image)
+ *   -> tf_bboxes_nms: score > select_threshold, all classes together, greedy in score order, at most keep_top_k kept,
+ *   overlap 'union' (what main() passes) or 'min' -> tfe.bboxes_resize(bbox_img).
+ * min_sizes: device [n], filter_boxes' min_size of every image (max(1e-4, 0.03 * sqrt(h * w / (320 * 320)))).
+ * Output: ron_detections (classes = labels), capacity >= keep_top_k, kept rows in score order, zero padded.
+ * The 1024 highest scores that pass the filters are the NMS candidates (the reference considers all of them; with its
+ * thresholds, 0.95 / 0.6, a few dozen pass).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  float objectness_thres;   /* 0.95 */
+  float select_threshold;   /* 0.6  */
+  float nms_threshold;      /* 0.4  */
+  int32_t keep_top_k;       /* nms_topk = 20 */
+  int32_t nms_mode;         /* 1 = 'union', 0 = 'min' */
+  float bbox_img[4];
+  float prior_scaling[4];
+  uint32_t input_flags;
+} ron_eval_cfg;
+int64_t ron_post_eval_workspace_bytes(const ron_heads* heads, int n);
+int ron_post_eval(const ron_heads* heads, int n, const float* min_sizes, const ron_eval_cfg* cfg,
+                  void* workspace, int64_t workspace_bytes, ron_detections* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Evaluation preprocessing: preprocess_for_eval with Resize.WARP_RESIZE
  * (preprocessing/ssd_vgg_preprocessing.py:358-425, tf_image.py:269-282): uint8 RGB -> float, minus the channel means,
  * TF1 bilinear resize (align_corners=False, no half-pixel centres) to [out_h, out_w].

@@ -43,6 +43,12 @@ class PostCfg(C.Structure):
                 ('input_flags', C.c_uint32)]
 
 
+class EvalCfg(C.Structure):
+    _fields_ = [('objectness_thres', C.c_float), ('select_threshold', C.c_float), ('nms_threshold', C.c_float),
+                ('keep_top_k', C.c_int32), ('nms_mode', C.c_int32), ('bbox_img', C.c_float * 4),
+                ('prior_scaling', C.c_float * 4), ('input_flags', C.c_uint32)]
+
+
 class TfeCfg(C.Structure):
     _fields_ = [('objectness_thres', C.c_float), ('select_threshold', C.c_float), ('nms_threshold', C.c_float),
                 ('top_k', C.c_int32), ('keep_top_k', C.c_int32), ('nms_mode', C.c_int32), ('clip', C.c_int32),
@@ -86,6 +92,8 @@ SIGNATURES = {
     'ron_bboxes_decode_layer': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P,
                                           C.POINTER(C.c_float), _P, _P]),
     'ron_softmax_last': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P]),
+    'ron_post_eval_workspace_bytes': (C.c_int64, [C.POINTER(Heads), C.c_int]),
+    'ron_post_eval': (C.c_int, [C.POINTER(Heads), C.c_int, _P, C.POINTER(EvalCfg), _P, C.c_int64, C.POINTER(Detections), _P]),
     'ron_post_tfe_workspace_bytes': (C.c_int64, [C.POINTER(Heads), C.c_int]),
     'ron_preprocess_eval': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P, _P]),
     'ron_preprocess_eval_geom': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P, _P]),

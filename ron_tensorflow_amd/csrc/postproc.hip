@@ -909,7 +909,191 @@ __global__ __launch_bounds__(kTopkThreads) void tfe_topk_nms_kernel(HeadsDev hd,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// ron_eval.py variant (the reference's second, per-image harness): flaten_predict (ron_eval.py:111-144) ->
+// tfe.bboxes_clip -> filter_boxes (:369-392) -> tf_bboxes_nms (:146-206, class agnostic) -> bboxes_resize.
+// ------------------------------------------------------------------------------------------
+struct EvalDev {
+  float obj_thr, sel_thr, nms_thr;
+  int keep_top_k, nms_mode;
+  float ref[4];
+  float ps[4];
+  unsigned flags;
+  const float* min_size;     // [n] filter_boxes' min_size per image
+};
+
+__device__ __forceinline__ void eval_box(const HeadsDev& hd, const EvalDev& pc, int img, int layer, int local, float* box) {
+  TfeDev t;
+  t.flags = pc.flags; t.clip = 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { t.ref[i] = pc.ref[i]; t.ps[i] = pc.ps[i]; }
+  tfe_box(hd, t, img, layer, local, box);
+}
+
+// one thread per anchor: score[c] = objectness * class probability, label = argmax over ALL classes (first maximum),
+// kept when label > 0 and objectness > thres, the clipped box passes filter_boxes and score[label] > select_threshold.
+// key = (score, anchor * 64 + label): score descending, then the flattened anchor order like tf.nn.top_k.
+__global__ __launch_bounds__(kSelectThreads) void eval_select_kernel(HeadsDev hd, EvalDev pc, u64* keys, int* counts, int cap) {
+  extern __shared__ __attribute__((aligned(16))) float stage[];
+  const int img = blockIdx.y;
+  const int tid = threadIdx.x;
+  int layer = 0;
+#pragma unroll
+  for (int l = 1; l < RON_MAX_LAYERS; ++l)
+    if (l < hd.num_layers && (int)blockIdx.x >= hd.block_base[l]) layer = l;
+  const int C = hd.num_classes;
+  const int n_anchor_layer = hd.cells[layer] * hd.num_anchors[layer];
+  const int first = ((int)blockIdx.x - hd.block_base[layer]) * kSelectThreads;
+  const int n_here = min(kSelectThreads, n_anchor_layer - first);
+  const float* cls = hd.cls[layer] + ((size_t)img * n_anchor_layer + first) * C;
+  for (int i = tid; i < n_here * C; i += kSelectThreads) stage[i] = cls[i];
+  __syncthreads();
+  if (tid >= n_here) return;
+  const int local = first + tid;
+  float objp;
+  if (pc.flags & RON_IN_OBJ_IS_PROB) {
+    objp = hd.obj[layer][(size_t)img * n_anchor_layer + local];
+  } else {
+    const float2 o = *reinterpret_cast<const float2*>(hd.obj[layer] + ((size_t)img * n_anchor_layer + local) * 2);
+    const float m = fmaxf(o.x, o.y);
+    const float e0 = expf(o.x - m), e1 = expf(o.y - m);
+    objp = e1 / (e0 + e1);
+  }
+  if (!(objp > pc.obj_thr)) return;
+  const float* row = stage + tid * C;
+  const bool is_prob = (pc.flags & RON_IN_CLS_IS_PROB) != 0;
+  float sum = 1.f, mx = 0.f;
+  if (!is_prob) {
+    mx = row[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float sacc = 0.f;
+    for (int c = 0; c < C; ++c) sacc += expf(row[c] - mx);
+    sum = sacc;
+  }
+  int label = 0;
+  float best = objp * (is_prob ? row[0] : expf(row[0] - mx) / sum);
+  for (int c = 1; c < C; ++c) {
+    const float sc = objp * (is_prob ? row[c] : expf(row[c] - mx) / sum);
+    if (sc > best) { best = sc; label = c; }
+  }
+  if (label == 0 || !(best > pc.sel_thr)) return;
+  float box[4];
+  eval_box(hd, pc, img, layer, local, box);
+  const float ws = box[3] - box[1], hs = box[2] - box[0];
+  const float xc = box[1] + ws / 2.f, yc = box[0] + hs / 2.f;
+  const float ms = pc.min_size[img];
+  if (!(ws > ms && hs > ms && xc > 0.f && yc > 0.f && xc < 1.f && yc < 1.f)) return;
+  const int pos = atomicAdd(&counts[img * kCountStride], 1);
+  if (pos < cap) keys[(size_t)img * cap + pos] = make_key(best, (unsigned)(hd.anchor_base[layer] + local) * 64u + (unsigned)label);
+}
+
+constexpr int kEvalCand = 1024;     // NMS candidates of the ron_eval.py variant: one thread each
+
+__global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, EvalDev pc, const u64* keys, const int* counts,
+                                                                int cap, DetDev out) {
+  static_assert(kEvalCand == kTopkThreads && kSortCap >= kEvalCand + kEvalCand * 2, "one thread per candidate; boxes live behind the keys");
+  __shared__ ImageLds lds;
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = min(counts[img * kCountStride], cap);
+  const int n = topk_keys(keys + (size_t)img * cap, m, kEvalCand, lds);     // the kEvalCand highest scores, sorted
+  float* box = reinterpret_cast<float*>(&lds.sort[kEvalCand]);              // [kEvalCand][4]
+  u64* words = reinterpret_cast<u64*>(lds.hist);                            // alive bits, one word per wave
+  int* kept = lds.order;                                                    // sorted rows in pick order (<= kMaxTopK)
+  float my[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned my_p = 0;
+  if (tid < n) {
+    const u64 k = lds.sort[tid];
+    my_p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+    const int anchor = (int)(my_p >> 6);
+    int layer = 0;
+#pragma unroll
+    for (int l = 1; l < RON_MAX_LAYERS; ++l)
+      if (l < hd.num_layers && anchor >= hd.anchor_base[l]) layer = l;
+    eval_box(hd, pc, img, layer, anchor - hd.anchor_base[layer], my);
+  }
+  __syncthreads();                                                          // every key is read before boxes overwrite the tail
+  const float my_score = tid < n ? __uint_as_float((unsigned)(lds.sort[tid] >> 32)) : 0.f;
+  box[tid * 4 + 0] = my[0]; box[tid * 4 + 1] = my[1]; box[tid * 4 + 2] = my[2]; box[tid * 4 + 3] = my[3];
+  // greedy, class agnostic, in score order (ron_eval.py:187-203): pick the first live row, drop every live row it overlaps
+  bool alive = tid < n;
+  int n_kept = 0;
+  const int mode = pc.nms_mode == 1 ? 2 : 1;
+  for (int it = 0; it < pc.keep_top_k; ++it) {
+    const u64 bal = __ballot(alive);
+    if (lane == 0) words[wave] = bal;
+    __syncthreads();
+    int first = -1;
+#pragma unroll
+    for (int w = kTopkThreads / 64 - 1; w >= 0; --w)
+      if (words[w] != 0ull) first = w * 64 + __ffsll((long long)words[w]) - 1;
+    if (first < 0) break;
+    if (tid == first) { alive = false; kept[it] = first; }
+    n_kept = it + 1;
+    if (alive && tfe_suppresses(&box[first * 4], my, pc.nms_thr, mode)) alive = false;
+    __syncthreads();
+  }
+  __syncthreads();
+  const int total = min(n_kept, out.capacity);
+  const float sy = pc.ref[2] - pc.ref[0], sx = pc.ref[3] - pc.ref[1];
+  for (int i = tid; i < out.capacity; i += blockDim.x)
+    if (i >= total) {
+      const size_t o = (size_t)img * out.capacity + i;
+      out.classes[o] = 0; out.scores[o] = 0.f; out.anchor_index[o] = 0;
+      out.bboxes[o * 4 + 0] = 0.f; out.bboxes[o * 4 + 1] = 0.f; out.bboxes[o * 4 + 2] = 0.f; out.bboxes[o * 4 + 3] = 0.f;
+    }
+  // scores / labels of the kept rows: row r's thread still holds them
+  for (int pos = 0; pos < total; ++pos)
+    if (kept[pos] == tid) {
+      const size_t o = (size_t)img * out.capacity + pos;
+      out.classes[o] = (int)(my_p & 63u);
+      out.scores[o] = my_score;
+      out.anchor_index[o] = (int)(my_p >> 6);
+      out.bboxes[o * 4 + 0] = (my[0] - pc.ref[0]) / sy;      // tfe.bboxes_resize, tf_extended/bboxes.py:147-171
+      out.bboxes[o * 4 + 1] = (my[1] - pc.ref[1]) / sx;
+      out.bboxes[o * 4 + 2] = (my[2] - pc.ref[0]) / sy;
+      out.bboxes[o * 4 + 3] = (my[3] - pc.ref[1]) / sx;
+    }
+  if (tid == 0) out.count[img] = total;
+}
+
 }  // namespace
+
+extern "C" int64_t ron_post_eval_workspace_bytes(const ron_heads* heads, int n) {
+  HeadsDev hd;
+  if (build_heads_dev(heads, &hd, false) != RON_OK || n <= 0) return -1;
+  return ron::align_up((int64_t)n * kCountStride * 4, 256) + (int64_t)n * hd.anchor_base[RON_MAX_LAYERS] * 8;
+}
+
+extern "C" int ron_post_eval(const ron_heads* heads, int n, const float* min_sizes, const ron_eval_cfg* cfg, void* workspace,
+                             int64_t workspace_bytes, ron_detections* out, void* stream) {
+  RON_REQUIRE(cfg != nullptr && n > 0 && out != nullptr && min_sizes != nullptr, "bad argument");
+  RON_REQUIRE(cfg->keep_top_k >= 1 && cfg->keep_top_k <= kMaxTopK, "keep_top_k %d not in [1, %d]", cfg->keep_top_k, kMaxTopK);
+  RON_REQUIRE(cfg->nms_mode == 0 || cfg->nms_mode == 1, "unknown mode to use for nms.");
+  RON_REQUIRE(heads != nullptr && heads->num_classes <= 64, "num_classes must be <= 64");
+  HeadsDev hd;
+  int rc = build_heads_dev(heads, &hd, (cfg->input_flags & RON_IN_LOC_DECODED) == 0);
+  if (rc != RON_OK) return rc;
+  for (int i = 0; i < hd.num_layers; ++i) RON_REQUIRE(hd.obj[i] != nullptr, "ron_post_eval needs the objectness tensors");
+  DetDev d_out;
+  if ((rc = to_det_dev(out, &d_out, cfg->keep_top_k, "out", false))) return rc;
+  const int64_t need = ron_post_eval_workspace_bytes(heads, n);
+  RON_REQUIRE(workspace != nullptr && workspace_bytes >= need, "workspace too small: %lld < %lld", (long long)workspace_bytes, (long long)need);
+  EvalDev pc;
+  pc.obj_thr = cfg->objectness_thres; pc.sel_thr = cfg->select_threshold; pc.nms_thr = cfg->nms_threshold;
+  pc.keep_top_k = cfg->keep_top_k; pc.nms_mode = cfg->nms_mode; pc.flags = cfg->input_flags; pc.min_size = min_sizes;
+  for (int i = 0; i < 4; ++i) { pc.ref[i] = cfg->bbox_img[i]; pc.ps[i] = cfg->prior_scaling[i]; }
+  hipStream_t s = (hipStream_t)stream;
+  int* counts = (int*)workspace;
+  const int64_t cbytes = ron::align_up((int64_t)n * kCountStride * 4, 256);
+  u64* keys = (u64*)((char*)workspace + cbytes);
+  const int cap = hd.anchor_base[RON_MAX_LAYERS];
+  RON_HIP_CHECK(hipMemsetAsync(counts, 0, cbytes, s));
+  const size_t lds = (size_t)kSelectThreads * hd.num_classes * sizeof(float);
+  hipLaunchKernelGGL(eval_select_kernel, dim3(hd.block_base[RON_MAX_LAYERS], n), dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
+  hipLaunchKernelGGL(eval_nms_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, d_out);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
 
 extern "C" int64_t ron_post_tfe_workspace_bytes(const ron_heads* heads, int n) {
   HeadsDev hd;
