@@ -172,14 +172,15 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * RB > 80 * 1024) ? (W
       }                                                                                                              \
       if ((i_) < A_IT)                                                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst + (i_) * kRowsPerIt * kRowBytes), 16,         \
-                                                 a_voff[(i_) < A_IT ? (i_) : 0], a_soff, 0, 0);                      \
+                                                 a_voff[(i_) < A_IT ? (i_) : 0], a_soff, 0, ABL == 11 ? 2 : 0);      \
       else                                                                                                           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(dst + kABytes + ((i_) - A_IT) * kRowsPerIt * kRowBytes), 16, \
-                                                 b_voff[(i_) >= A_IT ? (i_) - A_IT : 0], b_soff, 0, 0);              \
+                                                 b_voff[(i_) >= A_IT ? (i_) - A_IT : 0], b_soff, 0,                  \
+                                                 (ABL == 10 || ABL == 11 || ABL == 12) ? 2 : 0);                     \
     } while (0)
 #define RON_STAGE_END()                                                                                              \
     do {                                                                                                             \
-      if (ABL == 8) { /* timing-only: taps innermost, channel chunk outermost (weights are not in that order) */     \
+      if (ABL == 8 || ABL == 12) { /* timing-only: taps innermost, channel chunk outermost (weights are not in that order) */     \
         if (++kx == p.kw) { kx = 0; if (++ky * p.kw >= p.KT * kChunkElems / p.Cin) { ky = 0; cc += kChunkElems; } }  \
         break;                                                                                                       \
       }                                                                                                              \
@@ -590,6 +591,9 @@ constexpr TileCfg kCfgs[] = {
     {128, 128, 2, 2, 2, 2, 128, 16},   // 58: 36 likewise
     {128, 64, 2, 2, 2, 2, 128, 16},    // 59: 37 likewise
     {256, 256, 4, 2, 2, 2, 128, 16},   // 60: 35 likewise
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 61: 30 with non-temporal (aux 2) weight loads            (results valid)
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 62: 30 with non-temporal weight AND activation loads    (results valid)
+    {256, 256, 4, 2, 2, 1, 128, 16},   // 63: diagnostic (timing only): taps innermost + non-temporal weight loads
 };
 constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 // workgroups of configuration i the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
@@ -673,6 +677,9 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case 58: return launch_t<typename SmallShape<Tr>::type, 128, 128, 2, 2, 2, 2, 0, 128, 2>(a, s);
     case 59: return launch_t<typename SmallShape<Tr>::type, 128, 64, 2, 2, 2, 2, 0, 128, 2>(a, s);
     case 60: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 2, 0, 128, 2>(a, s);
+    case 61: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 10>(a, s);
+    case 62: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 11>(a, s);
+    case 63: return launch_t<typename SmallShape<Tr>::type, 256, 256, 4, 2, 2, 1, 12>(a, s);
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;

@@ -119,11 +119,11 @@ def test_maxpool(ops, dev, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 20, 21, 22, 23, 24, 26, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 51, 52, 53, 56, 57, 58, 59, 60])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 20, 21, 22, 23, 24, 26, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 51, 52, 53, 56, 57, 58, 59, 60, 61, 62])
 def test_every_tile_configuration(ops, dev, cfg, dtype):
     """Each (tile, wave grid, stage count) variant of the kernel on a ragged multi-tile problem, K = 18 steps."""
     from ron_tensorflow_amd import _lib
-    assert _lib.lib().ron_conv_num_tile_cfgs() == 61
+    assert _lib.lib().ron_conv_num_tile_cfgs() == 64
     rs = np.random.RandomState(40 + cfg)
     x = rs.randn(3, 13, 11, 128).astype(np.float32)            # M = 429: two 256-row or four 128-row tiles, ragged
     wt = (rs.randn(3, 3, 128, 192) * 0.03).astype(np.float32)  # Cout 192 -> padded to 256
