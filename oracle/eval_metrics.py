@@ -104,3 +104,40 @@ def average_precision_voc12(precision, recall):
     r = np.concatenate([[0.0], np.asarray(recall, np.float64), [1.0]])
     p = np.maximum.accumulate(p[::-1])[::-1]
     return float(np.sum(p[1:] * (r[1:] - r[:-1])))
+
+
+def voc_eval_class(image_ids, confidence, boxes, gt_boxes, gt_difficult, ovthresh=0.5, use_07_metric=True):
+    """datasets/voc_eval.py:224-295 (one class) on arrays: **pinned** by tests/golden/g7_voc_eval.npz, which the reference's own
+    ``DetectorEvalPascal.voc_eval`` produced from files holding these arrays."""
+    n = len(image_ids)
+    if n == 0:
+        return -1., -1., -1.
+    conf = np.asarray(confidence, np.float64)
+    bbs = np.asarray(boxes, np.float64).reshape(-1, 4)
+    npos = sum(int((~np.asarray(d, bool)).sum()) for d in gt_difficult.values())
+    used = {k: [False] * len(v) for k, v in gt_difficult.items()}
+    order = np.argsort(-conf)
+    tp, fp = np.zeros(n), np.zeros(n)
+    for d, o in enumerate(order):
+        img, bb = int(image_ids[o]), bbs[o]
+        g = np.asarray(gt_boxes.get(img, []), np.float64).reshape(-1, 4)
+        ovmax, jmax = -np.inf, -1
+        if g.size:
+            iw = np.maximum(np.minimum(g[:, 2], bb[2]) - np.maximum(g[:, 0], bb[0]), 0.)
+            ih = np.maximum(np.minimum(g[:, 3], bb[3]) - np.maximum(g[:, 1], bb[1]), 0.)
+            inter = iw * ih
+            ov = inter / ((bb[2] - bb[0]) * (bb[3] - bb[1]) + (g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1]) - inter)
+            ovmax, jmax = ov.max(), int(ov.argmax())
+        if ovmax > ovthresh:
+            if not gt_difficult[img][jmax]:
+                if not used[img][jmax]:
+                    tp[d] = 1.
+                    used[img][jmax] = True
+                else:
+                    fp[d] = 1.
+        else:
+            fp[d] = 1.
+    fp, tp = np.cumsum(fp), np.cumsum(tp)
+    rec = tp / float(npos)
+    prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+    return rec, prec, (average_precision_voc07 if use_07_metric else average_precision_voc12)(prec, rec)

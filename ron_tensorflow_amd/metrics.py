@@ -116,6 +116,49 @@ def average_precision_voc07(precision, recall):
     return ap
 
 
+def voc_eval_class(image_ids, confidence, boxes, gt_boxes, gt_difficult, ovthresh=0.5, use_07_metric=True):
+    """The PASCAL evaluation of ONE class as ``ron_eval.py`` runs it (datasets/voc_eval.py:164-295), on arrays instead of files:
+    image_ids [D] int, confidence [D], boxes [D, 4] (x1, y1, x2, y2, pixels) of the detections; gt_boxes / gt_difficult: dicts
+    image id -> [G, 4] / [G] of this class's ground truth (as parse_rec returns it: XML values minus one).
+    Returns (recall [D], precision [D], ap), or (-1., -1., -1.) when there is no detection, like the reference."""
+    image_ids = np.asarray(image_ids).reshape(-1)
+    if image_ids.shape[0] == 0:
+        return -1., -1., -1.
+    confidence = np.asarray(confidence, np.float64).reshape(-1)
+    bb_all = np.asarray(boxes, np.float64).reshape(-1, 4)
+    npos = int(sum(int(np.sum(~np.asarray(d).astype(bool))) for d in gt_difficult.values()))
+    det = {k: np.zeros(len(np.asarray(v).reshape(-1)), bool) for k, v in gt_difficult.items()}
+    order = np.argsort(-confidence)
+    nd = order.shape[0]
+    tp, fp = np.zeros(nd), np.zeros(nd)
+    for d in range(nd):
+        img = int(image_ids[order[d]])
+        bb = bb_all[order[d]]
+        bbgt = np.asarray(gt_boxes.get(img, np.zeros((0, 4))), np.float64).reshape(-1, 4)
+        ovmax, jmax = -np.inf, -1
+        if bbgt.size > 0:
+            iw = np.maximum(np.minimum(bbgt[:, 2], bb[2]) - np.maximum(bbgt[:, 0], bb[0]), 0.)
+            ih = np.maximum(np.minimum(bbgt[:, 3], bb[3]) - np.maximum(bbgt[:, 1], bb[1]), 0.)
+            inters = iw * ih
+            uni = (bb[2] - bb[0]) * (bb[3] - bb[1]) + (bbgt[:, 2] - bbgt[:, 0]) * (bbgt[:, 3] - bbgt[:, 1]) - inters
+            overlaps = inters / uni
+            ovmax, jmax = np.max(overlaps), int(np.argmax(overlaps))
+        if ovmax > ovthresh:
+            if not np.asarray(gt_difficult[img]).astype(bool)[jmax]:
+                if not det[img][jmax]:
+                    tp[d] = 1.
+                    det[img][jmax] = True
+                else:
+                    fp[d] = 1.
+        else:
+            fp[d] = 1.
+    fp, tp = np.cumsum(fp), np.cumsum(tp)
+    rec = tp / float(npos)
+    prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+    ap = average_precision_voc07(prec, rec) if use_07_metric else average_precision_voc12(prec, rec)
+    return rec, prec, ap
+
+
 def evaluate(stream, voc07=True, voc12=True):
     """eval_ron_network.py:289-335: per-class AP and mAP from a StreamingTpFp.  Returns dict name -> value with the
     reference's summary names ('AP_VOC07/<c>', 'AP_VOC07/mAP', ...)."""

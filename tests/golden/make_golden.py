@@ -101,6 +101,72 @@ def g6_voc_ap():
     np.savez_compressed(os.path.join(HERE, 'g6_voc_ap.npz'), **out)
 
 
+def g7_voc_eval():
+    """The reference's numpy VOC evaluation (datasets/voc_eval.py:164-295) run on a small synthetic VOC tree written to a temp
+    directory: XML annotations + per-class detection files in, (recall, precision, AP07, AP12) per class out.  The arrays the
+    files held (as parsed back by the reference) are stored as the inputs."""
+    import tempfile
+    sys.modules.setdefault('cv2', mock.MagicMock(name='cv2'))
+    from datasets import voc_eval
+    rs = np.random.RandomState(77)
+    classes = ['aeroplane', 'bicycle', 'bird']
+    n_img = 12
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        voc = os.path.join(root, 'VOC2007')
+        for d in ('Annotations', 'ImageSets/Main', 'JPEGImages'):
+            os.makedirs(os.path.join(voc, d))
+        names = ['%06d' % (i + 1) for i in range(n_img)]
+        with open(os.path.join(voc, 'ImageSets', 'Main', 'test.txt'), 'w') as f:
+            f.write('\n'.join(names) + '\n')
+        gt = []                                         # (image, class, difficult, xmin, ymin, xmax, ymax) as written to the XML
+        for i, name in enumerate(names):
+            objs = []
+            for _ in range(rs.randint(0, 5)):
+                c = rs.randint(0, 3)
+                x1, y1 = rs.randint(1, 300), rs.randint(1, 200)
+                w, h = rs.randint(20, 150), rs.randint(20, 150)
+                diff = int(rs.rand() < 0.25)
+                objs.append((c, diff, x1, y1, x1 + w, y1 + h))
+                gt.append((i, c, diff, x1, y1, x1 + w, y1 + h))
+            xml = '<annotation>' + ''.join(
+                '<object><name>%s</name><pose>Unspecified</pose><truncated>0</truncated><difficult>%d</difficult>'
+                '<bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>'
+                % (classes[c], d, a, b, cc, dd) for (c, d, a, b, cc, dd) in objs) + '</annotation>'
+            with open(os.path.join(voc, 'Annotations', name + '.xml'), 'w') as f:
+                f.write(xml)
+        out['gt'] = np.array(gt, np.int64).reshape(-1, 7)
+        ev = voc_eval.DetectorEvalPascal(root, root, set_type='test', output_dir=os.path.join(root, 'out_{}'))
+        for ci, cname in enumerate(classes):
+            # detections: jittered ground truth of this class (some duplicated), boxes of other classes, random boxes
+            dets = []
+            for (i, c, d, a, b, cc, dd) in gt:
+                reps = rs.randint(0, 3) if c == ci else (1 if rs.rand() < 0.3 else 0)
+                for _ in range(reps):
+                    j = rs.randint(-25, 26, 4) if rs.rand() < 0.3 else rs.randint(-6, 7, 4)
+                    dets.append((i, a + j[0], b + j[1], cc + j[2], dd + j[3]))
+            for _ in range(10):
+                i = rs.randint(0, n_img)
+                x1, y1 = rs.randint(1, 300), rs.randint(1, 200)
+                dets.append((i, x1, y1, x1 + rs.randint(10, 120), y1 + rs.randint(10, 120)))
+            scores = rs.permutation(np.arange(1, 1000))[:len(dets)] / 1000.0        # unique at the 3 decimals the file keeps
+            detfile = os.path.join(root, 'det_test_%s.txt' % cname)
+            with open(detfile, 'w') as f:
+                for (i, a, b, cc, dd), sc in zip(dets, scores):
+                    f.write('{:s} {:.3f} {:.1f} {:.1f} {:.1f} {:.1f}\n'.format(names[i], sc, a, b, cc, dd))
+            cache = os.path.join(root, 'cache_%d' % ci)
+            for use07 in (True, False):
+                rec, prec, ap = ev.voc_eval(os.path.join(root, 'det_test_{}.txt'), cname, cache, ovthresh=0.5, use_07_metric=use07)
+                out['rec_%d' % ci], out['prec_%d' % ci] = np.asarray(rec, np.float64), np.asarray(prec, np.float64)
+                out['ap%s_%d' % ('07' if use07 else '12', ci)] = np.float64(ap)
+            out['det_%d' % ci] = np.array([(i, a, b, cc, dd) for (i, a, b, cc, dd) in dets], np.float64).reshape(-1, 5)
+            out['score_%d' % ci] = np.array([float('%.3f' % sc) for sc in scores], np.float64)
+        # an empty detection file: the reference returns -1 for everything
+        with open(os.path.join(root, 'det_test_empty.txt'), 'w') as f:
+            pass
+    np.savez_compressed(os.path.join(HERE, 'g7_voc_eval.npz'), **out)
+
+
 def g2_decode(npm, anchors):
     out = {'seed': np.int64(11)}
     rs = np.random.RandomState(11)
@@ -240,6 +306,7 @@ def main():
     anchors = g1_anchors(ron)
     g5_anchors_ssd(ron)
     g6_voc_ap()
+    g7_voc_eval()
     g2_decode(npm, anchors)
     g3_pipeline(npm, anchors)
     g4_edge(npm)

@@ -80,3 +80,26 @@ def test_no_ground_truth_and_no_detections():
     z = np.zeros((0,))
     assert em.average_precision_voc12(z, z) == 0.
     assert metrics.average_precision_voc07(z, z) == 0.
+
+
+GOLD7 = os.path.join(os.path.dirname(__file__), 'golden', 'g7_voc_eval.npz')
+
+
+@pytest.mark.parametrize('cls', range(3))
+def test_voc_eval_vs_reference(cls):
+    """Oracle and host metric vs what the reference's DetectorEvalPascal.voc_eval returned for the same detections / XML
+    ground truth (tests/golden/make_golden.py::g7_voc_eval): recall and precision arrays and both APs, exactly."""
+    g = np.load(GOLD7)
+    gt = g['gt']                                     # (image, class, difficult, xmin, ymin, xmax, ymax) as in the XML
+    gt_boxes, gt_diff = {}, {}
+    for i in range(12):
+        rows = gt[(gt[:, 0] == i) & (gt[:, 1] == cls)]
+        gt_boxes[i] = (rows[:, 3:7] - 1).astype(np.float64)          # parse_rec subtracts one (voc_eval.py:67-70)
+        gt_diff[i] = rows[:, 2].astype(bool)
+    det = g['det_%d' % cls]
+    for fn in (em.voc_eval_class, metrics.voc_eval_class):
+        for use07, key in ((True, 'ap07_%d'), (False, 'ap12_%d')):
+            rec, prec, ap = fn(det[:, 0].astype(int), g['score_%d' % cls], det[:, 1:5], gt_boxes, gt_diff, 0.5, use07)
+            assert np.array_equal(rec, g['rec_%d' % cls]) and np.array_equal(prec, g['prec_%d' % cls])
+            assert abs(ap - float(g[key % cls])) < 1e-15
+    assert metrics.voc_eval_class([], [], np.zeros((0, 4)), gt_boxes, gt_diff) == (-1., -1., -1.)
