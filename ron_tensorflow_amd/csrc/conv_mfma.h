@@ -66,6 +66,7 @@ int launch_stem_conv(const float* x, int n, int h, int w, int dtype, const void*
 
 // conv1_1 + conv1_2 + pool1 fused (stem.hip): image -> pool1, bf16 / f16 only
 void stem2_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* lds_image);
+void stem2_pack_w1(const float* hwio, int dtype, std::vector<uint16_t>* frags);
 int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w1frag, const float* d_bias1,
                  const void* d_w2img, const float* d_bias2, const TensorView& out, hipStream_t s);
 

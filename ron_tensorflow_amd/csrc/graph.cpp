@@ -109,6 +109,7 @@ struct ron_ctx {
   void* d_stem_w = nullptr;             // conv1_1 fragments + bias for the dedicated stem kernel (bf16 / f16)
   float* d_stem_b = nullptr;
   void* d_stem2_w = nullptr;            // conv1_2 weights as the LDS image of stem2_kernel (conv1_1 + conv1_2 + pool1 fused)
+  void* d_stem2_w1 = nullptr;           // conv1_1 weights as 16x16x32 fragments for stem2_kernel
   float* d_stem2_b = nullptr;
   void* d_splitk[4] = {};               // fp32 slabs of the split-K launches, one set per stream lane
   int64_t splitk_bytes[4] = {};
@@ -518,7 +519,7 @@ extern "C" int ron_destroy(ron_ctx* c) {
   if (borrowed) {                        // the weights belong to the owner
     --c->weights_owner->clones;
     c->packed.clear();
-    c->d_l2_gamma = nullptr; c->d_stem_w = nullptr; c->d_stem_b = nullptr; c->d_stem2_w = nullptr; c->d_stem2_b = nullptr;
+    c->d_l2_gamma = nullptr; c->d_stem_w = nullptr; c->d_stem_b = nullptr; c->d_stem2_w = nullptr; c->d_stem2_b = nullptr; c->d_stem2_w1 = nullptr;
   }
   for (auto& t : c->tensors) if (t.d) (void)hipFree(t.d);
   for (auto& p : c->packed) { if (p.d_w) (void)hipFree(p.d_w); if (p.d_bias) (void)hipFree(p.d_bias); }
@@ -538,6 +539,7 @@ extern "C" int ron_destroy(ron_ctx* c) {
   if (c->d_stem_b) (void)hipFree(c->d_stem_b);
   if (c->d_stem2_w) (void)hipFree(c->d_stem2_w);
   if (c->d_stem2_b) (void)hipFree(c->d_stem2_b);
+  if (c->d_stem2_w1) (void)hipFree(c->d_stem2_w1);
   delete c;
   return RON_OK;
 }
@@ -630,6 +632,10 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
         RON_HIP_CHECK(hipMemcpy(c->d_stem2_w, img.data(), img.size() * 2, hipMemcpyHostToDevice));
         RON_HIP_CHECK(hipMalloc((void**)&c->d_stem2_b, 64 * sizeof(float)));
         RON_HIP_CHECK(hipMemcpy(c->d_stem2_b, c->var("conv1/conv1_2/biases").data.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
+        // conv1_1 as 16x16x32 fragments for the fused kernel (the stand-alone stem kernel keeps its 32x32 fragments in d_stem_w)
+        stem2_pack_w1(c->var("conv1/conv1_1/weights").data.data(), c->cfg.dtype, &img);
+        RON_HIP_CHECK(hipMalloc(&c->d_stem2_w1, img.size() * 2));
+        RON_HIP_CHECK(hipMemcpy(c->d_stem2_w1, img.data(), img.size() * 2, hipMemcpyHostToDevice));
         Op f; f.kind = OP_STEM2; f.name = "conv1_1+conv1_2+pool1"; f.out = T(pname);
         f.flops = c->ops[n_ops - 2].flops + c->ops[n_ops - 1].flops;
         c->ops.pop_back(); c->ops.pop_back();
@@ -841,7 +847,7 @@ extern "C" int ron_clone(ron_ctx* src, ron_ctx** out) {
   c->packed = owner->packed;
   c->ops = owner->ops;
   c->d_l2_gamma = owner->d_l2_gamma; c->d_stem_w = owner->d_stem_w; c->d_stem_b = owner->d_stem_b;
-  c->d_stem2_w = owner->d_stem2_w; c->d_stem2_b = owner->d_stem2_b;
+  c->d_stem2_w = owner->d_stem2_w; c->d_stem2_b = owner->d_stem2_b; c->d_stem2_w1 = owner->d_stem2_w1;
   c->flops_per_image = owner->flops_per_image;
   c->weights_owner = owner;
   ++owner->clones;
@@ -914,7 +920,7 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
       if ((rc = launch_stem_conv(d_images, n, t.H, t.W, c->cfg.dtype, c->d_stem_w, c->d_stem_b, c->view(o.out, n), s))) return rc;
     } else if (o.kind == OP_STEM2) {
       const Tensor& t = c->tensors[o.out];
-      if ((rc = launch_stem2(d_images, n, 2 * t.H, 2 * t.W, c->cfg.dtype, c->d_stem_w, c->d_stem_b, c->d_stem2_w, c->d_stem2_b,
+      if ((rc = launch_stem2(d_images, n, 2 * t.H, 2 * t.W, c->cfg.dtype, c->d_stem2_w1, c->d_stem_b, c->d_stem2_w, c->d_stem2_b,
                              c->view(o.out, n), s))) return rc;
     } else if (o.kind == OP_POOL) {
       if ((rc = launch_maxpool2x2(c->view(o.in, n), c->view(o.out, n), c->cfg.dtype, s))) return rc;

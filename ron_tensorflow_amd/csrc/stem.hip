@@ -12,6 +12,8 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include <stdlib.h>
+
 #include <vector>
 
 #include "pack.h"
@@ -23,6 +25,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 struct StemBF16 {
   static __device__ __forceinline__ unsigned short cvt(float v) { return __builtin_bit_cast(unsigned short, __float2bfloat16(v)); }
@@ -30,12 +34,18 @@ struct StemBF16 {
   static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
   }
+  static __device__ __forceinline__ void mma16(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+  }
 };
 struct StemF16 {
   static __device__ __forceinline__ unsigned short cvt(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
   static __device__ __forceinline__ float tof(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)v); }
   static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void mma16(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
   }
 };
 
@@ -143,7 +153,9 @@ template <class Tr>
 __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x, int n_img, int H, int W,
                                                     const u32x4* __restrict__ w1frag, const float* __restrict__ bias1,
                                                     const u32x4* __restrict__ w2img, const float* __restrict__ bias2,
-                                                    unsigned short* __restrict__ out, int out_Hp, int out_Wp, int out_pad) {
+                                                    unsigned short* __restrict__ out, int out_Hp, int out_Wp, int out_pad,
+                                                    int abl) {
+  // abl (diagnostic, RON_STEM2_ABL): 1 = skip conv1_1 (phase B), 2 = skip the tap loop (phase C), 4 = skip pooling / stores
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_w2 = smem;
   char* s_p = s_w2 + kS2W2Bytes;
@@ -154,23 +166,43 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
 
   // conv1_2 weights: the host packed the exact LDS image (tap, permuted output row, swizzled 16-byte chunks)
   for (int i = tid; i < kS2W2Bytes / 16; i += 512) reinterpret_cast<u32x4*>(s_w2)[i] = w2img[i];
-  // conv1_1 weights in registers, as in stem_conv_kernel
-  u32x4 wb[2][2];
+  // conv1_1 runs on 16x16x32 MFMAs (K = 27 -> 32 is ONE instruction): groups of 16 patch pixels, so the 340-pixel patch splits
+  // 3 / 3 / ... over the 8 waves instead of 2 / 1 groups of 32.  Weights in registers: n-tile t, lane (c = l & 15, kg = l >> 4)
+  // holds W[k = 8 kg + j][channel 4c + t]: a lane's four accumulators are adjacent channels (one 8-byte LDS store per pixel).
+  const int c16 = lane & 15, kg = lane >> 4;
+  u32x4 wb[4];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < 4; ++t) wb[t] = w1frag[t * 64 + lane];
+  float b1[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) wb[t][s] = w1frag[(t * 2 + s) * 64 + lane];
-  const float b1_0 = bias1[2 * r], b1_1 = bias1[2 * r + 1];
+  for (int t = 0; t < 4; ++t) b1[t] = bias1[4 * c16 + t];
   const float b2_0 = bias2[2 * r], b2_1 = bias2[2 * r + 1];
-  int a_off[2][8];
+  int a_off[8];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * kg + j;
+    const int ty = k / 9, rem = k - ty * 9;
+    a_off[j] = k < 27 ? ty * (kS2IW * 3) + rem : -1;               // rem = tx*3 + c
+  }
+  // phase B bookkeeping is the same for every tile: this wave's (up to three) groups of 16 patch pixels, the gather base of the
+  // lane's pixel, and per accumulator register the LDS store offset + patch coordinates of the pixel it holds
+  // (bits 0-15 offset, 16-19 patch row, 20-25 patch column, 31 = past the patch)
+  constexpr int kGroups16 = (kS2Rows + 15) / 16;                    // 22
+  int gb[3];
+  unsigned st[3][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = 16 * s + 8 * h + j;
-      const int ty = k / 9, rem = k - ty * 9;
-      a_off[s][j] = k < 27 ? ty * (kS2IW * 3) + rem : -1;           // rem = tx*3 + c
+  for (int gi = 0; gi < 3; ++gi) {
+    const int g = wave + 8 * gi;
+    const int q = min(g * 16 + c16, kS2Rows - 1);
+    gb[gi] = ((q / kS2PW) * kS2IW + q % kS2PW) * 3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int qq = g * 16 + 4 * kg + e;
+      const int qy = qq / kS2PW, qx = qq - qy * kS2PW;
+      const unsigned off = (unsigned)(qq * 128 + ((((c16 >> 1) ^ ((qq >> 1) & 7))) << 4) + (c16 & 1) * 8);
+      st[gi][e] = qq < kS2Rows ? (off | ((unsigned)qy << 16) | ((unsigned)qx << 20)) : 0x80000000u;
     }
+  }
   const int tiles_x = W / kS2TW, tiles_y = H / kS2TH;
   const int n_tiles = n_img * tiles_y * tiles_x;
   // ---- A: image patch (rows y0-2 .. y0+9, columns x0-2 .. x0+33) of a tile: 1296 floats, <= 3 per thread.  The patch of
@@ -209,37 +241,31 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
     const int y0 = ty_ * kS2TH, x0 = tx * kS2TW;
     RON_S2_FETCH(tile + gridDim.x);                   // in flight during phase B
     // ---- B: conv1_1 of the 340 patch pixels, 32 at a time
-    for (int g = wave; g * 32 < kS2Rows; g += 8) {
-      const int q = min(g * 32 + r, kS2Rows - 1);
-      const int py = q / kS2PW, px = q - py * kS2PW;
-      const float* base = s_img + (py * kS2IW + px) * 3;
-      u32x4 fa[2];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        unsigned short e[8];
+    for (int gi = 0; gi < 3; ++gi) {
+      if (wave + 8 * gi >= kGroups16 || (abl & 1)) break;              // wave-uniform
+      const float* base = s_img + gb[gi];
+      unsigned short ev[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = Tr::cvt(a_off[s][j] >= 0 ? base[a_off[s][j]] : 0.f);
-        fa[s] = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
-                      (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
-      }
-      f32x16 acc[2];
+      for (int j = 0; j < 8; ++j) ev[j] = Tr::cvt(a_off[j] >= 0 ? base[a_off[j]] : 0.f);
+      const u32x4 fa = u32x4{(unsigned)ev[0] | ((unsigned)ev[1] << 16), (unsigned)ev[2] | ((unsigned)ev[3] << 16),
+                             (unsigned)ev[4] | ((unsigned)ev[5] << 16), (unsigned)ev[6] | ((unsigned)ev[7] << 16)};
+      f32x4 acc[4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-        Tr::mma(fa[0], wb[t][0], acc[t]);
-        Tr::mma(fa[1], wb[t][1], acc[t]);
+      for (int t = 0; t < 4; ++t) {
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Tr::mma16(fa, wb[t], acc[t]);
       }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int qq = g * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (qq >= kS2Rows) continue;
-        const int qy = qq / kS2PW, qx = qq - qy * kS2PW;
-        const int iy = y0 - 1 + qy, ix = x0 - 1 + qx;
-        const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const unsigned lo = Tr::cvt(inside ? fmaxf(acc[0][e] + b1_0, 0.f) : 0.f);
-        const unsigned hi = Tr::cvt(inside ? fmaxf(acc[1][e] + b1_1, 0.f) : 0.f);
-        *reinterpret_cast<unsigned*>(s_p + qq * 128 + ((((r >> 2) ^ ((qq >> 1) & 7))) << 4) + (r & 3) * 4) = lo | (hi << 16);
+      for (int e = 0; e < 4; ++e) {
+        const unsigned m = st[gi][e];
+        if (m & 0x80000000u) continue;
+        const int iy = y0 - 1 + (int)((m >> 16) & 15u), ix = x0 - 1 + (int)((m >> 20) & 63u);
+        const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        unsigned v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = Tr::cvt(inside ? fmaxf(acc[t][e] + b1[t], 0.f) : 0.f);
+        *reinterpret_cast<u32x2*>(s_p + (m & 0xFFFFu)) = u32x2{v[0] | (v[1] << 16), v[2] | (v[3] << 16)};
       }
     }
     __syncthreads();
@@ -253,6 +279,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
     const int key_b = (r >> 1) & 7;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+      if (abl & 2) break;
       const int prow = (wave + tap / 3) * kS2PW + r + tap % 3;
       const char* pa = s_p + prow * 128;
       const int key_a = (prow >> 1) & 7;
@@ -278,7 +305,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
         *reinterpret_cast<unsigned*>(s_pool + (wave * 16 + m) * 128 + r * 4) = (unsigned)Tr::cvt(m0) | ((unsigned)Tr::cvt(m1) << 16);
       }
     __syncthreads();
-    {
+    if (!(abl & 4)) {
       const int yp = tid >> 7, m = (tid >> 3) & 15, c8 = tid & 7;     // 4 pooled rows x 16 columns x 8 chunks of 8 channels
       const u32x4 a = *reinterpret_cast<const u32x4*>(s_pool + ((2 * yp) * 16 + m) * 128 + c8 * 16);
       const u32x4 b = *reinterpret_cast<const u32x4*>(s_pool + ((2 * yp + 1) * 16 + m) * 128 + c8 * 16);
@@ -335,6 +362,19 @@ int launch_stem_conv(const float* x, int n, int h, int w, int dtype, const void*
 
 namespace ron {
 
+// conv1_1 weight fragments for stem2_kernel (16x16x32 MFMA) from the HWIO [3,3,3,64] filter: n-tile t, lane (c, kg), element j
+// holds W[k = 8 kg + j][channel 4c + t] (zero for k >= 27).
+void stem2_pack_w1(const float* hwio, int dtype, std::vector<uint16_t>* frags) {
+  frags->assign(4 * 64 * 8, 0);
+  for (int t = 0; t < 4; ++t)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int j = 0; j < 8; ++j) {
+        const int c = lane & 15, kg = lane >> 4, k = 8 * kg + j, ch = 4 * c + t;
+        const float v = k < 27 ? hwio[(size_t)k * 64 + ch] : 0.f;
+        (*frags)[((size_t)t * 64 + lane) * 8 + j] = dtype == RON_DTYPE_BF16 ? f32_to_bf16_rne(v) : f32_to_f16_rne(v);
+      }
+}
+
 // LDS image of the conv1_2 weights for stem2_kernel from the HWIO [3,3,64,64] filter: tap-major, row (j*32 + r) of a tap
 // holds output channel 2r + j, 64 input channels = 8 chunks of 16 B, chunk c in slot c ^ ((row >> 1) & 7).
 void stem2_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* img) {
@@ -357,6 +397,7 @@ int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w
               "stem2 kernel: bad shape");
   const int tiles = n * (h / kS2TH) * (w / kS2TW);
   const int grid = std::min(tiles, 256);
+  static const int abl = getenv("RON_STEM2_ABL") ? atoi(getenv("RON_STEM2_ABL")) : 0;
   static bool attr_set[2] = {false, false};
   const int which = dtype == RON_DTYPE_BF16 ? 0 : 1;
   if (!attr_set[which]) {
@@ -366,10 +407,10 @@ int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w
   }
   if (which == 0)
     hipLaunchKernelGGL(stem2_kernel<StemBF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
-                       (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad);
+                       (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad, abl);
   else
     hipLaunchKernelGGL(stem2_kernel<StemF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
-                       (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad);
+                       (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad, abl);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
