@@ -15,15 +15,15 @@ class Ticket(object):
     ``release()`` (optional) marks, on the current stream, the point after which the detections are no longer read -
     without it the buffers are simply assumed free by the time they come round again."""
 
-    def __init__(self, detections, done, consumed):
-        self.detections, self._done, self._consumed = detections, done, consumed
+    def __init__(self, detections, done, on_release):
+        self.detections, self._done, self._on_release = detections, done, on_release
 
     def wait(self):
         torch.cuda.current_stream().wait_event(self._done)
         return self.detections
 
     def release(self):
-        self._consumed.record(torch.cuda.current_stream())
+        self._on_release()
 
 
 class DetectPipeline(object):
@@ -64,15 +64,11 @@ class DetectPipeline(object):
             done = torch.cuda.Event()
             done.record(s)
         self._released[b] = False
-        t = Ticket(self.buffers[b], done, self.consumed[b])
-        t.release = self._release_fn(b, t)
-        return t
+        return Ticket(self.buffers[b], done, lambda: self._release(b))
 
-    def _release_fn(self, b, ticket):
-        def release():
-            ticket._consumed.record(torch.cuda.current_stream())
-            self._released[b] = True
-        return release
+    def _release(self, b):
+        self.consumed[b].record(torch.cuda.current_stream())
+        self._released[b] = True
 
     def synchronize(self):
         for s in self.streams:
