@@ -18,13 +18,22 @@ Contents
                  ``nets/ron_vgg_320.py:196-256``).
 ``ron_forward``  fp32 NHWC restatement of the conv stack
                  (``nets/ron_vgg_320.py:378-580``) with slim semantics
-                 (``nets/ron_vgg_320.py:595-629``).
+                 (``nets/ron_vgg_320.py:595-629``); ``ssd_forward``: SSD-512.
+``eval_metrics`` GT matching (``tf_extended/bboxes.py:316-450``), streaming TP/FP, P/R,
+                 AP VOC07/12 (``tf_extended/metrics.py:100-258``), the numpy PASCAL
+                 evaluation of one class (``datasets/voc_eval.py:164-295``).
+``preprocess``   ``preprocess_for_eval`` in all resize modes
+                 (``preprocessing/ssd_vgg_preprocessing.py:358-425``, ``tf_image.py:141-282``).
+``ron_eval_post`` post-processing of the second harness (``ron_eval.py:111-206,369-392``).
 
 Pinning status
 --------------
 * ``anchors`` and ``np_post`` are pinned against outputs of the reference's own
   numpy code, imported in the build container by ``tests/golden/make_golden.py``
   (fixtures ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``).
+* ``eval_metrics``: the AP integrals and ``voc_eval_class`` are pinned against the reference's own numpy
+  ``voc_ap`` / ``DetectorEvalPascal.voc_eval`` (fixtures g6, g7); the TF matching is **parity unpinned**.
+* ``preprocess`` (TF1 bilinear resize restated from its published algorithm) and ``ron_eval_post``: **parity unpinned**.
 * ``ron_forward`` and ``tfe_post`` restate TensorFlow-1.x graph code.  TensorFlow
   is not installable here and the reference ships no tests, golden vectors or
   checkpoints for it, so for these two: **parity unpinned** (cross-checked only
