@@ -243,3 +243,23 @@ def test_fused_stem_matches_separate_launches(pkg, dev, weights_reduced, dtype):
     assert np.mean(p_a != p_b) < 0.05                               # and nearly everywhere bit-identical
     for a, b in zip(outs[0][1], outs[1][1]):
         assert _rel_err(a, b) < (3e-2 if dtype == 'bf16' else 5e-3)
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-5), ('bf16', 3e-2)])
+def test_ragged_batch_sizes(pkg, dev, weights_reduced, dtype, tol):
+    """Every batch size up to max_batch goes through the same launch plan (tile counts, split-K factors and the fused stem's tile
+    loop change with n): the first n images of a batch of 7 give the heads of a batch of n."""
+    cls = pkg['factory'].get_network('ron_320_vgg')
+    net = cls(variant='reducedfc', dtype=dtype, max_batch=7, device=dev, fuse_pools=dtype != 'fp32')
+    net.load_weights(weights_reduced)
+    x = torch.from_numpy(pkg['W'].synthetic_images(7, seed=21)).to(dev)
+    full = [t.clone() for t in net.forward_heads(x)[0]]
+    for n in (1, 2, 3, 5, 6):
+        part = net.forward_heads(x[:n])[0]
+        for a, b in zip(part, full):
+            assert torch.isfinite(a).all()
+            scale = float(b[:n].abs().max())
+            assert float((a - b[:n]).abs().max()) <= tol * scale, (n, dtype)
+    with pytest.raises(Exception):
+        net.forward_heads(torch.cat([x, x[:1]]))                  # 8 > max_batch
+    net.close()
