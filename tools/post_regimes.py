@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Post-processing time (ron_post_np, batch 32) across candidate-count regimes: background / objectness biases of
+the synthetic head tensors set how many of the 425 k (anchor, class) pairs pass the thresholds.  python tools/post_regimes.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ron_tensorflow_amd import ops
+from ron_tensorflow_amd.nets.ron_vgg_320 import RONNet
+
+
+def head_tensors(seed, batch, bg, ob, num_classes=21, anchors=10):
+    """cls logits N(0,1) with +bg on class 0, objectness logits N(0,1) with +ob on the positive channel, loc N(0,1)."""
+    rs = np.random.RandomState(seed)
+    cls, obj, loc = [], [], []
+    for f in (5, 10, 20, 40):
+        c = rs.randn(batch, f, f, anchors, num_classes).astype(np.float32)
+        c[..., 0] += bg
+        o = rs.randn(batch, f, f, anchors, 2).astype(np.float32)
+        o[..., 1] += ob
+        cls.append(c); obj.append(o); loc.append(rs.randn(batch, f, f, anchors, 4).astype(np.float32))
+    return cls, obj, loc
+
+
+def main():
+    dev = torch.device('cuda:0')
+    adev = ops.anchors_to_device(RONNet().anchors((320, 320)), dev)
+    for bg, ob in ((8.0, -4.0), (7.0, -3.0), (6.0, -2.0), (4.0, -2.0), (0.0, 2.0)):
+        cls, obj, loc = head_tensors(5, batch=32, bg=bg, ob=ob)
+        t = [[torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in lst] for lst in (cls, obj, loc)]
+        for _ in range(3):
+            det, _, ncand = ops.post_np(t[0], t[1], t[2], adev)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            det, _, ncand = ops.post_np(t[0], t[1], t[2], adev)
+        e1.record()
+        torch.cuda.synchronize()
+        print('bg %+.0f ob %+.0f: %8.0f candidates / image, %6.1f detections / image, %8.1f us per batch of 32'
+              % (bg, ob, float(ncand.float().mean()), float(det.count.float().mean()), e0.elapsed_time(e1) * 100), flush=True)
+
+
+if __name__ == '__main__':
+    main()
