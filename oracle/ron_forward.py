@@ -4,7 +4,8 @@ Follows the reference graph code, which is TensorFlow-1.x / tf.contrib.slim and 
 executed here (TensorFlow is not installable; the reference ships no tests or checkpoints
 for it): **parity unpinned** -- the layer semantics below are restated from the reference
 source and cross-checked against the independent torch-CPU operators
-(tests/test_oracle_forward.py), not against outputs of the reference itself.
+(tests/test_oracle_forward.py: every layer shape of RON-320 and SSD-512, both back-ends), not against
+outputs of the reference itself.
 
   VGG-16 body, fc6/fc7 (both variants)   nets/ron_vgg_320.py:454-483, :530-556
   reverse connection + objectness        nets/ron_vgg_320.py:418-432
@@ -90,12 +91,20 @@ def _t(x):
 
 
 def conv2d_torch(x, w, stride=1, rate=1):
+    """Same contract as conv2d_np.  TF's SAME rule puts the odd pixel of an even kernel's padding AFTER the data
+    (total = (k-1)*rate, before = total // 2), which F.conv2d's symmetric `padding` cannot express: pad explicitly."""
     import torch
     import torch.nn.functional as Fn
     kh, kw = w.shape[:2]
     wt = torch.from_numpy(np.ascontiguousarray(w)).permute(3, 2, 0, 1)
-    pad = 0 if stride > 1 else ((kh - 1) * rate // 2, (kw - 1) * rate // 2)
-    y = Fn.conv2d(_t(x), wt, None, stride=stride, padding=pad, dilation=rate)
+    xt = _t(x)
+    if stride == 1:
+        pt, pb = _same_pad(kh, rate)
+        pl, pr = _same_pad(kw, rate)
+        xt = Fn.pad(xt, (pl, pr, pt, pb))
+    else:
+        assert kh == stride and kw == stride and x.shape[1] % stride == 0 and x.shape[2] % stride == 0 and rate == 1
+    y = Fn.conv2d(xt, wt, None, stride=stride, padding=0, dilation=rate)
     return y.permute(0, 2, 3, 1).contiguous().numpy()
 
 
@@ -149,7 +158,7 @@ class _Net(object):
         return np.maximum(y, 0)
 
 
-def _reverse_module(net, left, right, layer, num_anchors, num_classes):
+def _reverse_module(net, left, right, layer, num_anchors, num_classes, collect=None):
     """nets/ron_vgg_320.py:418-432 for one scale -> (ref_map, objness_logits, cls_logits, loc)."""
     vs = 'reverse_module/%s_reverse' % layer
     if right is None:
@@ -159,6 +168,8 @@ def _reverse_module(net, left, right, layer, num_anchors, num_classes):
         up = net.deconv_bias_relu(right, vs + '_deconv_right')
         ref = np.maximum(lc + up, 0)
     obj_h = net.conv_bn_relu(ref, vs + '_objectness')
+    keep = {} if collect is None else collect
+    keep[layer + '_objectness'] = obj_h
     obj = net.conv_bias(obj_h, vs + '_objectness_score', relu=False)
     # class head: two (3x3 || 1x1) -> concat -> BN -> ReLU blocks, then 3x3 -> A*C   (:378-404)
     x = ref
@@ -166,9 +177,11 @@ def _reverse_module(net, left, right, layer, num_anchors, num_classes):
         b0 = net.conv_bias(x, vs + blk + '/Branch_0/Conv2d_3x3', relu=False)
         b1 = net.conv_bias(x, vs + blk + '/Branch_1/Conv2d_1x1', relu=False)
         x = np.maximum(net.bn(np.concatenate([b0, b1], axis=3), vs + blk), 0)
+        keep[layer + blk] = x
     cls = net.conv_bias(x, vs + '_inception2/Conv2d_pred_3x3', relu=False)
     # box head (:406-415)
     r = net.conv_bn_relu(ref, vs + '/Conv2d_0_3x3')
+    keep[layer + '_reg_hidden'] = r
     loc = net.conv_bias(r, vs + '/Conv2d_1_3x3', relu=False)
     n, h, w, _ = ref.shape
     return (ref, obj.reshape(n, h, w, num_anchors, 2), cls.reshape(n, h, w, num_anchors, num_classes),
@@ -208,7 +221,7 @@ def ron_forward(images, weights, variant='reducedfc', num_classes=21, num_anchor
     predictions, logits, objness_pred, objness_logits, localisations = [], [], [], [], []
     ref = None
     for layer in FEAT_LAYERS:
-        ref, obj, cls, loc = _reverse_module(net, end_points[layer], ref, layer, num_anchors, num_classes)
+        ref, obj, cls, loc = _reverse_module(net, end_points[layer], ref, layer, num_anchors, num_classes, collect)
         if collect is not None:
             collect[layer + '_ref'] = ref
         predictions.append(np_post.softmax_last(cls))

@@ -70,6 +70,23 @@ def conv2d_pad_np(x, w, stride=1, rate=1, pad=0):
     return out.reshape(n, ho, wo, cout)
 
 
+def conv2d_pad_torch(x, w, stride=1, rate=1, pad=0):
+    """conv2d_pad_np on the independent torch-CPU operator (cross-check back-end)."""
+    import torch
+    import torch.nn.functional as Fn
+    xt = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
+    wt = torch.from_numpy(np.ascontiguousarray(w)).permute(3, 2, 0, 1)
+    y = Fn.conv2d(xt, wt, None, stride=stride, padding=pad, dilation=rate)
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def max_pool3x3_s1_torch(x):
+    import torch
+    import torch.nn.functional as Fn
+    xt = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
+    return Fn.max_pool2d(xt, 3, 1, padding=1).permute(0, 2, 3, 1).contiguous().numpy()
+
+
 def max_pool3x3_s1_np(x):
     """slim.max_pool2d [3,3] stride 1 SAME: padding never wins the max."""
     xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)), constant_values=-np.inf)
@@ -87,9 +104,14 @@ def l2_normalization(x, gamma):
     return (x / np.sqrt(np.maximum(ss, F32(1e-12))) * gamma).astype(F32)
 
 
-def ssd_forward(images, weights, num_classes=21, round_fn=None, collect=None):
-    """Returns (predictions, localisations, logits, end_points) like SSDNet.net (nets/ssd_vgg_512.py:459)."""
+def ssd_forward(images, weights, num_classes=21, round_fn=None, collect=None, backend='numpy'):
+    """Returns (predictions, localisations, logits, end_points) like SSDNet.net (nets/ssd_vgg_512.py:459).
+    backend 'torch' swaps every conv / pool for the independent torch-CPU operator (tests/test_oracle_forward.py)."""
+    from .ron_forward import BACKENDS
     rnd = round_fn if round_fn is not None else (lambda a: a)
+    conv_same, _, pool2 = BACKENDS[backend]
+    conv_pad = conv2d_pad_np if backend == 'numpy' else conv2d_pad_torch
+    pool3 = max_pool3x3_s1_np if backend == 'numpy' else max_pool3x3_s1_torch
 
     def var(name):
         return np.asarray(weights[SCOPE + '/' + name], dtype=F32)
@@ -97,9 +119,9 @@ def ssd_forward(images, weights, num_classes=21, round_fn=None, collect=None):
     def conv(x, scope, stride=1, rate=1, pad=None, relu=True):
         w = var(scope + '/weights')
         if pad is None:
-            y = conv2d_np(rnd(x), rnd(w), stride, rate)
+            y = conv_same(rnd(x), rnd(w), stride, rate)
         else:
-            y = conv2d_pad_np(rnd(x), rnd(w), stride, rate, pad)
+            y = conv_pad(rnd(x), rnd(w), stride, rate, pad)
         y = y + var(scope + '/biases')
         return np.maximum(y, 0) if relu else y
 
@@ -108,14 +130,20 @@ def ssd_forward(images, weights, num_classes=21, round_fn=None, collect=None):
     for bi, reps in enumerate([2, 2, 3, 3, 3]):
         for r in range(reps):
             x = conv(x, 'conv%d/conv%d_%d' % (bi + 1, bi + 1, r + 1))
+            if collect is not None:
+                collect['conv%d_%d' % (bi + 1, r + 1)] = x
         end_points['block%d' % (bi + 1)] = x
-        x = max_pool2x2_np(x) if bi < 4 else max_pool3x3_s1_np(x)
+        x = pool2(x) if bi < 4 else pool3(x)
+        if collect is not None:
+            collect['pool%d' % (bi + 1)] = x
     x = conv(x, 'conv6', rate=6)
     end_points['block6'] = x
     x = conv(x, 'conv7')
     end_points['block7'] = x
     for b in range(8, 13):
         x = conv(x, 'block%d/conv1x1' % b)
+        if collect is not None:
+            collect['block%d_mid' % b] = x
         if b < 12:
             x = conv(x, 'block%d/conv3x3' % b, stride=2, pad=1)
         else:
