@@ -179,3 +179,28 @@ def evaluate(stream, voc07=True, voc12=True):
     if voc12:
         out['AP_VOC12/mAP'] = float(np.mean(aps12))
     return out
+
+
+def detection_agreement(got, ref, tol=1e-4):
+    """How well one detection list reproduces another ("detection agreement rate" on synthetic inputs,
+    the stand-in for mAP while no checkpoint ships).  `got` / `ref`: dicts with classes, anchor_index, scores, bboxes
+    (one image).  A reference detection is *reproduced* when `got` holds the same (class, anchor_index) pair.
+
+    Returns dict(n_ref, n_got, reproduced, within_tol, max_score_diff, max_box_diff):
+      reproduced  fraction of the reference detections present in `got`;
+      within_tol  fraction of the reproduced ones whose score AND box agree within `tol` (north-star: 1e-4);
+      max_*_diff  largest absolute differences over the reproduced ones."""
+    ref_keys = {(int(c), int(a)): k for k, (c, a) in enumerate(zip(ref['classes'], ref['anchor_index']))}
+    hit = [(k, ref_keys[(int(c), int(a))]) for k, (c, a) in enumerate(zip(got['classes'], got['anchor_index']))
+           if (int(c), int(a)) in ref_keys]
+    out = dict(n_ref=len(ref_keys), n_got=int(len(got['classes'])), reproduced=1.0, within_tol=1.0,
+               max_score_diff=0.0, max_box_diff=0.0)
+    if ref_keys:
+        out['reproduced'] = len(hit) / float(len(ref_keys))
+    if hit:
+        gi, ri = np.array([h[0] for h in hit]), np.array([h[1] for h in hit])
+        ds = np.abs(np.asarray(got['scores'])[gi] - np.asarray(ref['scores'])[ri])
+        db = np.abs(np.asarray(got['bboxes'])[gi] - np.asarray(ref['bboxes'])[ri]).max(axis=1)
+        out['within_tol'] = float(np.mean((ds <= tol) & (db <= tol)))
+        out['max_score_diff'], out['max_box_diff'] = float(ds.max()), float(db.max())
+    return out
