@@ -30,3 +30,20 @@ def head_tensors(seed, batch=1, feat_shapes=RON_FEAT_SHAPES, num_anchors=10,
         obj_l.append(obj)
         loc_l.append(loc)
     return cls_l, obj_l, loc_l
+
+
+SSD512_FEAT_SHAPES = [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+SSD512_ANCHORS = [4, 6, 6, 6, 6, 4, 4]
+
+
+def ssd_head_tensors(seed, batch=1, num_classes=21, bg=6.0, cls_scale=1.0):
+    """SSD-512 head tensors (7 scales, 4 / 6 anchors per cell = 24 564 anchors, no objectness):
+    per-layer (cls_logits [B,H,W,A,C], loc [B,H,W,A,4])."""
+    rs = np.random.RandomState(seed)
+    cls_l, loc_l = [], []
+    for (h, w), a in zip(SSD512_FEAT_SHAPES, SSD512_ANCHORS):
+        cls = (rs.randn(batch, h, w, a, num_classes) * cls_scale).astype(np.float32)
+        cls[..., 0] += np.float32(bg)
+        cls_l.append(cls)
+        loc_l.append(rs.randn(batch, h, w, a, 4).astype(np.float32))
+    return cls_l, loc_l

@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference).  It imports
 
-  * ``nets/np_methods.py``  (numpy only)                      -> G2, G3, G4
+  * ``nets/np_methods.py``  (numpy only)                      -> G2, G3, G4, G5 (SSD-512 pipeline)
   * ``nets/ron_vgg_320.py`` under a stubbed ``tensorflow``     -> G1 (anchor grids)
 
 and stores inputs (or the seed that regenerates them) together with the outputs the
@@ -79,6 +79,49 @@ def g5_anchors_ssd(ron_module):
     for i, (y, x, h, w) in enumerate(layers):
         out['y%d' % i], out['x%d' % i], out['h%d' % i], out['w%d' % i] = y, x, h, w
     np.savez_compressed(os.path.join(HERE, 'g5_anchors_ssd512.npz'), **out)
+    return layers
+
+
+G5_CASES = [
+    # name, seed, bg, cls_scale, select_thr, nms_thr
+    ('ssd_real_s0', 40, 8.0, 1.0, 0.01, 0.45),
+    ('ssd_real_s1', 41, 7.0, 1.0, 0.01, 0.45),
+    ('ssd_dense_s2', 42, 4.0, 1.0, 0.01, 0.45),
+    ('ssd_thr50_s3', 43, 6.0, 3.0, 0.5, 0.40),
+    ('ssd_empty_s4', 44, 30.0, 1.0, 0.01, 0.45),
+]
+
+
+def g5_pipeline_ssd(npm, anchors):
+    """The reference's np_methods pipeline on the 24 564 SSD-512 anchors (7 scales, 4 / 6 anchors per cell, no
+    objectness gate; SURVEY.md 8c "G5"): ssd_bboxes_select -> bboxes_clip -> bboxes_sort(400) -> bboxes_nms ->
+    bboxes_resize (nets/np_methods.py:100-131, 137-150, 153-183, 229-242), on seeded head tensors."""
+    out = {}
+    names = []
+    for name, seed, bg, scale, thr, nms in G5_CASES:
+        cls, loc = synth.ssd_head_tensors(seed, batch=1, bg=bg, cls_scale=scale)
+        pred = [np_post.softmax_last(x) for x in cls]
+        rbbox_img = np.array([0., 0., 1., 1.], dtype=np.float32)
+        c, s, b = npm.ssd_bboxes_select(pred, loc, anchors, select_threshold=thr, img_shape=(512, 512), num_classes=21, decode=True)
+        n_cand = c.shape[0]
+        b = npm.bboxes_clip(rbbox_img, b)
+        c, s, b = npm.bboxes_sort(c, s, b, top_k=400)
+        srt = (c.copy(), s.copy(), b.copy())
+        assert len(np.unique(s)) == len(s), name          # the reference's argsort is unstable: tie-free cases only
+        c, s, b = npm.bboxes_nms(c, s, b, nms_threshold=nms)
+        b = npm.bboxes_resize(rbbox_img, b)
+        names.append(name)
+        out[name + '/params'] = np.array([seed, bg, scale, thr, nms], dtype=np.float64)
+        out[name + '/n_cand'] = np.int64(n_cand)
+        out[name + '/n_sorted'] = np.int64(srt[0].shape[0])
+        out[name + '/classes'] = c.astype(np.int64)
+        out[name + '/scores'] = s.astype(np.float32)
+        out[name + '/bboxes'] = b.astype(np.float32).reshape(-1, 4)
+        out[name + '/sorted_classes'] = srt[0].astype(np.int64)
+        out[name + '/sorted_scores'] = srt[1].astype(np.float32)
+        print('%-13s cand=%6d sorted=%3d kept=%3d' % (name, n_cand, srt[0].shape[0], c.shape[0]))
+    out['names'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'g5_pipeline_ssd512.npz'), **out)
 
 
 def g6_voc_ap():
@@ -304,11 +347,12 @@ def main():
     npm = load_np_methods()
     ron = load_ref_ron()
     anchors = g1_anchors(ron)
-    g5_anchors_ssd(ron)
+    ssd_anchors = g5_anchors_ssd(ron)
     g6_voc_ap()
     g7_voc_eval()
     g2_decode(npm, anchors)
     g3_pipeline(npm, anchors)
+    g5_pipeline_ssd(npm, ssd_anchors)
     g4_edge(npm)
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith('.npz'):

@@ -182,6 +182,59 @@ def test_g4_select_threshold_and_topk_cut(ops, dev, golden_dir):
     assert np.array_equal(s['bboxes'], g['cut/sorted_bboxes'])
 
 
+def test_g4_clip_and_resize_against_a_non_unit_reference_box(ops, dev, golden_dir):
+    """bboxes_clip and bboxes_resize with bbox_img != [0,0,1,1] (/root/reference/nets/np_methods.py:153-183) THROUGH
+    ron_post_np: the five boxes of golden G4 (outside, straddling, inverted after the clip -- the np version has no
+    repair) go in as decoded boxes of five different classes, so nothing is suppressed and the score order is the input
+    order.  Sorted list = after the clip, final list = after the resize; both against the reference's own outputs."""
+    g = np.load(os.path.join(golden_dir, 'g4_edge.npz'))
+    boxes, ref2 = g['clip/in_bboxes'], g['clip/ref2']
+    n = boxes.shape[0]
+    pred = np.zeros((1, 1, 1, n, 21), np.float32)
+    for k in range(n):
+        pred[0, 0, 0, k, k + 1] = np.float32(0.9 - 0.1 * k)
+    out, srt, ncand = ops.post_np([torch.from_numpy(pred).to(dev)], None, [torch.from_numpy(boxes.reshape(1, 1, 1, n, 4)).to(dev)],
+                                  None, select_threshold=0.01, nms_threshold=0.45, cls_is_prob=True, loc_decoded=True,
+                                  bbox_img=tuple(float(v) for v in ref2), want_sorted=True)
+    assert int(ncand.cpu().numpy()[0]) == n
+    s, o = srt.to_lists()[0], out.to_lists()[0]
+    assert list(s['classes']) == list(range(1, n + 1)) and list(o['classes']) == list(range(1, n + 1))
+    assert np.array_equal(s['bboxes'], g['clip/out_bboxes2'])                      # min / max: exact
+    np.testing.assert_allclose(o['bboxes'], g['resize/out_bboxes2'], rtol=0, atol=1e-6)
+    # and the unit box: clip only, resize is the identity
+    out, srt, _ = ops.post_np([torch.from_numpy(pred).to(dev)], None, [torch.from_numpy(boxes.reshape(1, 1, 1, n, 4)).to(dev)],
+                              None, select_threshold=0.01, nms_threshold=0.45, cls_is_prob=True, loc_decoded=True, want_sorted=True)
+    assert np.array_equal(srt.to_lists()[0]['bboxes'], g['clip/out_bboxes'])
+    assert np.array_equal(out.to_lists()[0]['bboxes'], g['clip/out_bboxes'])
+
+
+def test_post_np_random_reference_boxes_vs_oracle(ops, dev, anchors, anchors_dev):
+    """Whole pipeline with non-identity bbox_img (a crop of the image, and a box larger than it) vs the oracle."""
+    cls, obj, loc = synth.head_tensors(108, batch=2)
+    for ref_box in ((0.1, 0.2, 0.7, 0.9), (-0.25, -0.5, 1.5, 1.25)):
+        ref = np_post.detect_from_logits(cls, obj, loc, anchors, bbox_img=ref_box)
+        out, _, _ = ops.post_np(_to_dev(cls, dev), _to_dev(obj, dev), _to_dev(loc, dev), anchors_dev, bbox_img=ref_box)
+        for got, r in zip(out.to_lists(), ref):
+            _assert_same_dets(got, r, scores_exact=False)
+
+
+def test_post_np_golden_pipeline_ssd512(ops, dev, golden_dir):
+    """ron_post_np on 24 564 SSD-512 anchors (7 scales, 4 / 6 anchors per cell, no objectness) against what the
+    reference's np_methods produced (tests/golden/g5_pipeline_ssd512.npz; SURVEY.md 8c "G5")."""
+    from oracle import ssd_forward as osf
+    adev = ops.anchors_to_device(osf.anchors_all_layers(), dev)
+    g = np.load(os.path.join(golden_dir, 'g5_pipeline_ssd512.npz'))
+    for name in [str(n) for n in g['names']]:
+        seed, bg, scale, thr, nms = g[name + '/params']
+        cls, loc = synth.ssd_head_tensors(int(seed), batch=1, bg=bg, cls_scale=scale)
+        out, srt, ncand = ops.post_np(_to_dev(cls, dev), None, _to_dev(loc, dev), adev, select_threshold=float(thr),
+                                      nms_threshold=float(nms), want_sorted=True)
+        assert int(ncand.cpu().numpy()[0]) == int(g[name + '/n_cand']), name
+        assert int(srt.count.cpu().numpy()[0]) == int(g[name + '/n_sorted']), name
+        ref = dict(classes=g[name + '/classes'], scores=g[name + '/scores'], bboxes=g[name + '/bboxes'])
+        _assert_same_dets(out.to_lists()[0], ref, scores_exact=False)
+
+
 def test_list_sort_nms_random_vs_oracle(ops, dev):
     rs = np.random.RandomState(77)
     for n_in in (1, 63, 400, 401, 5000):

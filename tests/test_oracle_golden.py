@@ -147,3 +147,24 @@ def test_g5_ssd512_anchors_bit_exact(golden_dir):
     for i, (y, x, h, w) in enumerate(layers):
         for nm, arr in (('y', y), ('x', x), ('h', h), ('w', w)):
             assert np.array_equal(arr, g['%s%d' % (nm, i)]), (nm, i)
+
+
+def test_g5_ssd512_pipeline_matches_reference(golden_dir):
+    """np_methods pipeline on the 24 564 SSD-512 anchors (no objectness gate), outputs of the reference's own numpy code
+    (/root/reference/nets/np_methods.py:100-131, 137-150, 153-183, 229-242; SURVEY.md 8c "G5")."""
+    from oracle import ssd_forward as osf
+    g = _load(golden_dir, 'g5_pipeline_ssd512.npz')
+    layers = osf.anchors_all_layers()
+    for name in [str(n) for n in g['names']]:
+        seed, bg, scale, thr, nms = g[name + '/params']
+        cls, loc = synth.ssd_head_tensors(int(seed), batch=1, bg=bg, cls_scale=scale)
+        pred = [np_post.softmax_last(c) for c in cls]
+        res = np_post.detect_from_predictions(pred, loc, layers, objness_pred=None, select_threshold=thr, top_k=400,
+                                              nms_threshold=nms)[0]
+        assert res['n_candidates'] == int(g[name + '/n_cand']), name
+        assert res['n_sorted'] == int(g[name + '/n_sorted']), name
+        assert np.array_equal(res['classes'], g[name + '/classes']), name
+        assert np.array_equal(res['scores'], g[name + '/scores']), name
+        assert np.array_equal(res['bboxes'].reshape(-1, 4), g[name + '/bboxes']), name
+        if res['anchor_index'].size:
+            assert res['anchor_index'].min() >= 0 and res['anchor_index'].max() < 24564
