@@ -144,6 +144,8 @@ int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cfg,
  * The last three steps alone, on explicit candidate lists (np_methods.bboxes_sort ->
  * bboxes_nms, np_methods.py:137-150, :229-242): classes [N, n_in] int32, scores [N, n_in],
  * bboxes [N, n_in, 4]; n_valid [N] (or NULL = n_in everywhere).  No clip / resize.
+ * Scores may be any float: negative ones sort below positive ones, -0 ties with +0, NaN sorts
+ * last (the order of np.argsort(-scores)); ties keep their input order.
  */
 int ron_np_sort_nms(const int32_t* classes, const float* scores, const float* bboxes,
                     const int32_t* n_valid, int n, int n_in, int top_k, float nms_threshold,

@@ -56,8 +56,16 @@ struct DetDev {
   int* count;
 };
 
+// score >= 0 (probabilities): the float's bit pattern is already monotone
 __device__ __forceinline__ u64 make_key(float score, unsigned p) {
   return ((u64)__float_as_uint(score) << 32) | (u64)(0xFFFFFFFFu - p);
+}
+// any float (caller-supplied lists): the usual order-preserving map (negative: all bits flipped, else the sign bit set);
+// -0 == +0 and NaN goes last, the order np.argsort(-scores) gives (np_methods.py:137-150)
+__device__ __forceinline__ u64 make_key_any(float score, unsigned p) {
+  unsigned u = __float_as_uint(score + 0.f);
+  u = (score != score) ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+  return ((u64)u << 32) | (u64)(0xFFFFFFFFu - p);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -180,14 +188,32 @@ __device__ void bitonic_sort_desc(u64* s, int n2, int tid, int nthreads) {
 
 // Puts the top_k largest keys of keys[0..m) (unique keys) sorted descending at lds.sort[0..).
 // Returns number of valid keys (min(m, top_k)).
-__device__ int topk_keys(const u64* __restrict__ keys, int m, int top_k, ImageLds& lds) {
+// With `below` != ~0: only keys < below take part (m_live of them; the caller knows how many it has consumed).
+__device__ int topk_keys(const u64* __restrict__ keys, int m, int top_k, ImageLds& lds, u64 below = ~0ull, int m_live = -1) {
   const int tid = threadIdx.x;
   const int nth = blockDim.x;
+  const bool bounded = below != ~0ull;
+  if (m_live < 0) m_live = m;
   int n_sel;
-  if (m <= kSelectCap) {
-    for (int i = tid; i < m; i += nth) lds.sort[i] = keys[i];
-    n_sel = m;
-    __syncthreads();
+  if (m_live <= kSelectCap) {
+    if (!bounded) {
+      for (int i = tid; i < m; i += nth) lds.sort[i] = keys[i];
+      n_sel = m;
+      __syncthreads();
+    } else {
+      if (tid == 0) lds.scalars[3] = 0;
+      __syncthreads();
+      for (int i = tid; i < m; i += nth) {
+        const u64 k = keys[i];
+        if (k < below) {
+          const int pos = atomicAdd(&lds.scalars[3], 1);
+          if (pos < kSortCap) lds.sort[pos] = k;
+        }
+      }
+      __syncthreads();
+      n_sel = min(lds.scalars[3], kSortCap);
+      __syncthreads();
+    }
   } else {
     // radix select from the most significant byte down until few enough keys survive for a short LDS sort
     u64 prefix = 0, mask = 0;
@@ -197,7 +223,7 @@ __device__ int topk_keys(const u64* __restrict__ keys, int m, int top_k, ImageLd
       __syncthreads();
       for (int i = tid; i < m; i += nth) {
         const u64 k = keys[i];
-        if ((k & mask) == prefix) atomicAdd(&lds.hist[(unsigned)(k >> shift) & 255u], 1u);
+        if ((k & mask) == prefix && k < below) atomicAdd(&lds.hist[(unsigned)(k >> shift) & 255u], 1u);
       }
       __syncthreads();
       if (tid < 64) {
@@ -234,7 +260,7 @@ __device__ int topk_keys(const u64* __restrict__ keys, int m, int top_k, ImageLd
     __syncthreads();
     for (int i = tid; i < m; i += nth) {
       const u64 k = keys[i];
-      if ((k & mask) >= prefix) {
+      if ((k & mask) >= prefix && k < below) {
         const int pos = atomicAdd(&lds.scalars[3], 1);
         if (pos < kSortCap) lds.sort[pos] = k;
       }
@@ -555,7 +581,7 @@ __global__ __launch_bounds__(kTopkThreads) void list_sort_nms_kernel(const int* 
   const int tid = threadIdx.x;
   const int m = n_valid ? min(n_valid[img], n_in) : n_in;
   u64* my_keys = keys + (size_t)img * n_in;
-  for (int i = tid; i < m; i += blockDim.x) my_keys[i] = make_key(scores[(size_t)img * n_in + i], (unsigned)i);
+  for (int i = tid; i < m; i += blockDim.x) my_keys[i] = make_key_any(scores[(size_t)img * n_in + i], (unsigned)i);
   __threadfence_block();
   __syncthreads();
   const int n = topk_keys(my_keys, m, top_k, lds);
@@ -987,72 +1013,88 @@ __global__ __launch_bounds__(kSelectThreads) void eval_select_kernel(HeadsDev hd
   if (pos < cap) keys[(size_t)img * cap + pos] = make_key(best, (unsigned)(hd.anchor_base[layer] + local) * 64u + (unsigned)label);
 }
 
-constexpr int kEvalCand = 1024;     // NMS candidates of the ron_eval.py variant: one thread each
+constexpr int kEvalCand = 1024;     // NMS candidates of the ron_eval.py variant per pass: one thread each
 
+// The reference takes ALL candidates (ron_eval.py:111-144 -> tf_bboxes_nms).  Greedy NMS only ever looks at candidates
+// in score order, so they are taken kEvalCand at a time: a pass sorts the next kEvalCand highest keys, drops the ones a
+// box kept by an earlier pass overlaps, and continues the greedy scan; it ends when keep_top_k rows are kept or the
+// candidates run out.  One pass in practice (the reference's thresholds let a few dozen through), exact for any count.
 __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, EvalDev pc, const u64* keys, const int* counts,
                                                                 int cap, DetDev out) {
   static_assert(kEvalCand == kTopkThreads && kSortCap >= kEvalCand + kEvalCand * 2, "one thread per candidate; boxes live behind the keys");
   __shared__ ImageLds lds;
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = min(counts[img * kCountStride], cap);
-  const int n = topk_keys(keys + (size_t)img * cap, m, kEvalCand, lds);     // the kEvalCand highest scores, sorted
   float* box = reinterpret_cast<float*>(&lds.sort[kEvalCand]);              // [kEvalCand][4]
   u64* words = reinterpret_cast<u64*>(lds.hist);                            // alive bits, one word per wave
-  int* kept = lds.order;                                                    // sorted rows in pick order (<= kMaxTopK)
-  float my[4] = {0.f, 0.f, 0.f, 0.f};
-  unsigned my_p = 0;
-  if (tid < n) {
-    const u64 k = lds.sort[tid];
-    my_p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
-    const int anchor = (int)(my_p >> 6);
-    int layer = 0;
-#pragma unroll
-    for (int l = 1; l < RON_MAX_LAYERS; ++l)
-      if (l < hd.num_layers && anchor >= hd.anchor_base[l]) layer = l;
-    eval_box(hd, pc, img, layer, anchor - hd.anchor_base[layer], my);
-  }
-  __syncthreads();                                                          // every key is read before boxes overwrite the tail
-  const float my_score = tid < n ? __uint_as_float((unsigned)(lds.sort[tid] >> 32)) : 0.f;
-  box[tid * 4 + 0] = my[0]; box[tid * 4 + 1] = my[1]; box[tid * 4 + 2] = my[2]; box[tid * 4 + 3] = my[3];
-  // greedy, class agnostic, in score order (ron_eval.py:187-203): pick the first live row, drop every live row it overlaps
-  bool alive = tid < n;
-  int n_kept = 0;
   const int mode = pc.nms_mode == 1 ? 2 : 1;
-  for (int it = 0; it < pc.keep_top_k; ++it) {
-    const u64 bal = __ballot(alive);
-    if (lane == 0) words[wave] = bal;
-    __syncthreads();
-    int first = -1;
+  const int max_keep = min(pc.keep_top_k, out.capacity);
+  int n_kept = 0;                                                           // kept records: lds.box / score / cls / anchor
+  u64 below = ~0ull;
+  for (int consumed = 0; consumed < m && n_kept < max_keep; consumed += kEvalCand) {
+    const int n = topk_keys(keys + (size_t)img * cap, m, kEvalCand, lds, below, m - consumed);   // sorted, the next highest scores
+    float my[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned my_p = 0;
+    float my_score = 0.f;
+    if (tid < n) {
+      const u64 k = lds.sort[tid];
+      my_score = __uint_as_float((unsigned)(k >> 32));
+      my_p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+      const int anchor = (int)(my_p >> 6);
+      int layer = 0;
 #pragma unroll
-    for (int w = kTopkThreads / 64 - 1; w >= 0; --w)
-      if (words[w] != 0ull) first = w * 64 + __ffsll((long long)words[w]) - 1;
-    if (first < 0) break;
-    if (tid == first) { alive = false; kept[it] = first; }
-    n_kept = it + 1;
-    if (alive && tfe_suppresses(&box[first * 4], my, pc.nms_thr, mode)) alive = false;
+      for (int l = 1; l < RON_MAX_LAYERS; ++l)
+        if (l < hd.num_layers && anchor >= hd.anchor_base[l]) layer = l;
+      eval_box(hd, pc, img, layer, anchor - hd.anchor_base[layer], my);
+    }
+    if (n > 0) below = lds.sort[n - 1];                                     // the next pass continues under this key
+    __syncthreads();                                                        // every key is read before boxes overwrite the tail
+    box[tid * 4 + 0] = my[0]; box[tid * 4 + 1] = my[1]; box[tid * 4 + 2] = my[2]; box[tid * 4 + 3] = my[3];
+    bool alive = tid < n;
+    for (int j = 0; j < n_kept && alive; ++j)                               // boxes kept by earlier passes come first in score order
+      if (tfe_suppresses(lds.box[j], my, pc.nms_thr, mode)) alive = false;
+    // greedy, class agnostic, in score order (ron_eval.py:187-203): pick the first live row, drop every live row it overlaps
+    while (n_kept < max_keep) {
+      const u64 bal = __ballot(alive);
+      if (lane == 0) words[wave] = bal;
+      __syncthreads();
+      int first = -1;
+#pragma unroll
+      for (int w = kTopkThreads / 64 - 1; w >= 0; --w)
+        if (words[w] != 0ull) first = w * 64 + __ffsll((long long)words[w]) - 1;
+      if (first < 0) break;
+      if (tid == first) {
+        alive = false;
+        lds.box[n_kept][0] = my[0]; lds.box[n_kept][1] = my[1]; lds.box[n_kept][2] = my[2]; lds.box[n_kept][3] = my[3];
+        lds.score[n_kept] = my_score;
+        lds.cls[n_kept] = (int)(my_p & 63u);
+        lds.anchor[n_kept] = (int)(my_p >> 6);
+      }
+      ++n_kept;
+      if (alive && tfe_suppresses(&box[first * 4], my, pc.nms_thr, mode)) alive = false;
+      __syncthreads();
+    }
     __syncthreads();
+    if (n < kEvalCand) break;                                               // that was the last of them
   }
   __syncthreads();
-  const int total = min(n_kept, out.capacity);
+  const int total = n_kept;
   const float sy = pc.ref[2] - pc.ref[0], sx = pc.ref[3] - pc.ref[1];
-  for (int i = tid; i < out.capacity; i += blockDim.x)
+  for (int i = tid; i < out.capacity; i += blockDim.x) {
+    const size_t o = (size_t)img * out.capacity + i;
     if (i >= total) {
-      const size_t o = (size_t)img * out.capacity + i;
       out.classes[o] = 0; out.scores[o] = 0.f; out.anchor_index[o] = 0;
       out.bboxes[o * 4 + 0] = 0.f; out.bboxes[o * 4 + 1] = 0.f; out.bboxes[o * 4 + 2] = 0.f; out.bboxes[o * 4 + 3] = 0.f;
+    } else {
+      out.classes[o] = lds.cls[i];
+      out.scores[o] = lds.score[i];
+      out.anchor_index[o] = lds.anchor[i];
+      out.bboxes[o * 4 + 0] = (lds.box[i][0] - pc.ref[0]) / sy;      // tfe.bboxes_resize, tf_extended/bboxes.py:147-171
+      out.bboxes[o * 4 + 1] = (lds.box[i][1] - pc.ref[1]) / sx;
+      out.bboxes[o * 4 + 2] = (lds.box[i][2] - pc.ref[0]) / sy;
+      out.bboxes[o * 4 + 3] = (lds.box[i][3] - pc.ref[1]) / sx;
     }
-  // scores / labels of the kept rows: row r's thread still holds them
-  for (int pos = 0; pos < total; ++pos)
-    if (kept[pos] == tid) {
-      const size_t o = (size_t)img * out.capacity + pos;
-      out.classes[o] = (int)(my_p & 63u);
-      out.scores[o] = my_score;
-      out.anchor_index[o] = (int)(my_p >> 6);
-      out.bboxes[o * 4 + 0] = (my[0] - pc.ref[0]) / sy;      // tfe.bboxes_resize, tf_extended/bboxes.py:147-171
-      out.bboxes[o * 4 + 1] = (my[1] - pc.ref[1]) / sx;
-      out.bboxes[o * 4 + 2] = (my[2] - pc.ref[0]) / sy;
-      out.bboxes[o * 4 + 3] = (my[3] - pc.ref[1]) / sx;
-    }
+  }
   if (tid == 0) out.count[img] = total;
 }
 

@@ -45,6 +45,7 @@ def anchors_to_device(anchors, device):
 # --------------------------------------------------------------------------- #
 class DetectionBuffers(object):
     """Fixed-capacity per-image detection lists (SURVEY.md 8b "detection record")."""
+    FIELDS = ('classes', 'scores', 'bboxes', 'anchor_index', 'count')
 
     def __init__(self, n, capacity, device):
         self.n, self.capacity = n, capacity
@@ -53,6 +54,22 @@ class DetectionBuffers(object):
         self.bboxes = torch.zeros((n, capacity, 4), dtype=torch.float32, device=device)
         self.anchor_index = torch.zeros((n, capacity), dtype=torch.int32, device=device)
         self.count = torch.zeros((n,), dtype=torch.int32, device=device)
+
+    def narrow(self, n):
+        """The first `n` images of this set as a DetectionBuffers over the same memory (leading-dimension views)."""
+        assert 1 <= n <= self.n
+        if n == self.n:
+            return self
+        v = object.__new__(DetectionBuffers)
+        v.n, v.capacity = n, self.capacity
+        for f in self.FIELDS:
+            setattr(v, f, getattr(self, f)[:n])
+        return v
+
+    def record_stream(self, stream):
+        """Tell the caching allocator that `stream` uses these tensors (they were allocated on another stream)."""
+        for f in self.FIELDS:
+            getattr(self, f).record_stream(stream)
 
     def c_struct(self):
         return Detections(self.capacity, ptr(self.classes), ptr(self.scores), ptr(self.bboxes),
@@ -91,7 +108,9 @@ _WORKSPACES = {}
 
 
 def _workspace(device, nbytes):
-    key = (device.type, device.index)
+    """Scratch of the post-processing entry points, one per (device, stream): calls on different streams never share
+    candidate lists, and a regrown buffer is dropped on the stream that was its only user."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)

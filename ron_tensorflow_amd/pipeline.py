@@ -11,27 +11,42 @@ from . import ops
 
 
 class Ticket(object):
-    """One submitted batch: ``wait()`` makes the caller's current stream wait for it, then returns the detections;
-    ``release()`` (optional) marks, on the current stream, the point after which the detections are no longer read -
-    without it the buffers are simply assumed free by the time they come round again."""
+    """One submitted batch.  ``wait()`` makes the caller's current stream wait for it and returns the detections: reads
+    of them belong on that stream.  ``release()`` (optional) marks, on the current stream, the point after which the
+    detections are no longer read.  The output set comes round again ``slots * buffers_per_slot`` submissions later; the
+    slot then waits for the release point or, without one, for everything the consumer's stream held at that moment.  A
+    ticket whose output set has been handed to a later batch is expired: ``wait()`` on it raises instead of returning
+    another batch's records."""
 
-    def __init__(self, detections, done, on_release):
-        self.detections, self._done, self._on_release = detections, done, on_release
+    def __init__(self, detections, done):
+        self.detections, self._done = detections, done
+        self._consumer = None            # stream wait() was called on
+        self._release_event = None
+        self._expired = False
 
     def wait(self):
-        torch.cuda.current_stream().wait_event(self._done)
+        if self._expired:
+            raise RuntimeError('DetectPipeline: this ticket was never waited for before its output set went to a later batch; '
+                               'consume tickets within slots * buffers_per_slot submissions')
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self._done)
+        self.detections.record_stream(cur)
+        self._consumer = cur
         return self.detections
 
     def release(self):
-        self._on_release()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._release_event = ev
 
 
 class DetectPipeline(object):
     """Round-robin submission of batches to ``slots`` execution slots of ``net``.
 
     ``submit(images)`` returns a Ticket; the detections it carries live in one of the slot's ``buffers_per_slot``
-    output sets and stay valid for the next ``slots * buffers_per_slot - 1`` submissions, so a consumer (host copy,
-    RCCL gather) can run on its own stream without holding the slot's next batch back."""
+    output sets (allocated once for ``net.max_batch`` images; smaller batches get leading views) and stay valid for the
+    next ``slots * buffers_per_slot - 1`` submissions, so a consumer (host copy, RCCL gather) can run on its own stream
+    without holding the slot's next batch back.  Reuse is safe by construction, see Ticket."""
 
     def __init__(self, net, slots=2, top_k=400, buffers_per_slot=2):
         assert slots >= 1 and buffers_per_slot >= 1
@@ -41,34 +56,37 @@ class DetectPipeline(object):
             self.streams = [torch.cuda.Stream(device=net.device) for _ in self.slots]
         self.ready = [torch.cuda.Event() for _ in self.slots]
         n_sets = len(self.slots) * buffers_per_slot
-        self.buffers = [None] * n_sets
-        self.consumed = [torch.cuda.Event() for _ in range(n_sets)]
-        self._released = [False] * n_sets
+        self.buffers = [ops.DetectionBuffers(net.max_batch, top_k, net.device) for _ in range(n_sets)]
+        for b, buf in enumerate(self.buffers):
+            buf.record_stream(self.streams[b % len(self.slots)])
+        self._tickets = [None] * n_sets
         self._next = 0
 
     def submit(self, images, **detect_args):
         b = self._next                                # output set; slot = b % slots
         self._next = (b + 1) % len(self.buffers)
         i = b % len(self.slots)
-        n = images.shape[0]
-        if self.buffers[b] is None or self.buffers[b].n != n:
-            self.buffers[b] = ops.DetectionBuffers(n, self.top_k, self.net.device)
+        out = self.buffers[b].narrow(images.shape[0])
         cur = torch.cuda.current_stream()
         self.ready[i].record(cur)                     # `images` are settled on the caller's stream
         s = self.streams[i]
         s.wait_event(self.ready[i])
-        if self._released[b]:                         # whoever read this output set last has said when it was done
-            s.wait_event(self.consumed[b])
+        prev = self._tickets[b]
+        if prev is not None:                          # the batch that used this output set last
+            prev._expired = True
+            if prev._release_event is not None:       # its reader said when it was done
+                s.wait_event(prev._release_event)
+            elif prev._consumer is not None:          # it did not: wait for everything its stream holds right now
+                ev = torch.cuda.Event()
+                ev.record(prev._consumer)
+                s.wait_event(ev)
         with torch.cuda.stream(s):
-            self.slots[i].detect(images, top_k=self.top_k, out=self.buffers[b], **detect_args)
+            self.slots[i].detect(images, top_k=self.top_k, out=out, **detect_args)
             done = torch.cuda.Event()
             done.record(s)
-        self._released[b] = False
-        return Ticket(self.buffers[b], done, lambda: self._release(b))
-
-    def _release(self, b):
-        self.consumed[b].record(torch.cuda.current_stream())
-        self._released[b] = True
+        t = Ticket(out, done)
+        self._tickets[b] = t
+        return t
 
     def synchronize(self):
         for s in self.streams:

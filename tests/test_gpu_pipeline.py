@@ -67,6 +67,57 @@ def test_pipeline_three_slots_many_batches():
     net.close()
 
 
+def test_slow_consumer_never_reads_overwritten_records():
+    """A consumer stream that lags (a long kernel sits in front of each of its reads) and never calls release(): the
+    slot must wait for it before it overwrites an output set -- reuse is safe by construction, not by convention."""
+    from ron_tensorflow_amd import weights as W
+    from ron_tensorflow_amd.pipeline import DetectPipeline
+    net = _net()
+    fields = ('count', 'classes', 'scores', 'bboxes', 'anchor_index')
+    batches = [torch.from_numpy(W.synthetic_images(4, seed=40 + i)).cuda() for i in range(6)]
+    refs = []
+    for b in batches:
+        d = net.detect(b)
+        refs.append({k: getattr(d, k).clone() for k in fields})
+    torch.cuda.synchronize()
+    assert any(not torch.equal(refs[0]['scores'], r['scores']) for r in refs[1:])
+    pipe = DetectPipeline(net, slots=2, buffers_per_slot=1)          # an output set comes round after two submissions
+    consumer = torch.cuda.Stream()
+    copies = []
+    for b in batches:
+        t = pipe.submit(b)
+        with torch.cuda.stream(consumer):
+            d = t.wait()
+            torch.cuda._sleep(40 * 1000 * 1000)                      # tens of ms: several forward passes long
+            copies.append({k: getattr(d, k).clone() for k in fields})
+    torch.cuda.synchronize()
+    for i, (c, r) in enumerate(zip(copies, refs)):
+        for k in fields:
+            assert torch.equal(c[k], r[k]), (i, k)
+    pipe.close()
+    net.close()
+
+
+def test_ticket_of_a_reused_output_set_fails_loudly():
+    from ron_tensorflow_amd import weights as W
+    from ron_tensorflow_amd.pipeline import DetectPipeline
+    net = _net()
+    x = torch.from_numpy(W.synthetic_images(2, seed=50)).cuda()       # a batch below max_batch: leading views of the set
+    pipe = DetectPipeline(net, slots=1, buffers_per_slot=1)
+    t0 = pipe.submit(x)
+    t1 = pipe.submit(x)
+    with pytest.raises(RuntimeError):
+        t0.wait()
+    d = t1.wait()
+    assert d.n == 2 and tuple(d.scores.shape) == (2, 400)
+    torch.cuda.synchronize()
+    ref = net.detect(x)
+    torch.cuda.synchronize()
+    _same(ref, d)
+    pipe.close()
+    net.close()
+
+
 def test_pack_detections_matches_torch_packing():
     from ron_tensorflow_amd import parallel
     from ron_tensorflow_amd import weights as W

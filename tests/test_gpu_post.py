@@ -250,3 +250,16 @@ def test_list_sort_nms_random_vs_oracle(ops, dev):
         assert np.array_equal(got['anchor_index'], idx)
         assert np.array_equal(got['scores'], s)
         assert np.array_equal(got['bboxes'], b)
+
+
+def test_list_sort_handles_negative_zero_and_nan_scores(ops, dev):
+    """Caller-supplied lists may hold any float (raw logits): order of np.argsort(-scores), np_methods.py:137-150."""
+    scores = np.array([0.5, -0.25, 0.0, -0.0, -3.0, 2.0, np.nan, -1e-30, 1e-30, -np.inf, np.inf], np.float32)
+    n = scores.shape[0]
+    classes = np.arange(1, n + 1).astype(np.int64)                  # all different: nothing is suppressed
+    boxes = np.tile(np.array([[.1, .1, .5, .5]], np.float32), (n, 1))
+    got, srt = _run_list(ops, dev, classes, scores, boxes)
+    with np.errstate(invalid='ignore'):
+        order = np.argsort(-scores, kind='stable')
+    assert list(srt['anchor_index']) == list(order)
+    assert list(got['anchor_index']) == list(order)

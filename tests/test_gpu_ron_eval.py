@@ -20,6 +20,10 @@ CASES = [  # seed, batch, bg, ob, obj_thr, sel_thr, nms_thr, keep_top_k, mode
     (301, 1, 1.0, 2.0, 0.7, 0.2, 0.4, 200, 'union'),       # more candidates than the 512-row NMS window
     (302, 2, 3.0, 0.0, 0.5, 0.4, 0.3, 50, 'min'),
     (303, 1, 30.0, -30.0, 0.95, 0.6, 0.4, 20, 'union'),    # nothing passes
+    # 20 167 / 16 056 candidates and heavy suppression: kept rows sit at score ranks up to 19 174, far beyond one
+    # 1 024-row pass of the NMS kernel (the reference, ron_eval.py:111-144, takes all candidates)
+    (304, 1, 0.0, 3.0, 0.1, 0.05, 0.1, 400, 'union'),
+    (305, 1, 1.0, 2.0, 0.3, 0.1, 0.05, 300, 'min'),
 ]
 
 
