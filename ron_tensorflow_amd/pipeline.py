@@ -5,9 +5,15 @@ rounds; 800 tiles = 3.125 ...) and with prologue / epilogue phases in which the 
 hides both by keeping a second batch in flight: while one slot's launch drains, the other slot's launch fills the
 free CUs.  The slots are ``ron_clone`` contexts (shared packed weights, own activations / scratch / head buffers),
 each fed on its own HIP stream; results are handed back through events, nothing blocks the host."""
-import torch
+import os
 
-from . import ops
+# one hardware queue per stream (slots + consumer + RCCL + default > the runtime's default of 4; streams that share a queue
+# serialise behind each other).  Read by the HIP runtime when it initialises, i.e. no effect if a kernel has already run.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+import torch  # noqa: E402
+
+from . import ops  # noqa: E402
 
 
 class Ticket(object):
