@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libron_hip.so')
+# tooling (tools/sweep_conv.py --exp / --diag) may point RON_HIP_LIB at the experimental / diagnostic build of the same ABI
+LIB_PATH = os.environ.get('RON_HIP_LIB') or os.path.join(_HERE, 'libron_hip.so')
 
 RON_MAX_LAYERS = 8
 RON_MAX_TOPK = 512

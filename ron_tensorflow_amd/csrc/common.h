@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -32,5 +33,29 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// hipFuncSetAttribute applies to the current device only: one of these per kernel instantiation remembers on which
+// devices (id < 64) it has been done.  first() is true once per device, from whichever host thread gets there first.
+struct PerDeviceOnce {
+  std::atomic<uint64_t> done{0};
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;      // unknown device: just set it again
+    const uint64_t bit = 1ull << dev;
+    return (done.fetch_or(bit) & bit) == 0;
+  }
+};
+
+// Makes `device` current for the lifetime of the guard and restores the caller's device afterwards.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) { err = hipSetDevice(device); switched = err == hipSuccess; }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 
 }  // namespace ron

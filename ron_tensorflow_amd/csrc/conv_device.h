@@ -170,8 +170,109 @@ template <> struct SmallShape<TraitsF16> { typedef TraitsF16S type; };
 template <> struct SmallShape<TraitsF32> { typedef TraitsF32S type; };
 
 constexpr int kRowBytes = 128;   // one LDS row = one K chunk of one tile row
+constexpr int kWeightBlockBytes = kWeightBlockRows * kRowBytes;   // one (64 rows, K step) block of the packed weights
 
 typedef __attribute__((address_space(3))) void lds_void;
+
+// Everything after the K loop, shared by the row-gather and the halo-patch kernel.  A lane holds, for each of its MR row
+// tiles, EPA accumulator registers (rows row0 + i*MT + (e & 3) + 8 * (e >> 2) + 4 * fh of the workgroup tile) times NR
+// ADJACENT output channels starting at n_glob (bias / validity) = channel n_store of the output view: + bias, ReLU,
+// optional relu(x + residual) (reverse-connection sum, nets/ron_vgg_320.py:425), optional fused 2x2 max-pool (tile rows
+// are ordered window-major, so a pool window is four consecutive accumulator registers of one lane), one vector store
+// per row (dtype or fp32).  s_out_off[row] = element offset of the row's output pixel, -1 for rows that store nothing.
+template <class Tr, int MR, int NR, int MT, int EPA>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, typename Tr::acc_t (&acc)[MR][NR], const int* s_out_off, int row0,
+                                              int fh, int n_glob, int n_store, int tap_off) {
+  float bias_v[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) bias_v[j] = p.bias[n_glob + j];
+  const int n_valid = p.Cout - n_glob;                 // channels of this lane's group that exist (may be <= 0)
+  if (n_valid <= 0) return;
+  if (p.pool) {
+    // max over the 2x2 window = max over registers 4t..4t+3; relu(max(x) + b) == max(relu(x + b))
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+      for (int t = 0; t < EPA / 4; ++t) {
+        const int ooff = s_out_off[row0 + i * MT + 8 * t + 4 * fh];
+        if (ooff < 0) continue;
+        float v[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const float mx = fmaxf(fmaxf(acc[i][j][4 * t], acc[i][j][4 * t + 1]), fmaxf(acc[i][j][4 * t + 2], acc[i][j][4 * t + 3]));
+          v[j] = mx + bias_v[j];
+          if (p.relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        const int o = ooff + n_store;
+        if (n_valid >= NR) {
+          Tr::template store_vec<NR>(p.out, o, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NR; ++j) if (j < n_valid) Tr::store(p.out, o + j, v[j]);
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+#pragma unroll
+    for (int e = 0; e < EPA; ++e) {
+      const int ooff = s_out_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
+      if (ooff < 0) continue;
+      const int o = ooff + tap_off + n_store;
+      float v[NR];
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        v[j] = acc[i][j][e] + bias_v[j];
+        if (p.relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (n_valid >= NR) {
+        if (p.res != nullptr) {
+          float rv[NR];
+          Tr::template load_vec<NR>(p.res, o, rv);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j] + rv[j], 0.f);
+        }
+        if (p.out_f32) store_f32_vec<NR>(reinterpret_cast<float*>(p.out) + o, v);
+        else Tr::template store_vec<NR>(p.out, o, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          if (j >= n_valid) break;
+          float x = v[j];
+          if (p.res != nullptr) x = fmaxf(x + Tr::load(p.res, o + j), 0.f);
+          if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = x;
+          else Tr::store(p.out, o + j, x);
+        }
+      }
+    }
+  }
+}
+
+// Geometry / pointers of a launch -> kernel arguments (tiling fields are the caller's).
+inline void fill_conv_args(const ConvLaunch& c, ConvArgs* out) {
+  ConvArgs a = ConvArgs();
+  const int chunk = kRowBytes / (int)dtype_size(c.dtype);
+  a.in = c.in.base; a.in_bytes = (unsigned)c.in.bytes;
+  a.wgt = c.wgt; a.wgt_bytes = (unsigned)c.wgt_bytes;
+  a.bias = c.bias; a.out = c.out.base; a.res = c.res;
+  a.Ho = c.Ho; a.Wo = c.Wo; a.M = c.in.N * c.Ho * c.Wo;
+  a.in_Hp = c.in.Hp(); a.in_Wp = c.in.Wp(); a.in_cstride = c.in.cstride; a.in_org = c.in.pad - c.cpad;
+  a.in_coff = c.in.coff;
+  a.Cin = c.in.C; a.kw = c.kw; a.K = c.kh * c.kw * c.in.C; a.KT = a.K / chunk;
+  a.stride = c.stride; a.dil = c.dil;
+  a.Cout = c.Cout;
+  a.out_Hp = c.out.Hp(); a.out_Wp = c.out.Wp(); a.out_cstride = c.out.cstride; a.out_pad = c.out.pad;
+  a.out_coff = c.out.coff;
+  a.up = c.up; a.up_cout = c.up_cout;
+  a.relu = c.relu; a.out_f32 = c.out_f32;
+  a.Npad = c.Npad;
+  a.splitk = 1; a.kt_split = a.KT; a.partial = nullptr;
+  a.pool = c.pool;
+  a.dbg = c.dbg;
+  *out = a;
+}
 
 }  // namespace detail
 }  // namespace ron

@@ -6,19 +6,25 @@
 
 namespace ron {
 
-// NHWC activation tensor in HBM.  Every activation carries a zero halo of `pad` pixels so the
-// 3x3 / 7x7 / dilated taps never need a bounds check: memory is [N][H+2pad][W+2pad][cstride],
-// element type = the ctx dtype (bf16 / f16 / f32).  A view may address a channel slice
-// [coff, coff + C) of a wider tensor.
+// NHWC activation tensor in HBM with SHARED zero halos: rows are W + pad pixels long (the right halo of a row is the
+// left halo of the next one), images are H + pad rows apart (the bottom halo of an image is the top halo of the next),
+// one more band of `pad` rows + `pad` pixels closes the allocation.  Pixel (n, y, x) sits at row n*(H+pad) + pad + y,
+// column pad + x; a tap that leaves the image lands in a halo pixel whichever side it leaves on, so the 3x3 / 7x7 /
+// dilated taps never need a bounds check.  Kernels write interiors only; halos are zeroed once at allocation.
+// The flat view matters to conv_patch.hip: positions that are consecutive in memory are consecutive pixels of the map
+// with only `pad` halo pixels per row between them (4.8 % of a 40 x 40 map, not 9.3 %).
+// Element type = the ctx dtype (bf16 / f16 / f32).  A view may address a channel slice [coff, coff + C) of a wider tensor.
 struct TensorView {
-  void* base = nullptr;      // start of the allocation (pixel (0,-pad,-pad), channel 0)
+  void* base = nullptr;      // start of the allocation (row 0, column 0, channel 0)
   int64_t bytes = 0;         // size of the allocation
   int N = 0, H = 0, W = 0, C = 0;
   int pad = 0;
   int cstride = 0;           // elements per pixel in memory
   int coff = 0;              // first channel of the view
-  int Hp() const { return H + 2 * pad; }
-  int Wp() const { return W + 2 * pad; }
+  int Hp() const { return H + pad; }     // rows from one image to the next
+  int Wp() const { return W + pad; }     // pixels per row
+  int64_t pixels() const { return halo_pixels(N, H, W, pad); }
+  static int64_t halo_pixels(int n, int h, int w, int pad) { return ((int64_t)n * (h + pad) + pad) * (w + pad) + pad; }
 };
 
 struct ConvLaunch {
@@ -38,25 +44,57 @@ struct ConvLaunch {
   int up_cout = 0;               // channels per tap of the transposed conv (Cout = up*up*up_cout)
   int Ho = 0, Wo = 0;            // GEMM rows = N*Ho*Wo (input grid for a transposed conv)
   int pool = 0;                  // fuse slim.max_pool2d [2,2] into the epilogue: `out` is the pooled map
-  int cfg = -1;                  // tile configuration index (conv_mfma.hip kCfgs); -1 = pick by shape
+  int cfg = -1;                  // tile configuration (kCfg* below); -1 = pick by shape
   int splitk = -1;               // split-K factor; -1 = pick by grid size, 1 = off
   void* scratch = nullptr;       // fp32 slabs for split-K (conv_scratch_bytes); null disables split-K
   int64_t scratch_bytes = 0;
-  unsigned long long* dbg = nullptr;   // stamp builds (tile cfgs 27-29): 4 x u64 per wave of the grid
+  unsigned long long* dbg = nullptr;   // diagnostic library only (stamp builds): 4 x u64 per wave of the grid
 };
 
+constexpr int kWeightBlockRows = 64;     // packed weights: [Npad / 64][K steps][64 rows][128 B] (pack.h, block_rows)
+
+// Tile configurations of the shipped library: exactly the ones conv_pick_cfg() can return (ron_conv_num_tile_cfgs()).
+enum {
+  kCfgIgemm256 = 0,        // row-gather kernel (conv_mfma.hip), 256 x 256 tile, 8 waves, 128 KB LDS
+  kCfgIgemm128 = 1,        // 128 x 128, 4 waves, 2 workgroups / CU
+  kCfgIgemm128Early = 2,   // ... with a stage's LDS-DMA pieces issued during its first k-step
+  kCfgIgemm128x64 = 3,     // 128 x 64 (Cout <= 64 and the skinny heads)
+  kCfgPatch256 = 4,        // halo-patch kernel (conv_patch.hip), 256 positions x 256 channels
+  kCfgPatch128 = 5,        // ... x 128 channels, 3 weight stages
+  kCfgPatch64 = 6,         // ... x 64 channels, 3 weight stages
+  kNumCfgs = 7,
+  // experimental builds only (make EXP=1 -> libron_hip_exp.so, tools/sweep_conv.py): timing variants, some with wrong results
+  kExpPatch128S4 = 7,      // halo-patch, 128 channels, 4 weight stages (three steps of lead)
+  kExpPatch256NoA = 8,     // halo-patch 256 without the patch traffic / without the weight traffic / without either
+  kExpPatch256NoB = 9,
+  kExpPatch256NoAB = 10,
+  kExpIgemm256NoA = 11,    // row-gather 256 x 256 likewise
+  kExpIgemm256NoB = 12,
+  kExpIgemm256NoAB = 13,
+  kExpIgemm256BFirst = 14, // row-gather 256 x 256 with the weight pieces of a stage issued before the activation pieces
+  kExpIgemm256Early = 15,  // ... with all pieces of a stage issued during its first k-step
+#ifdef RON_EXP
+  kNumCfgsBuilt = 16
+#else
+  kNumCfgsBuilt = kNumCfgs
+#endif
+};
+inline bool conv_cfg_is_patch(int cfg) {
+  return (cfg >= kCfgPatch256 && cfg <= kCfgPatch64) || (cfg >= kExpPatch128S4 && cfg <= kExpPatch256NoAB);
+}
+
 int launch_conv(const ConvLaunch& c, hipStream_t stream);
-// 3x3 / stride 1 / pad 1 with the input halo patch staged once per channel chunk (conv_patch.hip); cfg = kCfgPatch forces it
-constexpr int kCfgPatch = 100;
+// 3x3 / stride 1 / pad 1 with the input halo patch staged once per channel chunk (conv_patch.hip)
 bool conv_patch_applicable(const ConvLaunch& c);
-int launch_conv_patch(const ConvLaunch& c, hipStream_t stream);
+int conv_patch_pick(const ConvLaunch& c);          // kCfgPatch* when the patch kernel is the better choice for this launch, else -1
+int launch_conv_patch(const ConvLaunch& c, int cfg, hipStream_t stream);
 // Elements along K one staging step covers for this dtype (Cin must be a multiple of it).
 int conv_k_chunk(int dtype);
 int conv_n_tile(int cout);       // granularity Cout is padded to (64 or 128)
 int conv_num_cfgs();
-int conv_pick_cfg(int M, int Npad, int K);
+int conv_pick_cfg(const ConvLaunch& c);
 int conv_pick_splitk(int tiles, int KT, int slots);
-int64_t conv_scratch_bytes(int M, int Npad, int K, int dtype, int cfg, int splitk);
+int64_t conv_scratch_bytes(const ConvLaunch& c);   // fp32 split-K slabs this launch can ask for (0: none)
 size_t dtype_size(int dtype);
 
 // conv1_1 (stem.hip): 3 -> 64 channels straight from the fp32 image, bf16 / f16 only

@@ -29,7 +29,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // Tile configuration: BM x BN block tile, WM x WN waves (each wave owns (BM/WM) x (BN/WN)), S LDS stages.
 // SPREAD 1: the LDS-DMA pieces of a tile are shared out over the k-steps of the stage; 2: all go out during k-step 0.
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
+// EXP (experimental builds only, make EXP=1): 1 = the A descriptor has no records (only the weights move), 2 = the B
+// descriptor has none, 3 = neither moves.  Timing-only, results are wrong; 0 in everything the shipped library holds.
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0>
 __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * kRowBytes > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
   constexpr int kLanesPerRow = kRowBytes / 16;       // 16-byte chunks per row
   constexpr int MT = Tr::kMT;                        // MFMA output tile (16)
@@ -138,14 +140,15 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * kRowBytes > 80 * 102
     /* past the last tile: zero-record descriptors, the DMA moves nothing but keeps the vmcnt bookkeeping uniform */  \
     const bool live_ = (kt_) < kt1;                                                                                  \
     const __amdgpu_buffer_rsrc_t rs_a =                                                                              \
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, live_ ? p.in_bytes : 0u, 0x00020000);          \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (live_ && !(EXP & 1)) ? p.in_bytes : 0u, 0x00020000); \
     const __amdgpu_buffer_rsrc_t rs_b =                                                                              \
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, live_ ? p.wgt_bytes : 0u, 0x00020000);        \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (live_ && !(EXP & 2)) ? p.wgt_bytes : 0u, 0x00020000); \
     const int a_soff = ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz;                         \
     const int b_soff = (kt_) * kWeightBlockBytes;                                                                    \
     char* dst = smem + (((kt_) - kt0) % S) * kStage + wave * 1024;
-#define RON_STAGE_PIECE(i_)                                                                                          \
+#define RON_STAGE_PIECE(j_)                                                                                          \
     do {                                                                                                             \
+      const int i_ = (EXP & 4) ? ((j_) + A_IT) % LPT : (j_);   /* EXP 4: the weight pieces go out first */               \
       if ((i_) < A_IT)                                                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst + (i_) * kRowsPerIt * kRowBytes), 16,         \
                                                  a_voff[(i_) < A_IT ? (i_) : 0], a_soff, 0, 0);                      \
@@ -303,14 +306,14 @@ __global__ void splitk_finalize_kernel(ConvArgs p) {
   }
 }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0>
 int launch_t(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)S * (BM + BN) * kRowBytes + 2 * BM * sizeof(int);
   static PerDeviceOnce once;
   if (once.first())
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD>),
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -322,6 +325,13 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case kCfgIgemm128: return launch_t<Tr, 128, 128, 2, 2, 2, 1>(a, s);
     case kCfgIgemm128Early: return launch_t<Tr, 128, 128, 2, 2, 2, 2>(a, s);
     case kCfgIgemm128x64: return launch_t<Tr, 128, 64, 2, 2, 2, 2>(a, s);
+#ifdef RON_EXP
+    case kExpIgemm256NoA: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 1>(a, s);
+    case kExpIgemm256NoB: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 2>(a, s);
+    case kExpIgemm256NoAB: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 3>(a, s);
+    case kExpIgemm256BFirst: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 4>(a, s);
+    case kExpIgemm256Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0>(a, s);
+#endif
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;
@@ -342,17 +352,18 @@ using namespace detail;
 size_t dtype_size(int dtype) { return dtype == RON_DTYPE_F32 ? 4 : 2; }
 int conv_k_chunk(int dtype) { return kRowBytes / (int)dtype_size(dtype); }
 int conv_n_tile(int cout) { return cout <= 64 ? 64 : 128; }
-int conv_num_cfgs() { return kNumCfgs; }
+int conv_num_cfgs() { return kNumCfgsBuilt; }
 
-static int igemm_bm(int cfg) { return cfg == kCfgIgemm256 ? 256 : 128; }
-static int igemm_bn(int cfg) { return cfg == kCfgIgemm256 ? 256 : (cfg == kCfgIgemm128x64 ? 64 : 128); }
+static bool igemm_is256(int cfg) { return cfg == kCfgIgemm256 || (cfg >= kExpIgemm256NoA && cfg <= kExpIgemm256Early); }
+static int igemm_bm(int cfg) { return igemm_is256(cfg) ? 256 : 128; }
+static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : (cfg == kCfgIgemm128x64 ? 64 : 128); }
 // workgroups of a configuration the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
-static int igemm_slots(int cfg) { return cfg == kCfgIgemm256 ? 256 : 512; }
+static int igemm_slots(int cfg) { return igemm_is256(cfg) ? 256 : 512; }
 
 // Split-K factor for grids that leave most CUs idle: such launches are a serial chain of KT dependent
 // HBM round trips per workgroup, so the K loop is spread over enough workgroups to fill the chip (>= 8 steps each).
 int conv_pick_splitk(int tiles, int KT, int slots) {
-  if (tiles * 2 > slots || KT < 16) return 1;
+  if (tiles < 1 || tiles * 2 > slots || KT < 16) return 1;
   int sk = slots / tiles;
   if (sk > KT / 8) sk = KT / 8;
   return sk < 1 ? 1 : sk;
@@ -369,8 +380,7 @@ int conv_pick_igemm_cfg(int M, int Npad) {
   return ((M + 127) / 128) * (Npad / 128) >= 2048 ? kCfgIgemm128Early : kCfgIgemm128;
 }
 
-// The halo-patch kernel (conv_patch.hip) where it applies and wins: 3x3 / stride 1 convs on maps it tiles without waste
-// (16 x 16 pixel tiles) or nearly so (flat runs of 256 positions on maps <= 42 pixels wide), once the grid fills the chip.
+// The halo-patch kernel (conv_patch.hip) where it applies and wins (conv_patch_pick), else the row-gather kernel.
 int conv_pick_cfg(const ConvLaunch& c) {
   const int M = c.in.N * c.Ho * c.Wo;
   if (conv_patch_applicable(c)) {
@@ -382,8 +392,8 @@ int conv_pick_cfg(const ConvLaunch& c) {
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg(c);
-  RON_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "conv: tile config %d out of range [0, %d)", cfg, kNumCfgs);
-  if (cfg >= kCfgPatch256) return launch_conv_patch(c, cfg, stream);
+  RON_REQUIRE(cfg >= 0 && cfg < kNumCfgsBuilt, "conv: tile config %d out of range [0, %d)", cfg, kNumCfgsBuilt);
+  if (conv_cfg_is_patch(cfg)) return launch_conv_patch(c, cfg, stream);
   const int esz = (int)dtype_size(c.dtype);
   const int chunk = conv_k_chunk(c.dtype);
   RON_REQUIRE(c.in.C % chunk == 0, "conv: Cin %d is not a multiple of the K chunk %d", c.in.C, chunk);
@@ -427,7 +437,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
 
 int64_t conv_scratch_bytes(const ConvLaunch& c) {
   const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg(c);
-  if (cfg >= kCfgPatch256 || c.up > 0 || c.pool) return 0;      // the halo-patch kernel never splits K
+  if (conv_cfg_is_patch(cfg) || c.up > 0 || c.pool) return 0;      // the halo-patch kernel never splits K
   const int M = c.in.N * c.Ho * c.Wo;
   const int KT = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
   const int tiles = ((M + igemm_bm(cfg) - 1) / igemm_bm(cfg)) * (c.Npad / igemm_bn(cfg));

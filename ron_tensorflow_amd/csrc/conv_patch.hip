@@ -1,0 +1,386 @@
+// 3x3 / stride-1 / pad-1 convolution with an LDS-staged input halo patch (gfx950).
+//
+// The row-gather kernel (conv_mfma.hip) re-stages the A operand for every filter tap: the same input pixels travel
+// L2 -> LDS nine times, and with the K loop ordered tap-major the nine uses of a line are ~16 MB of other traffic apart,
+// so they come from beyond the XCD's L2 (round 1: 9.0 M fabric read requests for a launch whose input is 57 MB).  The
+// memory side, not the matrix cores, bounded that kernel.
+//
+// Here a workgroup owns 256 output positions and BN output channels.  Per 128-byte channel chunk it stages the input
+// patch those positions need ONCE (LDS-DMA, double buffered across chunks, one piece per tap step) and runs the nine taps
+// against it: the A fragment of tile row r for tap (ky, kx) is patch row pp(r) + ky*PW + kx, an LDS address shift.  Only
+// the weights (BN x 128 B per step) are staged per tap.  Two tilings, chosen per map on the host (PatchGeom):
+//   * pixel tile TH x TW (16 x 16, or 32 x 8) on maps these divide: no tile row is wasted, patch = (TH+2) x (TW+2) rows;
+//   * FLAT run of 256 consecutive positions of the input tensor's memory order, for maps <= 42 pixels wide.  Activations
+//     carry SHARED halos (conv_mfma.h, TensorView): consecutive positions are consecutive pixels with only `pad` halo
+//     positions per row between them, and a run may cross rows and images.  Patch = 256 + 2*(Wp+1) rows of the same
+//     order, tap shift = ky*Wp + kx.  A 40 x 40 map wastes 4.8 % of the rows (the halo positions), where 6 x 40-pixel
+//     tiles wasted 15 %.
+// Patch rows are 128 B; the 16-B chunk c of patch row i sits in slot c ^ key(i), key(i) = ((i >> 1) & 3) << 1: with the
+// 16-row fragments of the 16x16 MFMA this is conflict-free for ds_read_b128 at EVERY start row (a tap shift moves a
+// fragment to an arbitrary start), as long as the fragment's rows are consecutive patch rows.
+// MFMA, fragment double buffering, pinned issue order, weight row permutation and the epilogue are conv_mfma.hip's.
+#include "conv_device.h"
+
+namespace ron {
+namespace detail {
+
+constexpr int kPatchPieces = 6;                  // LDS-DMA pieces per thread and chunk (512 threads x 16 B = 64 rows each)
+constexpr int kPatchRows = 344;                  // rows a patch buffer holds (43 KB): 18 x 18, 34 x 10, 256 + 2 * 44
+
+__device__ __forceinline__ int patch_key(int i) { return ((i >> 1) & 3) << 1; }
+
+struct PatchArgs {
+  ConvArgs c;
+  int flat;                   // 1: runs of 256 positions; 0: TH x TW pixel tiles
+  int TH, TW, PW;             // pixel tile; PW = patch rows per tap row (TW + 2, flat: the tensor's row pitch Wp)
+  int tiles_x, tiles_y;       // pixel tiles per image
+  int H, W, pad;              // map (conv output == input size) and the input tensor's halo
+  int chunks;                 // Cin / chunk elements
+  int P0;                     // flat: first position (pixel index in the input tensor) of tile 0
+  int n_img;
+  unsigned max_pixel;         // last pixel index of the input allocation (patch addresses are clamped to it)
+};
+
+// SB weight stages: SB-1 steps of lead for the per-tap weight tiles.
+// EXP (experimental builds only, make EXP=1; 0 in everything the shipped library holds): bit 0 = no patch traffic, bit 1 =
+// no weight traffic (zero-record descriptors: timing only, results wrong).
+template <class Tr, int BN, int WN, int SB, int EXP = 0>
+__global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
+  const ConvArgs& p = pa.c;
+  constexpr int BM = 256, WM = 8 / WN, kThreads = 512;
+  constexpr int MT = Tr::kMT, kGroups = 64 / MT, KS = 8 / kGroups, EPA = MT * MT / 64;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MR = TM / MT, NR = TN / MT;
+  constexpr int B_IT = BN / 64;                   // B pieces per thread and step
+  constexpr int G = B_IT + 1;                     // LDS-DMA instructions per thread and step (the weights + one patch piece)
+  constexpr int kPatchBytes = kPatchRows * kRowBytes;
+  constexpr int kBBytes = BN * kRowBytes;
+  static_assert(MT == 16 && TM % MT == 0 && TN % MT == 0 && NR <= 8 && SB >= 2, "bad wave tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // layout: [patch 0][patch 1][B stage 0 .. SB-1][pp: BM ints][out_off: BM ints][sink 1 KB]
+  char* s_b = smem + 2 * kPatchBytes;
+  int* s_pp = reinterpret_cast<int*>(s_b + SB * kBBytes);
+  int* s_out_off = s_pp + BM;
+  // a zero-record LDS-DMA still writes (zeros): the placeholder pieces that keep the vmcnt groups uniform land here
+  char* s_sink = reinterpret_cast<char*>(s_out_off + BM);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const unsigned nwg = gridDim.x, bid = blockIdx.x;
+  const unsigned xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
+  const unsigned wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_n = (int)(wgid % (unsigned)p.tiles_n);
+  const unsigned tsp = wgid / (unsigned)p.tiles_n;           // spatial tile
+  const int n0 = tile_n * BN;
+  const int Wp = p.in_Wp, Hp = p.in_Hp;
+
+  // tile row -> patch row of tap (0,0) and output offset; first pixel (index in the input tensor) of the patch
+  int patch_pix0;
+  if (pa.flat) {
+    const int Pt = pa.P0 + (int)tsp * BM;
+    patch_pix0 = Pt - Wp - 1;
+    for (int r = tid; r < BM; r += kThreads) {
+      const int P = Pt + r;
+      const int row = P / Wp, x = P - row * Wp - pa.pad;
+      const int rr = row - pa.pad;
+      const int img = rr / Hp, y = rr - img * Hp;
+      const bool valid = x >= 0 && y < pa.H && img < pa.n_img;
+      s_pp[r] = r;
+      s_out_off[r] = valid ? ((img * p.out_Hp + y + p.out_pad) * p.out_Wp + x + p.out_pad) * p.out_cstride + p.out_coff : -1;
+    }
+  } else {
+    unsigned t = tsp;
+    const int tx = (int)(t % (unsigned)pa.tiles_x); t /= (unsigned)pa.tiles_x;
+    const int ty = (int)(t % (unsigned)pa.tiles_y);
+    const int img = (int)(t / (unsigned)pa.tiles_y);
+    const int y0 = ty * pa.TH, x0 = tx * pa.TW;
+    patch_pix0 = (img * Hp + pa.pad + y0 - 1) * Wp + pa.pad + x0 - 1;
+    for (int r = tid; r < BM; r += kThreads) {
+      int ly, lx;
+      if (p.pool) {                                           // window-major: rows 4w .. 4w+3 = the 2x2 window w
+        const int w = r >> 2, hw = pa.TW >> 1;
+        ly = 2 * (w / hw) + ((r >> 1) & 1);
+        lx = 2 * (w % hw) + (r & 1);
+      } else {
+        ly = r / pa.TW;
+        lx = r - ly * pa.TW;
+      }
+      const int y = y0 + ly, x = x0 + lx;
+      const bool valid = ly < pa.TH;                          // TH * TW may be < 256
+      s_pp[r] = valid ? ly * pa.PW + lx : 0;
+      int off;
+      if (p.pool) off = ((img * p.out_Hp + (y >> 1) + p.out_pad) * p.out_Wp + (x >> 1) + p.out_pad) * p.out_cstride + p.out_coff;
+      else off = ((img * p.out_Hp + y + p.out_pad) * p.out_Wp + x + p.out_pad) * p.out_cstride + p.out_coff;
+      s_out_off[r] = valid ? off : -1;
+    }
+  }
+
+  // patch pieces of this thread: LDS patch row i = q >> 3 (q = k*512 + tid), slot = q & 7
+  int p_voff[kPatchPieces];
+#pragma unroll
+  for (int k = 0; k < kPatchPieces; ++k) {
+    const int q = k * kThreads + tid;
+    const int i = q >> 3, slot = q & 7;
+    int pix;
+    if (pa.flat) {
+      pix = patch_pix0 + i;
+    } else {
+      const int py = i / (pa.TW + 2), px = i - py * (pa.TW + 2);
+      pix = patch_pix0 + py * Wp + px;
+    }
+    // rows outside the allocation belong to positions that store nothing; keep the address inside it
+    const unsigned upix = min((unsigned)max(pix, 0), pa.max_pixel);
+    p_voff[k] = (int)((upix * (unsigned)p.in_cstride + (unsigned)p.in_coff) * Tr::kEsz) + ((slot ^ patch_key(i)) << 4);
+  }
+  // B pieces: LDS row (j*MT + r) of a wave's TN-wide group <- weight row (r*NR + j)   (coalesced epilogue, see conv_mfma.hip);
+  // weight row n, K step kt at ((n / 64) * KT + kt) * 8 KB + (n % 64) * 128 B
+  int b_voff[4];
+  static_assert(B_IT <= 4, "BN <= 256");
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int lrow = it * 64 + (tid >> 3);
+    const int grp = lrow / TN, loc = lrow % TN;
+    const int nrow = n0 + grp * TN + (loc % MT) * NR + (loc / MT);
+    b_voff[it] = (int)((unsigned)(nrow >> 6) * (unsigned)p.KT * (unsigned)kWeightBlockBytes + (unsigned)(nrow & 63) * kRowBytes) +
+                 (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
+  }
+  __syncthreads();
+
+  const int fr = lane & (MT - 1), fh = lane / MT;
+  int pp[MR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) pp[i] = s_pp[wm * TM + i * MT + fr];
+  int rd_off_b[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) rd_off_b[s] = fr * kRowBytes + (((kGroups * s + fh) ^ ((fr >> 1) & 7)) << 4);
+  const int b_base = wn * TN * kRowBytes;
+
+  // descriptors are rebuilt at the use site with 0 records for pieces that have nothing to fetch
+#define RS_A(live_) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, ((live_) && !(EXP & 1)) ? p.in_bytes : 0u, 0x00020000)
+#define RS_B(live_) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, ((live_) && !(EXP & 2)) ? p.wgt_bytes : 0u, 0x00020000)
+  // piece k_ (compile time) of the patch of chunk cc_ into buffer buf_; a wave whose 8 rows lie past the buffer sinks it
+#define PATCH_PIECE(k_, buf_, cc_, live_)                                                                            \
+  do {                                                                                                               \
+    const bool in_ = (k_) * 64 + wave * 8 + 8 <= kPatchRows;                                                         \
+    char* d_ = in_ ? smem + (buf_) * kPatchBytes + ((k_) * kThreads + wave * 64) * 16 : s_sink;                      \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A((live_) && in_), (lds_void*)d_, 16, p_voff[k_], (cc_) * kRowBytes, 0, 0); \
+  } while (0)
+#define B_PIECE(it_, stage_, soff_, live_)                                                                           \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_B(live_), (lds_void*)(s_b + (stage_) * kBBytes + ((it_) * 64 + wave * 8) * kRowBytes), \
+                                           16, b_voff[it_], soff_, 0, 0)
+
+  typename Tr::acc_t acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int e = 0; e < EPA; ++e) acc[i][j][e] = 0.f;
+
+  // LDS-DMA order.  A wave's vmcnt retires in issue order, so a transfer holds up every younger one at a counted wait.
+  // The patch of the NEXT chunk (six pieces per thread, one per step during taps 0..5) is not needed before that chunk
+  // starts and comes from beyond L2 (first touch), while the weights of the next step are needed one step on and mostly
+  // hit L2.  Every step issues one group of G = B_IT + 1 instructions: the weights of step + SB - 1 FIRST, then one
+  // piece of the next chunk's patch (a zero-record placeholder into the sink when there is none to fetch, so that the
+  // groups stay uniform).  The wait at the top of a step leaves the newest SB-2 groups AND the piece behind them in
+  // flight: a patch piece gets two steps to land, not one (measured: with the piece issued first, the patch stream alone
+  // cost more than the eight times larger weight stream alone).  The prologue is shaped the same way.
+  const int n_steps = pa.chunks * 9;
+#pragma unroll
+  for (int k = 0; k < kPatchPieces; ++k) PATCH_PIECE(k, 0, 0, true);
+#pragma unroll
+  for (int t = 0; t < SB - 1; ++t) {
+    const int soff = ((t % 9) * pa.chunks + t / 9) * kWeightBlockBytes;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) B_PIECE(it, t, soff, t < n_steps);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(false), (lds_void*)s_sink, 16, p_voff[0], 0, 0, 0);
+  }
+
+  int tap = 0, cc = 0, ky = 0, kx = 0;
+  int ntap = (SB - 1) % 9, ncc = (SB - 1) / 9;      // tap / chunk of step + SB - 1
+  int st_rd = 0, st_wr = SB - 1;
+  for (int step = 0; step < n_steps; ++step) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((SB - 2) * G + 1) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* sa = smem + (cc & 1) * kPatchBytes;
+    const char* sb = s_b + st_rd * kBBytes + b_base;
+    if (++st_rd == SB) st_rd = 0;
+    const int tapoff = ky * pa.PW + kx;
+    int a_off[MR];                                       // byte offset of the k-step-0 fragment; k-step 1 is the same ^ 64
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      const int row = pp[i] + tapoff;
+      a_off[i] = row * kRowBytes + ((fh ^ patch_key(row)) << 4);
+    }
+    u32x4 fa[2][MR], fb[2][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) fa[0][i] = *reinterpret_cast<const u32x4*>(sa + a_off[i]);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(sb + j * MT * kRowBytes + rd_off_b[0]);
+    // this step's LDS-DMA group (branch free: the patch piece index is the tap, selected with v_cndmask)
+    {
+      const int soff = (ntap * pa.chunks + ncc) * kWeightBlockBytes;
+      const bool live = ncc < pa.chunks;
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it) B_PIECE(it, st_wr, soff, live);
+      if (++ntap == 9) { ntap = 0; ++ncc; }
+      if (++st_wr == SB) st_wr = 0;
+      const bool more = cc + 1 < pa.chunks && tap < kPatchPieces;
+      int voff = p_voff[0];
+#pragma unroll
+      for (int k = 1; k < kPatchPieces; ++k) voff = tap == k ? p_voff[k] : voff;
+      const bool in_ = tap * 64 + wave * 8 + 8 <= kPatchRows;
+      char* d_ = (more && in_) ? smem + ((cc + 1) & 1) * kPatchBytes + (tap * kThreads + wave * 64) * 16 : s_sink;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(more && in_), (lds_void*)d_, 16, voff, (cc + 1) * kRowBytes, 0, 0);
+    }
+    static_assert(KS == 2, "k-step 1 fragment = k-step 0 fragment ^ 64 bytes");
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      if (s2 < KS - 1) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i) fa[(s2 + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sa + (a_off[i] ^ 64));
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          fb[(s2 + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sb + j * MT * kRowBytes + rd_off_b[s2 + 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) Tr::mma(fa[s2 & 1][i], fb[s2 & 1][j], acc[i][j]);
+    }
+    // issue order: first fragments | k-step 0: MFMAs with the next reads and the G DMA instructions spaced between them |
+    // MFMAs of the last k-step
+    {
+      constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma;
+      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        const int ps = s2 == 0 ? G : 0;
+#pragma unroll
+        for (int q = 0; q < MM; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (s2 < KS - 1 && q < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (((q + 1) * ps) / MM > (q * ps) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        if (s2 < KS - 1 && RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+          if (x < ps - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    if (++tap == 9) { tap = 0; ++cc; ky = 0; kx = 0; }
+    else if (++kx == 3) { kx = 0; ++ky; }
+  }
+#undef PATCH_PIECE
+#undef B_PIECE
+#undef RS_A
+#undef RS_B
+
+  const int nloc = wn * TN + fr * NR;
+  conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n0 + nloc, 0);
+}
+
+template <class Tr, int BN, int WN, int SB, int EXP = 0>
+int launch_patch_t(const PatchArgs& a, int grid, hipStream_t s) {
+  const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
+  static PerDeviceOnce once;
+  if (once.first())
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN, SB, EXP>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((conv3x3_patch_kernel<Tr, BN, WN, SB, EXP>), dim3(grid), dim3(512), lds, s, a);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+// How an H x W map (input halo `pad`) is cut into 256-row tiles; false when the kernel does not apply.
+struct PatchGeom { int flat, TH, TW, tiles_x, tiles_y, tiles_sp; };
+static bool patch_geom(int n, int H, int W, int pad, bool pool, PatchGeom* g) {
+  if (H % 16 == 0 && W % 16 == 0) { g->flat = 0; g->TH = 16; g->TW = 16; }
+  else if (H % 8 == 0 && W % 32 == 0) { g->flat = 0; g->TH = 8; g->TW = 32; }
+  else if (!pool && 256 + 2 * (W + pad + 1) <= kPatchRows) { g->flat = 1; g->TH = 0; g->TW = 0; }
+  else return false;
+  if (g->flat) {
+    // positions from the first row that holds pixels to the end of the last image's last row
+    const int64_t span = ((int64_t)n * (H + pad) - pad) * (W + pad);
+    g->tiles_x = g->tiles_y = 0;
+    g->tiles_sp = (int)((span + 255) / 256);
+  } else {
+    g->tiles_x = W / g->TW; g->tiles_y = H / g->TH;
+    g->tiles_sp = n * g->tiles_x * g->tiles_y;
+  }
+  return true;
+}
+
+}  // namespace detail
+using namespace detail;
+
+bool conv_patch_applicable(const ConvLaunch& c) {
+  PatchGeom g;
+  return c.kh == 3 && c.kw == 3 && c.stride == 1 && c.dil == 1 && c.cpad == 1 && c.up == 0 && c.in.H == c.Ho && c.in.W == c.Wo &&
+         c.in.pad >= 1 && c.Npad % 64 == 0 && c.in.C % conv_k_chunk(c.dtype) == 0 &&
+         patch_geom(c.in.N, c.in.H, c.in.W, c.in.pad, c.pool != 0, &g);
+}
+
+static int patch_bn(int cfg) { return cfg == kCfgPatch64 ? 64 : ((cfg == kCfgPatch128 || cfg == kExpPatch128S4) ? 128 : 256); }
+
+// Where the patch kernel is the better choice (tools/sweep_conv.py on MI355X, profiles/r02/sweep_conv_exp_v*.txt): the skinny
+// heads (Cout <= 64: objectness_score, loc_pred) once the grid fills the chip.  There the row-gather kernel is bound by
+// re-staging the input nine times for almost no arithmetic (b4_loc 68 -> 58 us, b4_obj 67 -> 57 us).  On the wide layers
+// the two kernels are level per executed MFMA (the weight stream, not the activation stream, is what the 2-stage pipeline
+// cannot hide) and the patch kernel pays the halo positions of the flat tiling (4.8 % on 40 x 40), so the
+// row-gather kernel stays the default there.  Below a full grid the row-gather kernel with split-K keeps more CUs busy.
+int conv_patch_pick(const ConvLaunch& c) {
+  PatchGeom g;
+  if (!patch_geom(c.in.N, c.in.H, c.in.W, c.in.pad, c.pool != 0, &g)) return -1;
+  if (c.Npad != 64) return -1;
+  return g.tiles_sp >= 192 ? kCfgPatch64 : -1;
+}
+
+int launch_conv_patch(const ConvLaunch& c, int cfg, hipStream_t stream) {
+  RON_REQUIRE(conv_patch_applicable(c), "patch kernel: not a 3x3 / stride 1 / pad 1 conv on a map it can tile");
+  RON_REQUIRE(conv_cfg_is_patch(cfg) && cfg < kNumCfgsBuilt, "patch kernel: bad tile config %d", cfg);
+  const int BN = patch_bn(cfg);
+  RON_REQUIRE(c.Npad % BN == 0, "patch kernel: Npad %d not a multiple of the N tile %d", c.Npad, BN);
+  const int esz = (int)dtype_size(c.dtype);
+  RON_REQUIRE(c.in.bytes > 0 && c.in.bytes < (int64_t)1 << 32 && c.wgt_bytes < (int64_t)1 << 32, "conv: allocations must be < 4 GiB");
+  RON_REQUIRE(c.out.pixels() * c.out.cstride < (int64_t)1 << 31, "conv: output too large for 32-bit offsets");
+  PatchArgs a = PatchArgs();
+  fill_conv_args(c, &a.c);
+  RON_REQUIRE((int64_t)c.Npad * a.c.K * esz == c.wgt_bytes, "conv: packed weight size mismatch");
+  if (c.pool) RON_REQUIRE(c.res == nullptr && !c.out_f32 && c.out.H == c.Ho / 2 && c.out.W == c.Wo / 2, "conv + fused pool: bad output view");
+  PatchGeom g;
+  patch_geom(c.in.N, c.in.H, c.in.W, c.in.pad, c.pool != 0, &g);
+  a.flat = g.flat; a.TH = g.TH; a.TW = g.TW;
+  a.PW = g.flat ? c.in.Wp() : g.TW + 2;
+  a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
+  a.H = c.in.H; a.W = c.in.W; a.pad = c.in.pad; a.n_img = c.in.N;
+  a.chunks = c.in.C / conv_k_chunk(c.dtype);
+  a.P0 = c.in.pad * c.in.Wp();
+  a.max_pixel = (unsigned)(c.in.bytes / ((int64_t)c.in.cstride * esz) - 1);
+  a.c.tiles_n = c.Npad / BN;
+  const int grid = g.tiles_sp * a.c.tiles_n;
+#ifdef RON_EXP
+#define RON_PATCH_EXP(Tr)                                                                            \
+    if (cfg == kExpPatch128S4) return launch_patch_t<Tr, 128, 2, 4>(a, grid, stream);                \
+    if (cfg == kExpPatch256NoA) return launch_patch_t<Tr, 256, 2, 2, 1>(a, grid, stream);            \
+    if (cfg == kExpPatch256NoB) return launch_patch_t<Tr, 256, 2, 2, 2>(a, grid, stream);            \
+    if (cfg == kExpPatch256NoAB) return launch_patch_t<Tr, 256, 2, 2, 3>(a, grid, stream);
+#else
+#define RON_PATCH_EXP(Tr)
+#endif
+#define RON_PATCH_DISPATCH(Tr)                                                      \
+  do {                                                                              \
+    RON_PATCH_EXP(Tr)                                                               \
+    if (BN == 256) return launch_patch_t<Tr, 256, 2, 2>(a, grid, stream);           \
+    if (BN == 128) return launch_patch_t<Tr, 128, 2, 3>(a, grid, stream);           \
+    return launch_patch_t<Tr, 64, 2, 3>(a, grid, stream);                           \
+  } while (0)
+  if (c.dtype == RON_DTYPE_BF16) RON_PATCH_DISPATCH(TraitsBF16S);
+  if (c.dtype == RON_DTYPE_F16) RON_PATCH_DISPATCH(TraitsF16S);
+  RON_PATCH_DISPATCH(TraitsF32S);
+#undef RON_PATCH_DISPATCH
+#undef RON_PATCH_EXP
+}
+
+}  // namespace ron

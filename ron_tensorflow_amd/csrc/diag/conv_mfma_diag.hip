@@ -1,3 +1,8 @@
+// DIAGNOSTIC BUILD ONLY (make DIAG=1 -> libron_hip_diag.so, used by tools/sweep_conv.py --diag): the round-1 form of the
+// row-gather kernel with every ablation / stamp / experimental switch of DESIGN.md 3.1 (64 tile configurations; ABL != 0
+// builds compute wrong results on purpose).  Never linked into libron_hip.so.  Weights are row-major [Npad][K] here
+// (pack.h, RON_DIAG), not blocked.
+//
 // Implicit-GEMM convolution for gfx950 (CDNA4):   out[m, n] = sum_{tap, c} in[pix(m) + tap, c] * w[n][tap, c]
 //
 //   M = N_img * Ho * Wo output pixels, N = Cout, K = kh*kw*Cin, NHWC activations with a zero halo
@@ -595,18 +600,18 @@ constexpr TileCfg kCfgs[] = {
     {256, 256, 4, 2, 2, 1, 128, 16},   // 62: 30 with non-temporal weight AND activation loads    (results valid)
     {256, 256, 4, 2, 2, 1, 128, 16},   // 63: diagnostic (timing only): taps innermost + non-temporal weight loads
 };
-constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+constexpr int kNumDiagCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+constexpr int kCfgPatchDiag = 100;      // the round-1 halo-patch kernel (diag/conv_patch_diag.hip)
 // workgroups of configuration i the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
 inline int cfg_slots(int i) { return kCfgs[i].stages * (kCfgs[i].bm + kCfgs[i].bn) * kCfgs[i].rb <= 80 * 1024 ? 512 : 256; }
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int ABL = 0, int RB = 128, int ROT = 0>
 int launch_t(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)S * (BM + BN) * RB + 2 * BM * sizeof(int) + (ROT == 2 ? WM * WN * 256 : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  if (once.first()) {
     RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB, ROT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB, ROT>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
@@ -700,7 +705,7 @@ using namespace detail;
 size_t dtype_size(int dtype) { return dtype == RON_DTYPE_F32 ? 4 : 2; }
 int conv_k_chunk(int dtype) { return kRowBytes / (int)dtype_size(dtype); }
 int conv_n_tile(int cout) { return cout <= 64 ? 64 : 128; }
-int conv_num_cfgs() { return kNumCfgs; }
+int conv_num_cfgs() { return kNumDiagCfgs; }
 
 // Split-K factor for grids that leave most CUs idle: such launches are a serial chain of KT dependent
 // HBM round trips per workgroup, so the K loop is spread over enough workgroups to fill the chip (>= 8 steps each).
@@ -715,8 +720,7 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
 // the 16x16x32-MFMA forms (5-19 % over the 32x32x16 forms of the same tile: the chip holds a higher clock on them).
 // The 256x256 tile wins once it yields >= ~160 workgroups; below that the grid is the problem and the 128x128 /
 // 2-workgroups-per-CU form keeps more CUs busy (it also beats the 3-stage 256x128 tile wherever that used to win).
-int conv_pick_cfg(int M, int Npad, int K) {
-  (void)K;
+static int conv_pick_cfg_shape(int M, int Npad) {
   const int tm256 = (M + 255) / 256;
   if (Npad % 128 != 0) return 37;                                   // N tile 64
   if (Npad % 256 == 0 && tm256 * (Npad / 256) >= 160) return 30;
@@ -724,19 +728,22 @@ int conv_pick_cfg(int M, int Npad, int K) {
   return ((M + 127) / 128) * (Npad / 128) >= 2048 ? 36 : 33;
 }
 
+int conv_pick_cfg(const ConvLaunch& c) { return conv_pick_cfg_shape(c.in.N * c.Ho * c.Wo, c.Npad); }
+int conv_patch_pick(const ConvLaunch&) { return -1; }
+
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
-  if (c.cfg == kCfgPatch || c.cfg == kCfgPatch + 1) return launch_conv_patch(c, stream);
+  if (c.cfg == kCfgPatchDiag || c.cfg == kCfgPatchDiag + 1) return launch_conv_patch(c, c.cfg, stream);
   const int esz = (int)dtype_size(c.dtype);
   int chunk = conv_k_chunk(c.dtype);
   RON_REQUIRE(c.in.C % chunk == 0, "conv: Cin %d is not a multiple of the K chunk %d", c.in.C, chunk);
   RON_REQUIRE(c.in.pad >= c.cpad, "conv: input halo %d < conv padding %d", c.in.pad, c.cpad);
   RON_REQUIRE(c.in.bytes > 0 && c.in.bytes < (int64_t)1 << 32, "conv: input allocation must be < 4 GiB for buffer addressing");
   RON_REQUIRE(c.wgt_bytes > 0 && c.wgt_bytes < (int64_t)1 << 32, "conv: weight allocation must be < 4 GiB");
-  RON_REQUIRE((int64_t)c.out.N * c.out.Hp() * c.out.Wp() * c.out.cstride < (int64_t)1 << 31, "conv: output too large for 32-bit offsets");
+  RON_REQUIRE(c.out.pixels() * c.out.cstride < (int64_t)1 << 31, "conv: output too large for 32-bit offsets");
   const int K = c.kh * c.kw * c.in.C;
   const int M = c.in.N * c.Ho * c.Wo;
-  const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg(M, c.Npad, K);
-  RON_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "conv: tile config %d out of range", cfg);
+  const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg_shape(M, c.Npad);
+  RON_REQUIRE(cfg >= 0 && cfg < kNumDiagCfgs, "conv: tile config %d out of range", cfg);
   const int BN = kCfgs[cfg].bn;
   const int kt_heur = K / chunk;                    // the split-K heuristic counts 128-byte K steps
   chunk = kCfgs[cfg].rb / esz;
@@ -786,13 +793,15 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   return launch_finalize<TraitsF32>(a, stream);
 }
 
-int64_t conv_scratch_bytes(int M, int Npad, int K, int dtype, int cfg, int splitk) {
-  if (cfg == kCfgPatch || cfg == kCfgPatch + 1) return 0;                       // the halo-patch kernel never splits K
-  const int KT = K / conv_k_chunk(dtype);
-  const int c = cfg >= 0 ? cfg : conv_pick_cfg(M, Npad, K);
-  const int tiles = ((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * (Npad / kCfgs[c].bn);
-  const int sk = splitk >= 0 ? splitk : conv_pick_splitk(tiles, KT, cfg_slots(c));
-  return sk > 1 ? (int64_t)sk * M * Npad * 4 : 0;
+int64_t conv_scratch_bytes(const ConvLaunch& l) {
+  const int cfg = l.cfg;
+  if (cfg == kCfgPatchDiag || cfg == kCfgPatchDiag + 1 || l.up > 0 || l.pool) return 0;   // the halo-patch kernel never splits K
+  const int M = l.in.N * l.Ho * l.Wo;
+  const int KT = l.kh * l.kw * l.in.C / conv_k_chunk(l.dtype);
+  const int c = cfg >= 0 ? cfg : conv_pick_cfg_shape(M, l.Npad);
+  const int tiles = ((M + kCfgs[c].bm - 1) / kCfgs[c].bm) * (l.Npad / kCfgs[c].bn);
+  const int sk = l.splitk >= 0 ? l.splitk : conv_pick_splitk(tiles, KT, cfg_slots(c));
+  return sk > 1 ? (int64_t)sk * M * l.Npad * 4 : 0;
 }
 
 }  // namespace ron

@@ -1,3 +1,6 @@
+// DIAGNOSTIC BUILD ONLY (libron_hip_diag.so): the round-1 halo-patch kernel (6 x 40 / 8 x 32 pixel tiles, row-major weights),
+// kept for A/B runs against csrc/conv_patch.hip.  tile_cfg 100 / 101 in the diagnostic library.
+//
 // 3x3 / stride-1 / pad-1 convolution with an LDS-staged input halo patch (gfx950).
 //
 // The generic kernel (conv_mfma.hip) re-stages the A operand for every filter tap, so the same input pixels travel
@@ -17,6 +20,8 @@
 
 namespace ron {
 namespace detail {
+
+constexpr int kCfgPatchDiag = 100;
 
 constexpr int kPatchPieces = 6;                  // LDS-DMA pieces per thread and chunk (512 threads x 16 B = 64 rows each)
 constexpr int kPatchRows = 344;                  // rows a patch buffer holds (43 KB): 8 x 42, 10 x 34, 14 x 22 patches fit
@@ -313,11 +318,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
 template <class Tr, int BN, int WN, int SB>
 int launch_patch_t(const PatchArgs& a, int grid, hipStream_t s) {
   const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  if (once.first()) {
     RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN, SB>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv3x3_patch_kernel<Tr, BN, WN, SB>), dim3(grid), dim3(512), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
@@ -348,7 +352,7 @@ bool conv_patch_applicable(const ConvLaunch& c) {
          c.in.pad >= 1 && c.Npad % 64 == 0 && pick_tile(c.in.H, c.in.W, c.pool != 0, &th, &tw);
 }
 
-int launch_conv_patch(const ConvLaunch& c, hipStream_t stream) {
+int launch_conv_patch(const ConvLaunch& c, int cfg_id, hipStream_t stream) {
   RON_REQUIRE(conv_patch_applicable(c), "patch kernel: not a 3x3 / stride 1 / pad 1 conv on a supported map");
   const int esz = (int)dtype_size(c.dtype), chunk = conv_k_chunk(c.dtype);
   RON_REQUIRE(c.in.C % chunk == 0, "conv: Cin %d is not a multiple of the K chunk %d", c.in.C, chunk);
@@ -375,7 +379,7 @@ int launch_conv_patch(const ConvLaunch& c, hipStream_t stream) {
 #define RON_PATCH_DISPATCH(Tr)                                                                   \
   do {                                                                                           \
     typedef typename SmallShape<Tr>::type TS;                                                    \
-    if (BN == 256 && c.cfg == kCfgPatch + 1) return launch_patch_t<Tr, 256, 2, 2>(a, grid, stream); \
+    if (BN == 256 && cfg_id == kCfgPatchDiag + 1) return launch_patch_t<Tr, 256, 2, 2>(a, grid, stream); \
     if (BN == 256) return launch_patch_t<TS, 256, 2, 2>(a, grid, stream);                        \
     if (BN == 128) return launch_patch_t<TS, 128, 2, 3>(a, grid, stream);                        \
     return launch_patch_t<TS, 64, 2, 3>(a, grid, stream);                                        \

@@ -247,7 +247,7 @@ struct Rows {
 
 int upload(ron_ctx* c, const Rows& r, int cout) {
   PackedConv p;
-  std::vector<uint8_t> bytes = cast_rows(r.w, c->cfg.dtype);
+  std::vector<uint8_t> bytes = pack_conv_weights(r.w, r.npad, c->cfg.dtype);
   p.w_bytes = (int64_t)bytes.size();
   p.Npad = r.npad; p.Cout = cout;
   RON_HIP_CHECK(hipMalloc(&p.d_w, bytes.size()));
@@ -477,7 +477,7 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
     if ((cfg->flags & RON_CFG_FUSE_POOLS) && (t.name == "conv1_2" || t.name == "conv2_2" || t.name == "conv3_3")) continue;
     if ((cfg->flags & RON_CFG_FUSE_POOLS) && !(cfg->flags & RON_CFG_NO_STEM2) && cfg->dtype != RON_DTYPE_F32 && H % 8 == 0 &&
         W % 32 == 0 && t.name == "conv1_1") continue;         // conv1_1 + conv1_2 + pool1 run fused (stem2_kernel)
-    t.bytes = (int64_t)cfg->max_batch * (t.H + 2 * t.pad) * (t.W + 2 * t.pad) * t.cstride * c->esz();
+    t.bytes = TensorView::halo_pixels(cfg->max_batch, t.H, t.W, t.pad) * t.cstride * c->esz();     // shared halos, conv_mfma.h
     if (t.bytes >= ((int64_t)1 << 32)) {
       ron::set_error("tensor %s needs %lld bytes for max_batch %d: above the 4 GiB buffer-addressing limit; lower max_batch",
                      t.name.c_str(), (long long)t.bytes, cfg->max_batch);
@@ -810,6 +810,39 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
   return RON_OK;
 }
 
+// The launch description of conv op `o` at batch n (heads == nullptr: geometry only, for sizing).
+static int describe_conv(const ron_ctx* c, const Op& o, int n, const ron_heads* heads, ConvLaunch* out_l) {
+  const PackedConv& p = c->packed[o.packed];
+  ConvLaunch L;
+  L.dtype = c->cfg.dtype;
+  L.in = c->view(o.in, n, o.in_coff, o.in_C > 0 ? o.in_C : -1);
+  if (o.out == -2) {
+    float* dst = nullptr;
+    if (heads != nullptr) {
+      const float* const* arr = o.head_kind == 0 ? heads->cls : (o.head_kind == 1 ? heads->obj : heads->loc);
+      dst = const_cast<float*>(arr[o.head_layer]);
+      RON_REQUIRE(dst != nullptr, "ron_forward: head buffer (kind %d, layer %d) is NULL", o.head_kind, o.head_layer);
+    }
+    TensorView v;
+    const int A = c->feat_A[o.head_layer];
+    v.base = dst; v.N = n; v.H = o.Ho; v.W = o.Wo; v.pad = 0; v.coff = 0;
+    v.C = o.head_kind == 0 ? A * c->cfg.num_classes : (o.head_kind == 1 ? 2 * A : 4 * A);
+    v.cstride = v.C;
+    v.bytes = (int64_t)n * v.H * v.W * v.C * 4;
+    L.out = v;
+    L.out_f32 = 1;
+  } else {
+    L.out = c->view(o.out, n, o.out_coff, o.out_C > 0 ? o.out_C : -1);
+  }
+  L.res = o.res >= 0 ? c->tensors[o.res].d : nullptr;
+  L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.bias = p.d_bias; L.Cout = p.Cout; L.Npad = p.Npad;
+  L.kh = o.kh; L.kw = o.kw; L.stride = o.stride; L.dil = o.dil; L.cpad = o.cpad; L.relu = o.relu;
+  L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo; L.pool = o.pool;
+  L.scratch = c->d_splitk[o.lane]; L.scratch_bytes = c->splitk_bytes[o.lane];
+  *out_l = L;
+  return RON_OK;
+}
+
 // Streams, events, split-K scratch and timing slots of one execution slot (after c->ops / c->packed are in place).
 static int slot_resources(ron_ctx* c) {
   if ((c->cfg.flags & RON_CFG_MULTI_STREAM) && !c->is_ssd()) {
@@ -822,10 +855,10 @@ static int slot_resources(ron_ctx* c) {
   // split-K scratch: the largest slab set any launch of a lane can ask for at max_batch
   for (const Op& o : c->ops) {
     if (o.kind != OP_CONV || o.up > 0) continue;
-    const PackedConv& pk = c->packed[o.packed];
-    const int cin = o.in_C > 0 ? o.in_C : c->tensors[o.in].C;
     for (int nb = 1; nb <= c->cfg.max_batch; ++nb) {
-      const int64_t b = conv_scratch_bytes(nb * o.Ho * o.Wo, pk.Npad, o.kh * o.kw * cin, c->cfg.dtype, -1, -1);
+      ConvLaunch L;
+      describe_conv(c, o, nb, nullptr, &L);
+      const int64_t b = conv_scratch_bytes(L);
       if (b > c->splitk_bytes[o.lane]) c->splitk_bytes[o.lane] = b;
     }
   }
@@ -879,6 +912,9 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
   RON_REQUIRE(c && d_images && out, "NULL argument");
   if (!c->finalized) { ron::set_error("ron_forward before ron_finalize_weights"); return RON_ERR_STATE; }
   RON_REQUIRE(n >= 1 && n <= c->cfg.max_batch, "batch %d outside [1, max_batch=%d]", n, c->cfg.max_batch);
+  // launches go to the context's device whatever the caller's current device is (the stream must belong to it)
+  DeviceGuard on_device(c->cfg.device);
+  RON_HIP_CHECK(on_device.err);
   int rc = ron_heads_describe(c, out);
   if (rc) return rc;
   std::vector<hipEvent_t>* ev = nullptr;
@@ -929,30 +965,8 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
     } else if (o.kind == OP_L2NORM) {
       if ((rc = launch_l2norm(c->view(o.in, n), c->view(o.out, n), c->d_l2_gamma, c->cfg.dtype, s))) return rc;
     } else {
-      const PackedConv& p = c->packed[o.packed];
       ConvLaunch L;
-      L.dtype = c->cfg.dtype;
-      L.in = c->view(o.in, n, o.in_coff, o.in_C > 0 ? o.in_C : -1);
-      if (o.out == -2) {
-        const float* const* arr = o.head_kind == 0 ? out->cls : (o.head_kind == 1 ? out->obj : out->loc);
-        float* dst = const_cast<float*>(arr[o.head_layer]);
-        RON_REQUIRE(dst != nullptr, "ron_forward: head buffer (kind %d, layer %d) is NULL", o.head_kind, o.head_layer);
-        TensorView v;
-        const int A = c->feat_A[o.head_layer];
-        v.base = dst; v.N = n; v.H = o.Ho; v.W = o.Wo; v.pad = 0; v.coff = 0;
-        v.C = o.head_kind == 0 ? A * c->cfg.num_classes : (o.head_kind == 1 ? 2 * A : 4 * A);
-        v.cstride = v.C;
-        v.bytes = (int64_t)n * v.H * v.W * v.C * 4;
-        L.out = v;
-        L.out_f32 = 1;
-      } else {
-        L.out = c->view(o.out, n, o.out_coff, o.out_C > 0 ? o.out_C : -1);
-      }
-      L.res = o.res >= 0 ? c->tensors[o.res].d : nullptr;
-      L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.bias = p.d_bias; L.Cout = p.Cout; L.Npad = p.Npad;
-      L.kh = o.kh; L.kw = o.kw; L.stride = o.stride; L.dil = o.dil; L.cpad = o.cpad; L.relu = o.relu;
-      L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo; L.pool = o.pool;
-      L.scratch = c->d_splitk[o.lane]; L.scratch_bytes = c->splitk_bytes[o.lane];
+      if ((rc = describe_conv(c, o, n, out, &L))) return rc;
       if ((rc = launch_conv(L, s))) {
         std::string msg = ron_last_error();
         ron::set_error("%s: %s", o.name.c_str(), msg.c_str());
@@ -1069,8 +1083,9 @@ extern "C" int ron_detect(ron_ctx* c, const float* d_images, int n, const ron_po
   const int mb = c->cfg.max_batch;
   ron_heads hd;
   memset(&hd, 0, sizeof(hd));
+  DeviceGuard on_device(c->cfg.device);
+  RON_HIP_CHECK(on_device.err);
   if (c->d_head[0][0] == nullptr) {          // first call: allocate ctx-owned head buffers + scratch
-    RON_HIP_CHECK(hipSetDevice(c->cfg.device));
     for (int i = 0; i < c->n_feat; ++i) {
       const int A = c->feat_A[i];
       const size_t cells = (size_t)mb * c->feat_h[i] * c->feat_w[i];

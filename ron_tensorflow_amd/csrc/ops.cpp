@@ -23,7 +23,7 @@ struct DevBuf {
 ron::TensorView make_view(void* base, int n, int h, int w, int c, int pad, int esz) {
   ron::TensorView v;
   v.base = base; v.N = n; v.H = h; v.W = w; v.C = c; v.pad = pad; v.cstride = c; v.coff = 0;
-  v.bytes = (int64_t)n * (h + 2 * pad) * (w + 2 * pad) * c * esz;
+  v.bytes = ron::TensorView::halo_pixels(n, h, w, pad) * c * esz;
   return v;
 }
 
@@ -85,7 +85,7 @@ int setup_conv(const ron_conv_desc* d, const float* w, const float* bias, bool w
   }
   c.Cout = cout_gemm;
   c.relu = d->relu;
-  std::vector<uint8_t> wbytes = cast_rows(rows, d->dtype);
+  std::vector<uint8_t> wbytes = pack_conv_weights(rows, c.Npad, d->dtype);
   int rc;
   if ((rc = S->d_w.alloc((int64_t)wbytes.size(), false))) return rc;
   if ((rc = S->d_b.alloc((int64_t)bias_pad.size() * 4, false))) return rc;
@@ -112,8 +112,8 @@ int setup_conv(const ron_conv_desc* d, const float* w, const float* bias, bool w
     c.res = S->d_res.p;
   }
   c.splitk = d->splitk;
-  const int64_t sb = conv_scratch_bytes(d->n * c.Ho * c.Wo, c.Npad, c.kh * c.kw * c.in.C, d->dtype, c.cfg, c.splitk);
-  if (sb > 0 && c.up == 0) {
+  const int64_t sb = conv_scratch_bytes(c);
+  if (sb > 0) {
     if ((rc = S->d_scratch.alloc(sb, false))) return rc;
     c.scratch = S->d_scratch.p;
     c.scratch_bytes = sb;
@@ -190,30 +190,6 @@ extern "C" int ron_conv2d_bench(const ron_conv_desc* d, int warmup, int iters, f
   float ms = 0.f;
   RON_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   *ms_per_launch = ms / iters;
-  if ((d->tile_cfg >= 27 && d->tile_cfg <= 29) || d->tile_cfg == 44) {
-    // stamp build: one more launch with a debug buffer, shares of the K step to stderr
-    const size_t waves = (size_t)1 << 20;
-    unsigned long long* dbg = nullptr;
-    RON_HIP_CHECK(hipMalloc((void**)&dbg, waves * 4 * sizeof(unsigned long long)));
-    RON_HIP_CHECK(hipMemset(dbg, 0, waves * 4 * sizeof(unsigned long long)));
-    S.c.dbg = dbg;
-    if ((rc = launch_conv(S.c, nullptr))) return rc;
-    RON_HIP_CHECK(hipDeviceSynchronize());
-    std::vector<unsigned long long> h(waves * 4);
-    RON_HIP_CHECK(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sw = 0, sb = 0, sc = 0, steps = 0;
-    size_t n = 0;
-    for (size_t i = 0; i < waves; ++i) {
-      if (h[4 * i + 3] == 0) continue;
-      sw += (double)h[4 * i]; sb += (double)h[4 * i + 1]; sc += (double)h[4 * i + 2]; steps += (double)h[4 * i + 3];
-      ++n;
-    }
-    if (steps > 0)
-      fprintf(stderr, "[stamps cfg %d] waves %zu, per K step (s_memtime ticks, 100 MHz): wait %.1f  barrier %.1f  rest %.1f\n",
-              d->tile_cfg, n, sw / steps, sb / steps, sc / steps);
-    S.c.dbg = nullptr;
-    (void)hipFree(dbg);
-  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return RON_OK;

@@ -37,6 +37,29 @@ static inline std::vector<uint8_t> cast_rows(const std::vector<float>& rows, int
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
+// Row-major [npad][K] bytes -> 64-row x 128-byte blocks [npad / 64][K steps][64][128 B] (npad % 64 == 0, K * esz % 128 == 0):
+// the (64 rows, one K step) unit both conv kernels stage is 8 KB of consecutive memory, so a wave's LDS-DMA instruction
+// (8 rows x 128 B) reads one contiguous kilobyte instead of eight lines that are K * esz bytes apart.
+static inline std::vector<uint8_t> block_rows(const std::vector<uint8_t>& rows, int npad, int64_t row_bytes) {
+  const int64_t steps = row_bytes / 128;
+  std::vector<uint8_t> out(rows.size());
+  for (int n = 0; n < npad; ++n)
+    for (int64_t kt = 0; kt < steps; ++kt)
+      memcpy(&out[(((int64_t)(n / 64) * steps + kt) * 64 + n % 64) * 128], &rows[(int64_t)n * row_bytes + kt * 128], 128);
+  return out;
+}
+
+// fp32 rows [npad][K] -> what the conv kernels read: rounded to the dtype, blocked
+static inline std::vector<uint8_t> pack_conv_weights(const std::vector<float>& rows, int npad, int dtype) {
+#ifdef RON_DIAG      // libron_hip_diag.so: the round-1 kernels of csrc/diag read row-major weights
+  (void)npad;
+  return cast_rows(rows, dtype);
+#else
+  const int64_t K = (int64_t)(rows.size() / (size_t)npad);
+  return block_rows(cast_rows(rows, dtype), npad, K * (int64_t)dtype_size(dtype));
+#endif
+}
+
 // HWIO [kh,kw,cin,cout] -> rows[n][(ky*kw+kx)*cin + c], n < npad (extra rows zero)
 static inline void hwio_to_rows(const float* w, int kh, int kw, int cin, int cout, int npad, std::vector<float>* rows) {
   const int K = kh * kw * cin;

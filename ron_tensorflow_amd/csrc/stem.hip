@@ -398,12 +398,11 @@ int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w
   const int tiles = n * (h / kS2TH) * (w / kS2TW);
   const int grid = std::min(tiles, 256);
   static const int abl = getenv("RON_STEM2_ABL") ? atoi(getenv("RON_STEM2_ABL")) : 0;
-  static bool attr_set[2] = {false, false};
+  static PerDeviceOnce attr_set[2];                // the attribute is per device (common.h)
   const int which = dtype == RON_DTYPE_BF16 ? 0 : 1;
-  if (!attr_set[which]) {
+  if (attr_set[which].first()) {
     if (which == 0) RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem2_kernel<StemBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kS2Lds));
     else RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem2_kernel<StemF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kS2Lds));
-    attr_set[which] = true;
   }
   if (which == 0)
     hipLaunchKernelGGL(stem2_kernel<StemBF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,

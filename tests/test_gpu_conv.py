@@ -118,12 +118,17 @@ def test_maxpool(ops, dev, dtype):
     assert np.array_equal(got, orf.max_pool2x2_np(x))
 
 
+IGEMM_CFGS = [0, 1, 2, 3]           # conv_mfma.h: 256x256, 128x128, 128x128 early-issue, 128x64
+PATCH_CFGS = {256: 4, 128: 5, 64: 6}  # halo-patch kernel by N tile
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 20, 21, 22, 23, 24, 26, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 51, 52, 53, 56, 57, 58, 59, 60, 61, 62])
+@pytest.mark.parametrize('cfg', IGEMM_CFGS)
 def test_every_tile_configuration(ops, dev, cfg, dtype):
-    """Each (tile, wave grid, stage count) variant of the kernel on a ragged multi-tile problem, K = 18 steps."""
+    """Each tile configuration of the row-gather kernel on a ragged multi-tile problem, K = 18 steps.  The shipped library
+    holds exactly the configurations conv_pick_cfg() can select (the ablation builds live in libron_hip_diag.so)."""
     from ron_tensorflow_amd import _lib
-    assert _lib.lib().ron_conv_num_tile_cfgs() == 64
+    assert _lib.lib().ron_conv_num_tile_cfgs() == 7
     rs = np.random.RandomState(40 + cfg)
     x = rs.randn(3, 13, 11, 128).astype(np.float32)            # M = 429: two 256-row or four 128-row tiles, ragged
     wt = (rs.randn(3, 3, 128, 192) * 0.03).astype(np.float32)  # Cout 192 -> padded to 256
@@ -139,6 +144,21 @@ def test_every_tile_configuration(ops, dev, cfg, dtype):
         ref2 = orf.conv2d_np(rnd(x2), rnd(w2))
         got2 = ops.conv2d_nhwc(torch.from_numpy(x2).to(dev), w2, None, relu=False, dtype=dtype, tile_cfg=cfg).cpu().numpy()
         _check(got2, ref2, dtype)
+
+
+def test_no_entry_accepts_a_configuration_it_cannot_run(ops, dev):
+    """ron_conv2d_nhwc rejects tile configurations outside the selectable set, and the patch kernel on a conv it does not
+    cover, instead of producing something."""
+    from ron_tensorflow_amd._lib import RonError
+    x = torch.zeros((1, 10, 10, 64), device=dev)
+    w3 = np.zeros((3, 3, 64, 64), np.float32)
+    for cfg in (7, 30, 100):
+        with pytest.raises(RonError):
+            ops.conv2d_nhwc(x, w3, None, dtype='bf16', tile_cfg=cfg)
+    with pytest.raises(RonError):                                        # 1x1 conv through the 3x3 patch kernel
+        ops.conv2d_nhwc(x, np.zeros((1, 1, 64, 64), np.float32), None, dtype='bf16', tile_cfg=6)
+    with pytest.raises(RonError):                                        # N tile 256 on 64 output channels
+        ops.conv2d_nhwc(x, w3, None, dtype='bf16', tile_cfg=4)
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
@@ -163,11 +183,11 @@ def test_split_k(ops, dev, dtype, splitk):
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-@pytest.mark.parametrize('cfg', [-1, 0, 5, 6, 11])
+@pytest.mark.parametrize('cfg', [-1, 0, 1, 3])
 def test_conv_with_fused_maxpool(ops, dev, dtype, cfg):
     """conv3x3 + bias + ReLU + 2x2/2 max-pool in one kernel == pool(conv) (nets/ron_vgg_320.py:454-466)."""
     rs = np.random.RandomState(70)
-    cout = 64 if cfg == 5 else 256
+    cout = 64 if cfg == 3 else 256
     x = rs.randn(3, 12, 20, 64).astype(np.float32)
     wt = (rs.randn(3, 3, 64, cout) * 0.05).astype(np.float32)
     b = (rs.randn(cout) * 0.1).astype(np.float32)
@@ -182,18 +202,26 @@ def test_conv_with_fused_maxpool(ops, dev, dtype, cfg):
 
 
 PATCH_SHAPES = [  # n, h, w, cin, cout
-    (2, 40, 40, 64, 128),     # six full 40-wide rows per tile, ragged last tile row
-    (1, 12, 64, 128, 64),     # 4 x 64 strips, N tile 64
-    (2, 16, 96, 64, 256),     # 8 x 32 tiles
-    (1, 80, 80, 64, 210),     # 40-wide half rows, Cout 210 -> masked tail
-    (3, 44, 40, 192, 20),     # Cout 20
+    (2, 40, 40, 64, 128),     # flat runs of 256 positions (41 per row with the shared halo), crossing rows and the two images
+    (1, 20, 20, 128, 256),    # flat, N tile 256, two chunks
+    (3, 10, 10, 64, 64),      # flat, three images inside one and a half runs
+    (2, 5, 5, 128, 128),      # flat, everything in one run
+    (3, 44, 40, 192, 20),     # flat, Cout 20 -> N tile 64, masked tail, three chunks
+    (2, 16, 96, 64, 256),     # 16 x 16 pixel tiles
+    (1, 80, 80, 64, 210),     # 16 x 16 tiles, Cout 210 -> masked tail
+    (1, 8, 96, 128, 64),      # 8 x 32 tiles (H not a multiple of 16)
 ]
+
+
+def _patch_cfg(cout):
+    npad = -(-cout // 64) * 64 if cout <= 64 else -(-cout // 128) * 128
+    return PATCH_CFGS[256 if npad % 256 == 0 else (128 if npad % 128 == 0 else 64)]
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('shape', PATCH_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
 def test_patch_kernel_conv3x3(ops, dev, shape, dtype):
-    """The halo-patch 3x3 kernel (csrc/conv_patch.hip, tile_cfg = 100) vs the oracle conv."""
+    """The halo-patch 3x3 kernel (csrc/conv_patch.hip), flat and pixel-tile modes, vs the oracle conv."""
     n, h, w, cin, cout = shape
     rs = np.random.RandomState(sum(shape))
     x = rs.randn(n, h, w, cin).astype(np.float32)
@@ -201,12 +229,16 @@ def test_patch_kernel_conv3x3(ops, dev, shape, dtype):
     b = (rs.randn(cout) * 0.1).astype(np.float32)
     rnd = ROUND[dtype]
     ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0)
-    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=100).cpu().numpy()
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=_patch_cfg(cout)).cpu().numpy()
     _check(got, ref, dtype)
+    # the row-gather kernel on the same problem (its K loop runs tap-major, this one chunk-major: same sum, other order)
+    same = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=3 if cout <= 64 else 1, splitk=1)
+    if dtype != 'fp32':
+        _check(got, same.cpu().numpy(), dtype)
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-def test_patch_kernel_residual_and_pool(ops, dev, dtype):
+def test_patch_kernel_channel_slice_residual_and_pool(ops, dev, dtype):
     rs = np.random.RandomState(91)
     rnd = ROUND[dtype]
     x = rs.randn(2, 40, 40, 128).astype(np.float32)
@@ -215,12 +247,16 @@ def test_patch_kernel_residual_and_pool(ops, dev, dtype):
     res = np.maximum(rs.randn(2, 40, 40, 128), 0).astype(np.float32)
     ref = np.maximum(np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0) + rnd(res), 0)
     got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, residual=torch.from_numpy(res).to(dev), relu=True, dtype=dtype,
-                          tile_cfg=100).cpu().numpy()
+                          tile_cfg=5).cpu().numpy()
     _check(got, ref, dtype)
-    for (h, w) in ((40, 40), (16, 64), (24, 96)):
+    # input = channels [64, 192) of a 320-channel tensor (the heads read slices of the per-scale concatenated tensor)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, residual=torch.from_numpy(res).to(dev), relu=True, dtype=dtype,
+                          tile_cfg=5, in_cstride=320, in_coff=64).cpu().numpy()
+    _check(got, ref, dtype)
+    for (h, w) in ((16, 64), (32, 32), (8, 96)):
         x = rs.randn(2, h, w, 64).astype(np.float32)
         wt = (rs.randn(3, 3, 64, 128) * 0.05).astype(np.float32)
         ref = orf.max_pool2x2_np(np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0))
-        got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=100, pool=True).cpu().numpy()
+        got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=5, pool=True).cpu().numpy()
         assert got.shape == ref.shape
         _check(got, ref, dtype)

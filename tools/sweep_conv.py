@@ -2,11 +2,18 @@
 """Sweep the conv kernel's tile configurations over the RON-320 layer shapes (batch 32) on the GPU.
 
   python tools/sweep_conv.py [--dtype bf16] [--batch 32] [--cfgs 0,2,4] [--only name-substring]
-Prints ms and TFLOP/s per (layer, cfg); used to choose conv_pick_cfg() (csrc/conv_mfma.hip)."""
+Prints us and TFLOP/s per (layer, cfg); used to choose conv_pick_cfg() / conv_patch_pick() (csrc/conv_mfma.hip, conv_patch.hip).
+Configurations: csrc/conv_mfma.h kCfg* (0-3 row-gather tiles, 4-6 halo-patch N tiles); n/a = does not cover that layer."""
 import argparse
 import ctypes as C
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# --exp / --diag: the experimental (make EXP=1) or the round-1 diagnostic (make DIAG=1) build of the library
+for flag, so in (('--exp', 'libron_hip_exp.so'), ('--diag', 'libron_hip_diag.so')):
+    if flag in sys.argv:
+        sys.argv.remove(flag)
+        os.environ['RON_HIP_LIB'] = os.path.join(ROOT, 'ron_tensorflow_amd', so)
 from ron_tensorflow_amd import _lib
 
 # name, h, w, cin, cout, k, stride, rate, transpose
@@ -16,6 +23,7 @@ LAYERS = [
     ('conv2_2', 160, 160, 128, 128, 3, 1, 1, 0),
     ('conv3_1', 80, 80, 128, 256, 3, 1, 1, 0),
     ('conv3_2', 80, 80, 256, 256, 3, 1, 1, 0),
+    ('conv4_3', 40, 40, 512, 512, 3, 1, 1, 0),
     ('conv4_1', 40, 40, 256, 512, 3, 1, 1, 0),
     ('conv4_2', 40, 40, 512, 512, 3, 1, 1, 0),
     ('conv5_1', 20, 20, 512, 512, 3, 1, 1, 0),
@@ -24,24 +32,27 @@ LAYERS = [
     ('fc6_red', 10, 10, 512, 1024, 3, 1, 3, 0),
     ('b7_left_full', 10, 10, 4096, 512, 2, 2, 1, 0),
     ('b6_left_full', 10, 10, 4096, 512, 3, 1, 1, 0),
-    ('b7_trio', 5, 5, 512, 2048, 3, 1, 1, 0),
+    ('b7_trio', 5, 5, 512, 1536, 3, 1, 1, 0),
     ('b7_inc2', 5, 5, 1024, 1024, 3, 1, 1, 0),
     ('b7_cls', 5, 5, 1024, 210, 3, 1, 1, 0),
     ('b7_loc', 5, 5, 512, 40, 3, 1, 1, 0),
-    ('b6_trio', 10, 10, 512, 2048, 3, 1, 1, 0),
+    ('b6_trio', 10, 10, 512, 1536, 3, 1, 1, 0),
     ('b6_inc2', 10, 10, 1024, 1024, 3, 1, 1, 0),
     ('b6_cls', 10, 10, 1024, 210, 3, 1, 1, 0),
     ('b6_obj', 10, 10, 512, 20, 3, 1, 1, 0),
     ('b5_deconv', 10, 10, 512, 512, 2, 2, 1, 1),
-    ('b5_trio', 20, 20, 512, 2048, 3, 1, 1, 0),
+    ('b5_trio', 20, 20, 512, 1536, 3, 1, 1, 0),
     ('b5_inc2', 20, 20, 1024, 1024, 3, 1, 1, 0),
     ('b5_cls', 20, 20, 1024, 210, 3, 1, 1, 0),
     ('b5_loc', 20, 20, 512, 40, 3, 1, 1, 0),
     ('b4_deconv', 20, 20, 512, 512, 2, 2, 1, 1),
-    ('b4_trio', 40, 40, 512, 2048, 3, 1, 1, 0),
+    ('b4_trio', 40, 40, 512, 1536, 3, 1, 1, 0),
     ('b4_inc2', 40, 40, 1024, 1024, 3, 1, 1, 0),
     ('b4_cls', 40, 40, 1024, 210, 3, 1, 1, 0),
     ('b4_loc', 40, 40, 512, 40, 3, 1, 1, 0),
+    ('b4_obj', 40, 40, 512, 20, 3, 1, 1, 0),
+    ('b4_left', 40, 40, 512, 512, 3, 1, 1, 0),
+    ('b5_left', 20, 20, 512, 512, 3, 1, 1, 0),
 ]
 
 
@@ -50,7 +61,7 @@ def main():
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--cfgs', default='')
-    ap.add_argument('--only', default='')
+    ap.add_argument('--only', default='', help='comma-separated layer names (exact) or one substring')
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--cstride', type=int, default=0)
     ap.add_argument('--coff', type=int, default=0)
@@ -58,10 +69,10 @@ def main():
     a = ap.parse_args()
     lib = _lib.lib()
     ncfg = lib.ron_conv_num_tile_cfgs()
-    cfgs = [int(c) for c in a.cfgs.split(',')] if a.cfgs else list(range(ncfg))     # 100 = halo-patch 3x3 kernel, -1 = auto
+    cfgs = [int(c) for c in a.cfgs.split(',')] if a.cfgs else [-1] + list(range(ncfg))     # -1 = conv_pick_cfg's choice
     print('%-14s %8s %9s | ' % ('layer', 'GFLOP', 'M') + ' '.join('cfg%-2d us/TF   ' % c for c in cfgs))
     for (name, h, w, cin, cout, k, stride, rate, tr) in LAYERS:
-        if a.only and a.only not in name:
+        if a.only and not (name in a.only.split(',') or (',' not in a.only and a.only in name)):
             continue
         ho, wo = (h, w) if (tr or stride == 1) else (h // stride, w // stride)
         flop = 2.0 * a.batch * (h * w if tr else ho * wo) * k * k * cin * cout
