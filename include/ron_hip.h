@@ -276,6 +276,10 @@ typedef struct {
 /* With RON_CFG_FUSE_POOLS (bf16 / f16) conv1_1 + conv1_2 + pool1 run as ONE kernel that goes from the fp32 image to pool1
  * (neither 64-channel full-resolution map touches HBM).  This flag keeps them as separate launches (A/B tests). */
 #define RON_CFG_NO_STEM2 4u
+/* The small, mutually independent head convolutions of the coarse scales (block7 / block6 and the 1x1 / skinny ones of
+ * block5) run as grouped launches, several convolutions per launch (33 head launches -> 18); this flag keeps one launch
+ * per convolution (same results up to the order of the fp32 partial sums: the split of K differs; tests compare the two). */
+#define RON_CFG_NO_GROUPS 8u
 
 int ron_create(ron_ctx** out, const ron_config* cfg);
 int ron_destroy(ron_ctx* ctx);

@@ -19,6 +19,7 @@ RON_IN_LOC_DECODED = 4
 RON_CFG_FUSE_POOLS = 1
 RON_CFG_MULTI_STREAM = 2
 RON_CFG_NO_STEM2 = 4
+RON_CFG_NO_GROUPS = 8
 
 DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp16': 2, 'f16': 2, 'float16': 2}
 VARIANTS = {'reducedfc': 0, 'full': 1, 'ssd512': 2}

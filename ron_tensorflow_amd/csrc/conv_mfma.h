@@ -95,6 +95,10 @@ int conv_num_cfgs();
 int conv_pick_cfg(const ConvLaunch& c);
 int conv_pick_splitk(int tiles, int KT, int slots);
 int64_t conv_scratch_bytes(const ConvLaunch& c);   // fp32 split-K slabs this launch can ask for (0: none)
+// Several mutually independent convolutions as ONE launch of the row-gather kernel (tile kCfgIgemm128x64 or kCfgIgemm128)
+int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64_t scratch_bytes, hipStream_t stream);
+int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg);
+constexpr int kMaxConvGroup = 8;
 size_t dtype_size(int dtype);
 
 // conv1_1 (stem.hip): 3 -> 64 channels straight from the fp32 image, bf16 / f16 only

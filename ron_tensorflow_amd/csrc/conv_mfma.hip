@@ -31,8 +31,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // SPREAD 1: the LDS-DMA pieces of a tile are shared out over the k-steps of the stage; 2: all go out during k-step 0.
 // EXP (experimental builds only, make EXP=1): 1 = the A descriptor has no records (only the weights move), 2 = the B
 // descriptor has none, 3 = neither moves.  Timing-only, results are wrong; 0 in everything the shipped library holds.
+// One tile of launch `p`: workgroup `bid` of the `nwg` that launch consists of (a launch of its own, or a range of the
+// workgroups of a grouped launch).
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0>
-__global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * kRowBytes > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
+__device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigned bid, const unsigned nwg, char* smem) {
   constexpr int kLanesPerRow = kRowBytes / 16;       // 16-byte chunks per row
   constexpr int MT = Tr::kMT;                        // MFMA output tile (16)
   constexpr int kGroups = 64 / MT;                   // 16-byte K groups one instruction consumes per row
@@ -51,7 +53,6 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * kRowBytes > 80 * 102
   static_assert(TM % 32 == 0 && TN % 32 == 0 && S >= 2 && S <= 5, "bad wave tile / stage count");
   static_assert(NR <= 8, "vector epilogue: at most 8 channels per lane");
   static_assert(SPREAD == 1 || SPREAD == 2, "SPREAD");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   // layout: [stage 0 .. S-1: A | B][in_off: BM ints][out_off: BM ints]
   int* s_in_off = reinterpret_cast<int*>(smem + S * kStage);
   int* s_out_off = s_in_off + BM;
@@ -63,8 +64,6 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * kRowBytes > 80 * 102
 
   // XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) take consecutive tiles,
   // so the N-tiles that re-read one A tile hit the same L2.
-  const unsigned nwg = gridDim.x;
-  const unsigned bid = blockIdx.x;
   const unsigned xcd = bid & 7u, q = nwg >> 3, r8 = nwg & 7u;
   const unsigned wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
   const int zsplit = (int)(wgid / (unsigned)p.tiles_total);
@@ -276,9 +275,51 @@ __global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * kRowBytes > 80 * 102
   conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n_base + nloc, tap_off);
 }
 
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0>
+__global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * kRowBytes > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD, EXP>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Several independent small convolutions in ONE launch (the per-scale head layers of the coarse scales, each of which
+// alone leaves most of the chip idle): workgroups [first[k], first[k+1]) run conv k exactly as its own launch would.
+// The descriptions travel in the kernel-argument segment; a workgroup copies its own with scalar loads.
+constexpr int kMaxGroup = kMaxConvGroup;
+struct ConvGroupArgs {
+  ConvArgs op[kMaxGroup];
+  int first[kMaxGroup + 1];
+  int n;
+};
+// op[k] of the ConvGroupArgs this kernel was launched with (its only argument), read from the kernel-argument segment
+__device__ __forceinline__ ConvArgs load_group_op(int k) {
+  static_assert(sizeof(ConvArgs) % 4 == 0, "dword copy");
+  typedef __attribute__((address_space(4))) const unsigned* KernargWords;
+  const KernargWords src = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr() + k * (int)(sizeof(ConvArgs) / 4);
+  ConvArgs p;
+  unsigned* dst = reinterpret_cast<unsigned*>(&p);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(ConvArgs) / 4); ++i) dst[i] = src[i];
+  return p;
+}
+
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_group_kernel(ConvGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < kMaxGroup; ++j)
+    if (j < g.n && b >= g.first[j]) k = j;
+  const ConvArgs p = load_group_op(k);
+  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD, 0>(p, (unsigned)(b - g.first[k]), (unsigned)(g.first[k + 1] - g.first[k]), smem);
+}
+
+template <class Tr>
+__global__ void splitk_finalize_group_kernel(ConvGroupArgs g);
+
 // Adds the split-K slabs and applies the conv epilogue (bias, ReLU, relu(x + residual), dtype / fp32 store).
 template <class Tr>
-__global__ void splitk_finalize_kernel(ConvArgs p) {
+__device__ __forceinline__ void splitk_finalize_body(const ConvArgs& p) {
   const int groups = p.Npad / 4;
   const long long total = (long long)p.M * groups;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -304,6 +345,16 @@ __global__ void splitk_finalize_kernel(ConvArgs p) {
       else Tr::store(p.out, o + j, v);
     }
   }
+}
+
+template <class Tr>
+__global__ void splitk_finalize_kernel(ConvArgs p) { splitk_finalize_body<Tr>(p); }
+
+// blockIdx.y = conv of the group; the ones that did not split K have nothing to add
+template <class Tr>
+__global__ void splitk_finalize_group_kernel(ConvGroupArgs g) {
+  const ConvArgs p = load_group_op((int)blockIdx.y);
+  if (p.splitk > 1) splitk_finalize_body<Tr>(p);
 }
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0>
@@ -433,6 +484,107 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   if (c.dtype == RON_DTYPE_BF16) return launch_finalize<TraitsBF16S>(a, stream);
   if (c.dtype == RON_DTYPE_F16) return launch_finalize<TraitsF16S>(a, stream);
   return launch_finalize<TraitsF32S>(a, stream);
+}
+
+// ---- grouped launches ---------------------------------------------------------------------------------------------
+namespace detail {
+
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
+int launch_group_t(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
+  const size_t lds = (size_t)S * (BM + BN) * kRowBytes + 2 * BM * sizeof(int);
+  static PerDeviceOnce once;
+  if (once.first())
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(g.first[g.n]), dim3(WM * WN * 64), lds, s, g);
+  if (any_split) {
+    long long most = 0;
+    for (int k = 0; k < g.n; ++k)
+      if (g.op[k].splitk > 1) most = std::max(most, (long long)g.op[k].M * (g.op[k].Npad / 4));
+    const int grid = (int)std::min<long long>((most + 255) / 256, 512);
+    hipLaunchKernelGGL(splitk_finalize_group_kernel<Tr>, dim3(grid, g.n), dim3(256), 0, s, g);
+  }
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+template <class Tr>
+int launch_group_cfg(int cfg, const ConvGroupArgs& g, bool any_split, hipStream_t s) {
+  if (cfg == kCfgIgemm128x64) return launch_group_t<Tr, 128, 64, 2, 2, 2, 2>(g, any_split, s);
+  if (cfg == kCfgIgemm128) return launch_group_t<Tr, 128, 128, 2, 2, 2, 1>(g, any_split, s);
+  ron::set_error("conv group: tile config %d has no grouped form", cfg);
+  return RON_ERR_INVALID;
+}
+
+// Split-K inside a group: the group as a whole fills the chip, so K is split only to bound the serial chain of K steps
+// of one workgroup (the latency of the launch; <= ~24 steps each, >= 8) and only for convolutions with few tiles: the
+// fp32 slabs of a many-tile convolution cost more HBM traffic than the shorter chain saves.
+int group_pick_splitk(int KT, int tiles) {
+  if (KT < 16 || tiles < 1) return 1;
+  int sk = (KT + 23) / 24;
+  if (sk > 512 / tiles) sk = 512 / tiles;
+  if (sk > KT / 8) sk = KT / 8;
+  return sk < 1 ? 1 : sk;
+}
+
+}  // namespace detail
+
+static int64_t group_slab_bytes(const ConvLaunch& c, int cfg) {
+  if (c.up > 0 || c.pool) return 0;
+  const int M = c.in.N * c.Ho * c.Wo;
+  const int KT = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
+  const int tiles = ((M + igemm_bm(cfg) - 1) / igemm_bm(cfg)) * (c.Npad / igemm_bn(cfg));
+  const int sk = c.splitk >= 0 ? c.splitk : group_pick_splitk(KT, tiles);
+  return sk > 1 ? ron::align_up((int64_t)sk * M * c.Npad * 4, 256) : 0;
+}
+
+int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg) {
+  int64_t total = 0;
+  for (int k = 0; k < n; ++k) total += group_slab_bytes(ls[k], cfg);
+  return total;
+}
+
+// `n` mutually independent convolutions as one launch of tile configuration `cfg` (kCfgIgemm128x64 or kCfgIgemm128);
+// `scratch`: conv_group_scratch_bytes() for the split-K slabs (each conv gets its own part).
+int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
+  RON_REQUIRE(n >= 1 && n <= kMaxGroup, "conv group: %d launches (1..%d)", n, kMaxGroup);
+  RON_REQUIRE(cfg == kCfgIgemm128x64 || cfg == kCfgIgemm128, "conv group: tile config %d has no grouped form", cfg);
+  const int BM = igemm_bm(cfg), BN = igemm_bn(cfg);
+  ConvGroupArgs g = ConvGroupArgs();
+  g.n = n;
+  int64_t used = 0;
+  bool any_split = false;
+  for (int k = 0; k < n; ++k) {
+    const ConvLaunch& c = ls[k];
+    const int esz = (int)dtype_size(c.dtype), chunk = conv_k_chunk(c.dtype);
+    RON_REQUIRE(c.dtype == ls[0].dtype, "conv group: mixed dtypes");
+    RON_REQUIRE(c.in.C % chunk == 0 && c.in.pad >= c.cpad, "conv group: bad input (Cin %d, halo %d < %d)", c.in.C, c.in.pad, c.cpad);
+    RON_REQUIRE(c.in.bytes > 0 && c.in.bytes < (int64_t)1 << 32 && c.wgt_bytes > 0 && c.wgt_bytes < (int64_t)1 << 32,
+                "conv group: allocations must be < 4 GiB");
+    RON_REQUIRE(c.out.pixels() * c.out.cstride < (int64_t)1 << 31, "conv group: output too large for 32-bit offsets");
+    RON_REQUIRE(c.Npad % BN == 0 && !c.pool, "conv group: Npad %d not a multiple of the N tile %d, or a fused pool", c.Npad, BN);
+    if (c.up > 0) RON_REQUIRE(c.up_cout % BN == 0, "transposed conv: channels per tap %d not a multiple of %d", c.up_cout, BN);
+    ConvArgs& a = g.op[k];
+    fill_conv_args(c, &a);
+    RON_REQUIRE((int64_t)c.Npad * a.K * esz == c.wgt_bytes, "conv group: packed weight size mismatch");
+    a.tiles_n = c.Npad / BN;
+    a.tiles_total = ((a.M + BM - 1) / BM) * a.tiles_n;
+    const int64_t need = group_slab_bytes(c, cfg);
+    if (need > 0 && scratch != nullptr && used + need <= scratch_bytes) {
+      const int sk = c.splitk >= 0 ? c.splitk : group_pick_splitk(a.KT, a.tiles_total);
+      a.kt_split = (a.KT + sk - 1) / sk;
+      a.splitk = (a.KT + a.kt_split - 1) / a.kt_split;
+      a.partial = reinterpret_cast<float*>(static_cast<char*>(scratch) + used);
+      if (a.splitk == 1) { a.kt_split = a.KT; a.partial = nullptr; }
+      else { used += need; any_split = true; }
+    }
+    g.first[k + 1] = g.first[k] + a.tiles_total * a.splitk;
+  }
+  if (ls[0].dtype == RON_DTYPE_BF16) return launch_group_cfg<TraitsBF16S>(cfg, g, any_split, stream);
+  if (ls[0].dtype == RON_DTYPE_F16) return launch_group_cfg<TraitsF16S>(cfg, g, any_split, stream);
+  if (ls[0].dtype == RON_DTYPE_F32) return launch_group_cfg<TraitsF32S>(cfg, g, any_split, stream);
+  ron::set_error("conv group: unknown dtype %d", ls[0].dtype);
+  return RON_ERR_INVALID;
 }
 
 int64_t conv_scratch_bytes(const ConvLaunch& c) {

@@ -69,6 +69,8 @@ struct Op {
   int head_kind = -1, head_layer = -1;  // 0 cls, 1 obj, 2 loc
   int Ho = 0, Wo = 0;
   int lane = 0;                         // 0 = the caller's stream; 1..3 = side streams (independent head branches)
+  int group = -1;                       // >= 0: launched together with the neighbouring ops of the same group (launch_conv_group)
+  int group_cfg = 0;                    // tile configuration of that grouped launch
   double flops = 0;                     // algorithmic 2*MAC per image of this launch
   double act_bytes = 0;                 // algorithmic HBM bytes per image: input read once + output written once
   double wgt_bytes = 0;                 // ... plus the packed weights, once per launch
@@ -410,6 +412,65 @@ int make_anchors_ssd(ron_ctx* c) {
     }
   }
   return RON_OK;
+}
+
+// Launch order of the RON heads with the small convolutions grouped (launch_conv_group).  The reference builds the scales one
+// after the other (nets/ron_vgg_320.py:495-506); the only true dependencies are  ref(i) -> {trio3, inception1_1x1}(i) ->
+// {objectness_score, inception2_*, loc_pred}(i) -> cls_pred(i)  inside a scale and  ref(i) -> deconv_right(i+1) -> conv_left(i+1)
+// -> ref(i+1)  across scales.  At batch 32 the 5x5 and 10x10 scales (M = 800 / 3 200 rows) and the 1x1 / Cout <= 40 layers of
+// the 20x20 scale each fill a fraction of the chip and run 20-35 us apiece, mostly launch + pipeline fill; interleaving the
+// scales by dependency level gives launches of 3-6 independent convolutions each (measured, batch 32, one launch at a
+// time: 68 -> 47 us, 126 -> 50 us, 91 -> 38 us, 98 -> 78 us for the four T64 sets; the T128 sets of medium convolutions
+// are time-neutral and only save launches).  Every braced set below only reads what earlier entries wrote, and its
+// members write disjoint tensors / channel slices.
+void plan_groups(ron_ctx* c) {
+  if (c->is_ssd() || (c->cfg.flags & (RON_CFG_MULTI_STREAM | RON_CFG_NO_GROUPS))) return;
+  struct Slot { int cfg; std::vector<const char*> names; };     // cfg < 0: launches of their own
+  const int T64 = kCfgIgemm128x64, T128 = kCfgIgemm128;     // tiny convolutions / medium ones (Npad % 128 == 0)
+  const std::vector<Slot> order = {
+      {-1, {"block7_conv_left"}},
+      {T64, {"block7_trio3", "block7_inception1_1x1", "block6_deconv_right"}},
+      {-1, {"block6_conv_left"}},
+      {T64, {"block7_objectness_score", "block7_inception2_3x3", "block7_inception2_1x1", "block7_loc_pred",
+             "block6_inception1_1x1", "block5_deconv_right"}},
+      {T128, {"block6_trio3", "block5_conv_left"}},
+      {T128, {"block6_inception2_3x3", "block5_inception1_1x1", "block4_deconv_right"}},
+      {T64, {"block7_cls_pred", "block6_objectness_score", "block6_inception2_1x1", "block6_loc_pred"}},
+      {-1, {"block5_trio3"}},
+      {-1, {"block4_conv_left"}},
+      {T64, {"block6_cls_pred", "block5_objectness_score", "block5_loc_pred"}},
+      {T128, {"block5_inception2_3x3", "block5_inception2_1x1"}},
+      {-1, {"block4_trio3"}},
+      {-1, {"block5_cls_pred"}},             // grouped with block4_inception1_1x1 it ran 8 % slower than the two alone
+      {-1, {"block4_inception1_1x1"}},
+      {-1, {"block4_objectness_score"}},
+      {-1, {"block4_inception2_3x3"}},
+      {-1, {"block4_inception2_1x1"}},
+      {-1, {"block4_loc_pred"}},
+      {-1, {"block4_cls_pred"}},
+  };
+  std::map<std::string, int> at;
+  for (size_t i = 0; i < c->ops.size(); ++i) at[c->ops[i].name] = (int)i;
+  size_t first_head = c->ops.size(), n_named = 0;
+  for (const Slot& s : order)
+    for (const char* nm : s.names) {
+      auto it = at.find(nm);
+      if (it == at.end()) return;                         // not the graph this plan was written for: keep the plain order
+      first_head = std::min(first_head, (size_t)it->second);
+      ++n_named;
+    }
+  if (first_head + n_named != c->ops.size()) return;      // the heads must be exactly the tail of the op list
+  std::vector<Op> planned(c->ops.begin(), c->ops.begin() + first_head);
+  int gid = 0;
+  for (const Slot& s : order) {
+    for (const char* nm : s.names) {
+      Op o = c->ops[at[nm]];
+      if (s.cfg >= 0) { o.group = gid; o.group_cfg = s.cfg; }
+      planned.push_back(o);
+    }
+    if (s.cfg >= 0) ++gid;
+  }
+  c->ops.swap(planned);
 }
 
 Op conv_op(const std::string& name, int in, int out, int packed, int k, int cpad, int relu, int Ho, int Wo) {
@@ -782,6 +843,7 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
 #undef PACK
 #undef ATTR
   c->flops_per_image = flops;
+  plan_groups(c);
   // stream lanes: heads of block7 / block6 / block5 are independent of the main chain once their reference map exists
   if ((c->cfg.flags & RON_CFG_MULTI_STREAM) && !c->is_ssd()) {
     for (Op& o : c->ops)
@@ -852,15 +914,20 @@ static int slot_resources(ron_ctx* c) {
       RON_HIP_CHECK(hipEventCreateWithFlags(&c->lane_done[l], hipEventDisableTiming));
     }
   }
-  // split-K scratch: the largest slab set any launch of a lane can ask for at max_batch
-  for (const Op& o : c->ops) {
-    if (o.kind != OP_CONV || o.up > 0) continue;
-    for (int nb = 1; nb <= c->cfg.max_batch; ++nb) {
-      ConvLaunch L;
-      describe_conv(c, o, nb, nullptr, &L);
-      const int64_t b = conv_scratch_bytes(L);
-      if (b > c->splitk_bytes[o.lane]) c->splitk_bytes[o.lane] = b;
+  // split-K scratch: the largest slab set any launch (or grouped launch) of a lane can ask for at max_batch
+  for (size_t i = 0; i < c->ops.size();) {
+    const Op& o = c->ops[i];
+    size_t j = i + 1;
+    if (o.kind == OP_CONV && o.group >= 0) while (j < c->ops.size() && c->ops[j].group == o.group) ++j;
+    if (o.kind == OP_CONV && (o.group >= 0 || o.up == 0)) {
+      for (int nb = 1; nb <= c->cfg.max_batch; ++nb) {
+        ConvLaunch L[kMaxConvGroup];
+        for (size_t k = i; k < j; ++k) describe_conv(c, c->ops[k], nb, nullptr, &L[k - i]);
+        const int64_t b = o.group >= 0 ? conv_group_scratch_bytes(L, (int)(j - i), o.group_cfg) : conv_scratch_bytes(L[0]);
+        if (b > c->splitk_bytes[o.lane]) c->splitk_bytes[o.lane] = b;
+      }
     }
+    i = j;
   }
   for (int l = 0; l < 4; ++l)
     if (c->splitk_bytes[l] > 0) RON_HIP_CHECK(hipMalloc(&c->d_splitk[l], (size_t)c->splitk_bytes[l]));
@@ -937,7 +1004,8 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
   };
   const hipStream_t main_stream = (hipStream_t)stream;
   bool lane_started[4] = {false, false, false, false};
-  for (const Op& o : c->ops) {
+  for (size_t oi = 0; oi < c->ops.size(); ++oi) {
+    const Op& o = c->ops[oi];
     hipStream_t s = main_stream;
     if (o.lane > 0) {
       s = c->side[o.lane];
@@ -947,7 +1015,7 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
         lane_started[o.lane] = true;
       }
     }
-    if ((rc = stamp(s, (int)(&o - &c->ops[0])))) return rc;
+    if ((rc = stamp(s, (int)oi))) return rc;
     if (o.kind == OP_IM2COL) {
       const Tensor& t = c->tensors[o.out];
       if ((rc = launch_im2col_c3(d_images, n, t.H, t.W, c->cfg.dtype, t.d, t.C, s))) return rc;
@@ -964,6 +1032,20 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
       if ((rc = launch_maxpool3x3s1(c->view(o.in, n), c->view(o.out, n), c->cfg.dtype, s))) return rc;
     } else if (o.kind == OP_L2NORM) {
       if ((rc = launch_l2norm(c->view(o.in, n), c->view(o.out, n), c->d_l2_gamma, c->cfg.dtype, s))) return rc;
+    } else if (o.group >= 0) {
+      // this op and the following ones of the same group: one launch (the stamp above times the whole group)
+      ConvLaunch L[kMaxConvGroup];
+      size_t j = oi;
+      for (; j < c->ops.size() && c->ops[j].group == o.group; ++j) {
+        RON_REQUIRE(j - oi < (size_t)kMaxConvGroup, "conv group %d has more than %d members", o.group, kMaxConvGroup);
+        if ((rc = describe_conv(c, c->ops[j], n, out, &L[j - oi]))) return rc;
+      }
+      if ((rc = launch_conv_group(L, (int)(j - oi), o.group_cfg, c->d_splitk[o.lane], c->splitk_bytes[o.lane], s))) {
+        std::string msg = ron_last_error();
+        ron::set_error("group of %s: %s", o.name.c_str(), msg.c_str());
+        return rc;
+      }
+      oi = j - 1;
     } else {
       ConvLaunch L;
       if ((rc = describe_conv(c, o, n, out, &L))) return rc;
@@ -1032,13 +1114,32 @@ extern "C" int ron_profile_get(ron_ctx* c, int i, const char** name, int* is_con
   int rc = profile_collect(c);
   if (rc) return rc;
   const bool post = i == (int)c->ops.size();
-  if (name) *name = post ? "post_np" : c->ops[i].name.c_str();
+  // a grouped launch is reported on its first member (FLOPs / bytes of the whole group, name "first+N"); the other members
+  // report nothing, so sums over the rows stay right
+  double fl = 0, ab = 0, wb = 0;
+  static thread_local std::string label;
+  if (!post) {
+    const Op& o = c->ops[i];
+    label = o.name;
+    const bool member = o.group >= 0 && i > 0 && c->ops[i - 1].group == o.group;
+    if (!member) {
+      int extra = 0;
+      for (size_t j = i; j < c->ops.size() && (j == (size_t)i || (o.group >= 0 && c->ops[j].group == o.group)); ++j) {
+        fl += c->ops[j].flops; ab += c->ops[j].act_bytes; wb += c->ops[j].wgt_bytes;
+        if (j > (size_t)i) ++extra;
+      }
+      if (extra > 0) label = "group[" + o.name + "+" + std::to_string(extra) + "]";
+    } else {
+      label = "(" + o.name + ")";
+    }
+  }
+  if (name) *name = post ? "post_np" : label.c_str();
   if (is_conv) *is_conv = !post && c->ops[i].kind == OP_CONV;
-  if (flops_per_image) *flops_per_image = post ? 0.0 : c->ops[i].flops;
+  if (flops_per_image) *flops_per_image = fl;
   if (total_ms) *total_ms = c->timing[i].ms;
   if (launches) *launches = c->timing[i].launches;
-  if (act_bytes_per_image) *act_bytes_per_image = post ? 0.0 : c->ops[i].act_bytes;
-  if (weight_bytes) *weight_bytes = post ? 0.0 : c->ops[i].wgt_bytes;
+  if (act_bytes_per_image) *act_bytes_per_image = ab;
+  if (weight_bytes) *weight_bytes = wb;
   return RON_OK;
 }
 

@@ -40,7 +40,7 @@ class RONNet(object):
         prior_scaling=[0.1, 0.1, 0.2, 0.2])
 
     def __init__(self, params=None, variant='reducedfc', dtype='bf16', max_batch=32, device=None, fuse_pools=False,
-                 multi_stream=False):
+                 multi_stream=False, group_heads=True):
         self.params = params if isinstance(params, RONParams) else RONNet.default_params
         if variant not in _lib.VARIANTS:
             raise ValueError('Unknown RON variant %s' % variant)
@@ -52,6 +52,8 @@ class RONNet(object):
         self.fuse_pools = fuse_pools
         # multi_stream: heads of block7/6/5 on side streams (fork/join inside every forward)
         self.multi_stream = multi_stream
+        # group_heads: the small independent head convolutions of the coarse scales share launches (RON_CFG_NO_GROUPS off)
+        self.no_groups = not group_heads
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self._ctx = None
         self._anchors_dev = None
@@ -64,7 +66,8 @@ class RONNet(object):
                               self.device.index or 0,
                               (_lib.RON_CFG_FUSE_POOLS if self.fuse_pools else 0) |
                               (_lib.RON_CFG_MULTI_STREAM if getattr(self, 'multi_stream', False) else 0) |
-                              (_lib.RON_CFG_NO_STEM2 if getattr(self, 'no_stem2', False) else 0))
+                              (_lib.RON_CFG_NO_STEM2 if getattr(self, 'no_stem2', False) else 0) |
+                              (_lib.RON_CFG_NO_GROUPS if getattr(self, 'no_groups', False) else 0))
             h = C.c_void_p()
             check(lib().ron_create(C.byref(h), C.byref(cfg)))
             self._ctx = h

@@ -194,7 +194,8 @@ def test_multi_stream_heads_are_identical(pkg, dev, weights_reduced, images):
     """RON_CFG_MULTI_STREAM only changes which stream a head branch is enqueued on: bitwise the same tensors,
     also when calls follow each other without a host sync (fork/join ordering)."""
     x = torch.from_numpy(images).to(dev)
-    a = pkg['ron'].RONNet(variant='reducedfc', dtype='bf16', max_batch=2).load_weights(weights_reduced)
+    # one launch per convolution on both sides (side streams do not combine with grouped launches): identical launches, identical bits
+    a = pkg['ron'].RONNet(variant='reducedfc', dtype='bf16', max_batch=2, group_heads=False).load_weights(weights_reduced)
     b = pkg['ron'].RONNet(variant='reducedfc', dtype='bf16', max_batch=2, multi_stream=True).load_weights(weights_reduced)
     ha = a.forward_heads(x)
     for _ in range(3):
@@ -263,3 +264,26 @@ def test_ragged_batch_sizes(pkg, dev, weights_reduced, dtype, tol):
     with pytest.raises(Exception):
         net.forward_heads(torch.cat([x, x[:1]]))                  # 8 > max_batch
     net.close()
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-5), ('bf16', 2e-2)])
+def test_grouped_head_launches_match_one_launch_per_conv(pkg, dev, weights_reduced, images, dtype, tol):
+    """RON_CFG_NO_GROUPS: the same graph with every head convolution as its own launch.  Grouping changes tiles and the split
+    of K, i.e. only the order of fp32 partial sums (and, in bf16, where a value sits relative to a rounding boundary of the
+    next layer's input)."""
+    x = torch.from_numpy(images).to(dev)
+    a = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=2).load_weights(weights_reduced)
+    b = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=2, group_heads=False).load_weights(weights_reduced)
+    ha, hb = a.forward_heads(x), b.forward_heads(x)
+    for ta, tb in zip(ha, hb):
+        for u, v in zip(ta, tb):
+            assert _rel_err(u.cpu().numpy(), v.cpu().numpy()) <= tol
+    for name in ('block7_ref', 'block6_ref', 'block5_ref', 'block4_ref'):
+        assert _rel_err(a.end_point(name, 2).cpu().numpy(), b.end_point(name, 2).cpu().numpy()) <= tol, name
+    # grouped launches are deterministic: same bits on a second run
+    ha2 = a.forward_heads(x)
+    for ta, tb in zip(ha, ha2):
+        for u, v in zip(ta, tb):
+            assert torch.equal(u, v)
+    a.close()
+    b.close()
