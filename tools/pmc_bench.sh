@@ -21,12 +21,14 @@ for which in ('fetch', 'write'):
     vals = []
     for f in glob.glob('%s/pmc_%s/*/*counter_collection.csv' % (out, which)):
         for r in csv.DictReader(open(f)):
-            if 'conv_igemm_kernel' in r['Kernel_Name']:
+            if 'conv_igemm' in r['Kernel_Name'] or 'conv3x3_patch' in r['Kernel_Name']:      # every conv launch, grouped ones included
                 vals.append(float(r['Counter_Value']))
     tot[which] = (sum(vals) / max(len(vals), 1), len(vals))
 fetch_kib, n1 = tot['fetch']
 write_kib, n2 = tot['write']
-res = {'command': 'bench.py ' + ' '.join(args), 'conv_launches_sampled': [n1, n2],
+import os
+res = {'command': 'bench.py --steps 5 --warmup 2 --no-cpu-baseline ' + ' '.join(args), 'commit': os.environ.get('RON_COMMIT'),
+       'conv_launches_sampled': [n1, n2],
        'FETCH_SIZE_KiB_per_launch_raw': fetch_kib, 'WRITE_SIZE_KiB_per_launch': write_kib,
        'correction': 'FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B)',
        'hbm_bytes_per_conv_launch': (2 * fetch_kib + write_kib) * 1024}

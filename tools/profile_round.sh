@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's judged artefacts on the MI355X box into gpurun_out/final/ (copy what matters into profiles/rNN/).
-# usage: tools/profile_round.sh
+# usage: RON_COMMIT=<sha> tools/profile_round.sh
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/final
@@ -9,10 +9,23 @@ python3 bench.py --layers $O/layers_cfg2_inflight2.txt > $O/bench_cfg2_default.j
 python3 bench.py --no-cpu-baseline --in-flight 1 --layers $O/layers_cfg2_inflight1.txt > $O/bench_cfg2_inflight1.json 2>> $O/err.txt
 python3 bench.py --no-cpu-baseline --variant reducedfc --dtype fp16 --batch 64 --layers $O/layers_cfg4.txt > $O/bench_cfg4.json 2>> $O/err.txt
 python3 bench.py --no-cpu-baseline --variant ssd512 --batch 16 --layers $O/layers_cfg5.txt > $O/bench_cfg5.json 2>> $O/err.txt
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --no-cpu-baseline --check-gather > $O/bench_cfg2_torchrun_1rank.json 2>> $O/err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg2_under_rocprof_inflight2.json 2>> $O/err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --in-flight 1 > $O/bench_cfg2_under_rocprof_inflight1.json 2>> $O/err.txt
 for d in if1 if2; do f=$(ls $O/prof_$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$d.csv; done
 bash tools/pmc_bench.sh $O/pmc --in-flight 1 > $O/pmc.log 2>&1
 cp $O/pmc/traffic_*.json $O/ 2>/dev/null
-rm -rf $O/prof_if1 $O/prof_if2 $O/pmc/pmc_fetch $O/pmc/pmc_write
+bash tools/pmc_mfma.sh $O/pmc > $O/pmc_mfma.log 2>&1
+cp $O/pmc/mfma_busy_*.json $O/ 2>/dev/null
+rm -rf $O/prof_if1 $O/prof_if2 $O/pmc/pmc_fetch $O/pmc/pmc_write $O/pmc/pmc_mfma
 ls -la $O
+tail -3 $O/pmc.log; tail -30 $O/pmc_mfma.log
+for f in bench_cfg2_default bench_cfg2_inflight1 bench_cfg4 bench_cfg5 bench_cfg2_torchrun_1rank; do python3 - "$O/$f.json" <<'PY'
+import json,sys
+try:
+    l=[x for x in open(sys.argv[1]) if x.startswith('{')][-1]; d=json.loads(l)
+    r=d['roofline']
+    print(sys.argv[1], round(d['value'],1), 'ms', round(d['ms_per_step'],3), 'frac', round(r['frac'],3), 'per_kernel', round(r.get('per_kernel_frac',0),3))
+except Exception as e: print(sys.argv[1], 'ERR', e)
+PY
+done
