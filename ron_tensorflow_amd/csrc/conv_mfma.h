@@ -71,10 +71,12 @@ enum {
   kExpIgemm256NoA = 11,    // row-gather 256 x 256 likewise
   kExpIgemm256NoB = 12,
   kExpIgemm256NoAB = 13,
-  kExpIgemm256BFirst = 14, // row-gather 256 x 256 with the weight pieces of a stage issued before the activation pieces
-  kExpIgemm256Early = 15,  // ... with all pieces of a stage issued during its first k-step
+  kExpIgemm256A3 = 14,     // row-gather 256 x 256 with three activation stages (+ two weight stages = all 160 KB of LDS)
+  kExpIgemm256Early = 15,  // row-gather 256 x 256 with all pieces of a stage issued during its first k-step
+  kExpIgemm128A3 = 16,     // row-gather 128 x 128 with three activation stages (80 KB: still two workgroups per CU)
+  kExpIgemm256A3Early = 17,
 #ifdef RON_EXP
-  kNumCfgsBuilt = 16
+  kNumCfgsBuilt = 18
 #else
   kNumCfgsBuilt = kNumCfgs
 #endif

@@ -33,7 +33,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // descriptor has none, 3 = neither moves.  Timing-only, results are wrong; 0 in everything the shipped library holds.
 // One tile of launch `p`: workgroup `bid` of the `nwg` that launch consists of (a launch of its own, or a range of the
 // workgroups of a grouped launch).
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0>
+// SA: stages of the A (activation) ring; the B (weight) ring has S.  SA = S + 1 gives the activation pieces two K steps to
+// land instead of one: the two operands of a 256 x 256 x 64 step are 32 KB each, so three A stages + two B stages are
+// exactly the CU's 160 KB of LDS.  The per-row tables then alias a weight stage during set-up and the output offsets are
+// recomputed after the K loop.
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S>
 __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigned bid, const unsigned nwg, char* smem) {
   constexpr int kLanesPerRow = kRowBytes / 16;       // 16-byte chunks per row
   constexpr int MT = Tr::kMT;                        // MFMA output tile (16)
@@ -47,14 +51,20 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   constexpr int A_IT = BM / kRowsPerIt, B_IT = BN / kRowsPerIt;
   constexpr int LPT = A_IT + B_IT;                   // LDS-DMA instructions per thread and K step
   constexpr int kABytes = BM * kRowBytes, kBBytes = BN * kRowBytes;
-  constexpr int kStage = kABytes + kBBytes;
+  constexpr int kRingBytes = SA * kABytes + S * kBBytes;
+  constexpr bool kTablesAlias = SA > S;               // the deeper ring takes the LDS the tables would need: see SA above
   constexpr int kChunkElems = kRowBytes / Tr::kEsz;
+  static_assert(SA == S || SA == S + 1, "activation ring: as deep as the weight ring, or one deeper");
+  static_assert(!kTablesAlias || 2 * BM * (int)sizeof(int) <= kBBytes, "tables must fit a weight stage");
   static_assert(BM % kRowsPerIt == 0 && BN % kRowsPerIt == 0 && kRowsPerIt % 16 == 0, "tile / thread-count mismatch");
   static_assert(TM % 32 == 0 && TN % 32 == 0 && S >= 2 && S <= 5, "bad wave tile / stage count");
   static_assert(NR <= 8, "vector epilogue: at most 8 channels per lane");
   static_assert(SPREAD == 1 || SPREAD == 2, "SPREAD");
-  // layout: [stage 0 .. S-1: A | B][in_off: BM ints][out_off: BM ints]
-  int* s_in_off = reinterpret_cast<int*>(smem + S * kStage);
+  // layout: [A stage 0 .. SA-1][B stage 0 .. S-1][in_off: BM ints][out_off: BM ints]; kTablesAlias: the tables sit in the
+  // last B stage until the K loop starts (the first LDS-DMA into that stage is issued in step 0)
+  char* s_a = smem;
+  char* s_b = smem + SA * kABytes;
+  int* s_in_off = reinterpret_cast<int*>(kTablesAlias ? s_b + (S - 1) * kBBytes : smem + kRingBytes);
   int* s_out_off = s_in_off + BM;
 
   const int tid = threadIdx.x;
@@ -74,7 +84,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   const int kt0 = zsplit * p.kt_split;
   const int kt1 = min(p.KT, kt0 + p.kt_split);
 
-  // per-row addressing, once per tile
+  // per-row addressing, once per tile (kTablesAlias: the output offsets once more after the K loop)
+  auto fill_tables = [&](int* in_off, int* out_off) {
   for (int r = tid; r < BM; r += kThreads) {
     int img, oy, ox, off;
     bool valid;
@@ -102,9 +113,11 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
       off = ((img * p.out_Hp + oy * os + p.out_pad) * p.out_Wp + ox * os + p.out_pad) * p.out_cstride + p.out_coff;
     }
     const int iy = oy * p.stride + p.in_org, ix = ox * p.stride + p.in_org;
-    s_in_off[r] = (int)((((unsigned)(img * p.in_Hp + iy) * p.in_Wp + ix) * p.in_cstride + p.in_coff) * Tr::kEsz);
-    s_out_off[r] = valid ? off : -1;
+    if (in_off != nullptr) in_off[r] = (int)((((unsigned)(img * p.in_Hp + iy) * p.in_Wp + ix) * p.in_cstride + p.in_coff) * Tr::kEsz);
+    out_off[r] = valid ? off : -1;
   }
+  };
+  fill_tables(s_in_off, s_out_off);
   __syncthreads();
 
   // LDS-DMA source offsets (bytes): thread -> (row = it*kRowsPerIt + tid/8, slot = tid%8), source chunk = slot ^ key(row)
@@ -133,27 +146,29 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   const int chunks_per_tap = p.Cin / kChunkElems;
   const int tap0 = kt0 / chunks_per_tap;
   int ky = tap0 / p.kw, kx = tap0 - (tap0 / p.kw) * p.kw, cc = (kt0 - tap0 * chunks_per_tap) * kChunkElems;
-  // One tile = LPT LDS-DMA pieces per thread (A pieces first).  RON_STAGE_BEGIN computes the wave-uniform
-  // part once per tile, RON_STAGE_PIECE issues piece i (compile-time), RON_STAGE_END advances the tap.
+  // One K step issues LPT LDS-DMA pieces per thread: the B_IT weight pieces of tile kt+S-1 first, then the A_IT
+  // activation pieces of tile kt+SA-1 (a wave's vmcnt retires in issue order: the pieces that may stay in flight longest
+  // go out last).  RON_STAGE_BEGIN computes the wave-uniform part once per step, RON_STAGE_PIECE issues piece j
+  // (compile-time), RON_STAGE_END advances the tap of the activation ring.
 #define RON_STAGE_BEGIN(kt_)                                                                                         \
     /* past the last tile: zero-record descriptors, the DMA moves nothing but keeps the vmcnt bookkeeping uniform */  \
-    const bool live_ = (kt_) < kt1;                                                                                  \
+    const int kta_ = (kt_) + SA - 1, ktb_ = (kt_) + S - 1;                                                           \
     const __amdgpu_buffer_rsrc_t rs_a =                                                                              \
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (live_ && !(EXP & 1)) ? p.in_bytes : 0u, 0x00020000); \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (kta_ < kt1 && !(EXP & 1)) ? p.in_bytes : 0u, 0x00020000); \
     const __amdgpu_buffer_rsrc_t rs_b =                                                                              \
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (live_ && !(EXP & 2)) ? p.wgt_bytes : 0u, 0x00020000); \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (ktb_ < kt1 && !(EXP & 2)) ? p.wgt_bytes : 0u, 0x00020000); \
     const int a_soff = ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz;                         \
-    const int b_soff = (kt_) * kWeightBlockBytes;                                                                    \
-    char* dst = smem + (((kt_) - kt0) % S) * kStage + wave * 1024;
+    const int b_soff = ktb_ * kWeightBlockBytes;                                                                     \
+    char* dst_a = s_a + ((kta_ - kt0) % SA) * kABytes + wave * 1024;                                                 \
+    char* dst_b = s_b + ((ktb_ - kt0) % S) * kBBytes + wave * 1024;
+#define RON_STAGE_PIECE_B(i_)                                                                                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(dst_b + (i_) * kRowsPerIt * kRowBytes), 16, b_voff[i_], b_soff, 0, 0)
+#define RON_STAGE_PIECE_A(i_)                                                                                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst_a + (i_) * kRowsPerIt * kRowBytes), 16, a_voff[i_], a_soff, 0, 0)
 #define RON_STAGE_PIECE(j_)                                                                                          \
     do {                                                                                                             \
-      const int i_ = (EXP & 4) ? ((j_) + A_IT) % LPT : (j_);   /* EXP 4: the weight pieces go out first */               \
-      if ((i_) < A_IT)                                                                                               \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst + (i_) * kRowsPerIt * kRowBytes), 16,         \
-                                                 a_voff[(i_) < A_IT ? (i_) : 0], a_soff, 0, 0);                      \
-      else                                                                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(dst + kABytes + ((i_) - A_IT) * kRowsPerIt * kRowBytes), 16, \
-                                                 b_voff[(i_) >= A_IT ? (i_) - A_IT : 0], b_soff, 0, 0);              \
+      if ((j_) < B_IT) RON_STAGE_PIECE_B((j_) < B_IT ? (j_) : 0);                                                    \
+      else RON_STAGE_PIECE_A((j_) >= B_IT ? (j_) - B_IT : 0);                                                        \
     } while (0)
 #define RON_STAGE_END()                                                                                              \
     do {                                                                                                             \
@@ -178,38 +193,46 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
 #pragma unroll
   for (int s = 0; s < KS; ++s) rd_off[s] = fr * kRowBytes + (((kGroups * s + fh) ^ ((fr >> 1) & 7)) << 4);
   const int a_base = wm * TM * kRowBytes;
-  const int b_base = kABytes + wn * TN * kRowBytes;
+  const int b_base = wn * TN * kRowBytes;
 
-  // prologue: S-1 tiles in flight
+  // prologue: the steps before the first one, in the order the loop issues them: SA-1 activation tiles and S-1 weight
+  // tiles in flight (a step before tile 0 only issues what exists)
 #pragma unroll
-  for (int t = 0; t < S - 1; ++t) {
+  for (int t = -(SA - 1); t < 0; ++t) {
     RON_STAGE_BEGIN(kt0 + t)
+    if (t + S - 1 >= 0) {
 #pragma unroll
-    for (int i = 0; i < LPT; ++i) RON_STAGE_PIECE(i);
+      for (int i = 0; i < B_IT; ++i) RON_STAGE_PIECE_B(i);
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) RON_STAGE_PIECE_A(i);
     RON_STAGE_END();
   }
 
   for (int kt = kt0; kt < kt1; ++kt) {
-    wait_vmcnt<(S - 2) * LPT>();            // this wave's share of tile kt has landed
+    // this wave's share of tile kt has landed; the youngest S-2 groups and the activation pieces one group further back
+    // (SA = S + 1) may still be in flight
+    wait_vmcnt<(S - 2) * LPT + (SA - S) * A_IT>();
     __builtin_amdgcn_s_barrier();           // ... everyone's has, and everyone is done reading tile kt-1
-    // refill the stage tile kt-1 occupied; the LPT pieces go out between the MFMAs below
-    RON_STAGE_BEGIN(kt + S - 1)
-    const char* sbuf = smem + ((kt - kt0) % S) * kStage;
+    // refill the stages tile kt-1 occupied; the LPT pieces go out between the MFMAs below
+    RON_STAGE_BEGIN(kt)
+    const char* sbuf_a = s_a + ((kt - kt0) % SA) * kABytes;
+    const char* sbuf_b = s_b + ((kt - kt0) % S) * kBBytes;
     // fragments of k-step s+1 are read while the MFMAs of k-step s run (two register sets)
     u32x4 fa[2][MR], fb[2][NR];
 #pragma unroll
-    for (int i = 0; i < MR; ++i) fa[0][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * MT * kRowBytes + rd_off[0]);
+    for (int i = 0; i < MR; ++i) fa[0][i] = *reinterpret_cast<const u32x4*>(sbuf_a + a_base + i * MT * kRowBytes + rd_off[0]);
 #pragma unroll
-    for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * MT * kRowBytes + rd_off[0]);
+    for (int j = 0; j < NR; ++j) fb[0][j] = *reinterpret_cast<const u32x4*>(sbuf_b + b_base + j * MT * kRowBytes + rd_off[0]);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (s < KS - 1) {
 #pragma unroll
         for (int i = 0; i < MR; ++i)
-          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sbuf + a_base + i * MT * kRowBytes + rd_off[(s + 1) % KS]);
+          fa[(s + 1) & 1][i] = *reinterpret_cast<const u32x4*>(sbuf_a + a_base + i * MT * kRowBytes + rd_off[(s + 1) % KS]);
 #pragma unroll
         for (int j = 0; j < NR; ++j)
-          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sbuf + b_base + j * MT * kRowBytes + rd_off[(s + 1) % KS]);
+          fb[(s + 1) & 1][j] = *reinterpret_cast<const u32x4*>(sbuf_b + b_base + j * MT * kRowBytes + rd_off[(s + 1) % KS]);
       }
 #pragma unroll
       for (int i = 0; i < LPT; ++i)
@@ -246,7 +269,17 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   }
 #undef RON_STAGE_BEGIN
 #undef RON_STAGE_PIECE
+#undef RON_STAGE_PIECE_A
+#undef RON_STAGE_PIECE_B
 #undef RON_STAGE_END
+  if (kTablesAlias) {
+    // the output offsets were overwritten by the weight ring: once more, into the first activation stage (nobody reads
+    // the rings any more once every wave is past its last K step)
+    __syncthreads();
+    s_out_off = reinterpret_cast<int*>(s_a);
+    fill_tables(nullptr, s_out_off);
+    __syncthreads();
+  }
 
   // epilogue.  C/D layout of the 16x16 MFMA: column = lane % 16, row = e + 4 * (lane / 16), e < 4
   int tap_off = 0, n_base = n0;
@@ -275,10 +308,14 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n_base + nloc, tap_off);
 }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0>
-__global__ __launch_bounds__(WM * WN * 64, (S * (BM + BN) * kRowBytes > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
+constexpr int igemm_lds_bytes(int BM, int BN, int S, int SA) {
+  return (SA * BM + S * BN) * kRowBytes + (SA > S ? 0 : 2 * BM * (int)sizeof(int));
+}
+
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S>
+__global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S, SA) > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD, EXP>(p, blockIdx.x, gridDim.x, smem);
+  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA>(p, blockIdx.x, gridDim.x, smem);
 }
 
 // Several independent small convolutions in ONE launch (the per-scale head layers of the coarse scales, each of which
@@ -357,14 +394,14 @@ __global__ void splitk_finalize_group_kernel(ConvGroupArgs g) {
   if (p.splitk > 1) splitk_finalize_body<Tr>(p);
 }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S>
 int launch_t(const ConvArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)S * (BM + BN) * kRowBytes + 2 * BM * sizeof(int);
+  const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, SA);
   static PerDeviceOnce once;
   if (once.first())
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP>),
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -380,8 +417,10 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case kExpIgemm256NoA: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 1>(a, s);
     case kExpIgemm256NoB: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 2>(a, s);
     case kExpIgemm256NoAB: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 3>(a, s);
-    case kExpIgemm256BFirst: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 4>(a, s);
+    case kExpIgemm256A3: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 0, 3>(a, s);
     case kExpIgemm256Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0>(a, s);
+    case kExpIgemm128A3: return launch_t<Tr, 128, 128, 2, 2, 2, 1, 0, 3>(a, s);
+    case kExpIgemm256A3Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0, 3>(a, s);
 #endif
   }
   ron::set_error("conv: unknown tile config %d", cfg);
@@ -405,7 +444,7 @@ int conv_k_chunk(int dtype) { return kRowBytes / (int)dtype_size(dtype); }
 int conv_n_tile(int cout) { return cout <= 64 ? 64 : 128; }
 int conv_num_cfgs() { return kNumCfgsBuilt; }
 
-static bool igemm_is256(int cfg) { return cfg == kCfgIgemm256 || (cfg >= kExpIgemm256NoA && cfg <= kExpIgemm256Early); }
+static bool igemm_is256(int cfg) { return cfg == kCfgIgemm256 || (cfg >= kExpIgemm256NoA && cfg <= kExpIgemm256Early) || cfg == kExpIgemm256A3Early; }
 static int igemm_bm(int cfg) { return igemm_is256(cfg) ? 256 : 128; }
 static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : (cfg == kCfgIgemm128x64 ? 64 : 128); }
 // workgroups of a configuration the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
@@ -491,7 +530,7 @@ namespace detail {
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 int launch_group_t(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
-  const size_t lds = (size_t)S * (BM + BN) * kRowBytes + 2 * BM * sizeof(int);
+  const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, S);
   static PerDeviceOnce once;
   if (once.first())
     RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>),
