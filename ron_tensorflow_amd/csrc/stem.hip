@@ -140,6 +140,12 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 //   D. + bias, ReLU, 2x2 max-pool (horizontal pairs are adjacent accumulator registers, vertical pairs meet in LDS),
 //      16-byte stores of the pooled 4 x 16 tile.
 // HBM traffic: image in (1.2 MB / image), pool1 out (3.3 MB / image).
+// Round 2 tried the overlap DESIGN.md 3.2 had queued: waves 4-7 as producers (image fetch + conv1_1 of tile t+1 into a second
+// patch buffer) beside waves 0-3 as consumers (conv1_2 of tile t, two rows each, pooling in registers), three taps' weights in
+// registers to make room for the second buffer, one barrier per tile.  Correct (same tests), but 335 us instead of 310 us at
+// batch 32: conv1_1 on the fly costs ~1000 cycles per group of 16 patch pixels (gather + convert of 27 taps, bias / ReLU /
+// convert / inside-test per output), and four producer waves - one per SIMD, nothing to hide their latencies behind - take longer
+// over a tile's 22 groups than the consumers' 4600 MFMA cycles.  The sequential form below stays.
 constexpr int kS2TH = 8, kS2TW = 32;
 constexpr int kS2PW = kS2TW + 2, kS2PH = kS2TH + 2, kS2Rows = kS2PW * kS2PH;       // 34 x 10 = 340 patch rows
 constexpr int kS2IW = kS2TW + 4, kS2IH = kS2TH + 4;                                 // 36 x 12 image patch
@@ -397,7 +403,7 @@ int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w
               "stem2 kernel: bad shape");
   const int tiles = n * (h / kS2TH) * (w / kS2TW);
   const int grid = std::min(tiles, 256);
-  static const int abl = getenv("RON_STEM2_ABL") ? atoi(getenv("RON_STEM2_ABL")) : 0;
+  const int abl = 0;        // phase-skipping diagnostics of round 1 (kernel argument kept: 1 = no conv1_1, 2 = no tap loop, 4 = no stores)
   static PerDeviceOnce attr_set[2];                // the attribute is per device (common.h)
   const int which = dtype == RON_DTYPE_BF16 ? 0 : 1;
   if (attr_set[which].first()) {

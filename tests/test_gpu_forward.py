@@ -287,3 +287,20 @@ def test_grouped_head_launches_match_one_launch_per_conv(pkg, dev, weights_reduc
             assert torch.equal(u, v)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_fused_stem_vs_oracle_at_full_size(pkg, dev, weights_reduced, images, dtype):
+    """conv1_1 + conv1_2 + pool1 as ONE kernel (stem2_kernel, 320 x 320 input) against the ORACLE, not against the other GPU
+    path: pool1 and, two fused-pool convolutions further, pool2 vs the oracle with operands rounded to the storage type."""
+    rnd = {'bf16': orf.round_bf16, 'fp16': orf.round_f16}[dtype]
+    tol = {'bf16': 0.02, 'fp16': 0.003}[dtype]
+    col = {}
+    orf.ron_forward(images[:1], weights_reduced, 'reducedfc', backend='torch', round_fn=rnd, collect=col)
+    net = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=2, fuse_pools=True).load_weights(weights_reduced)
+    net.forward_heads(torch.from_numpy(images).to(dev))
+    for name in ('pool1', 'pool2'):
+        got = net.end_point(name, 2).cpu().numpy()[:1]
+        assert got.shape == col[name].shape
+        assert _rel_err(got, col[name]) < tol, name
+    net.close()
