@@ -45,10 +45,14 @@ def _start_torchrun_child(config):
             return
     except Exception:
         return
+    import socket
     import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:        # a free rendezvous port on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
-           '--master-port', '29671', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2',
            '--no-cpu-baseline', '--check-gather']
     try:
         p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
