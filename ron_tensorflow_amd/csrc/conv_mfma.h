@@ -62,21 +62,23 @@ enum {
   kCfgPatch256 = 4,        // halo-patch kernel (conv_patch.hip), 256 positions x 256 channels
   kCfgPatch128 = 5,        // ... x 128 channels, 3 weight stages
   kCfgPatch64 = 6,         // ... x 64 channels, 3 weight stages
-  kNumCfgs = 7,
+  kCfgIgemm256TapsInner = 7,   // 256 x 256 with K ordered chunk-major, taps innermost (layers with <= 2 column tiles)
+  kNumCfgs = 8,
   // experimental builds only (make EXP=1 -> libron_hip_exp.so, tools/sweep_conv.py): timing variants, some with wrong results
-  kExpPatch128S4 = 7,      // halo-patch, 128 channels, 4 weight stages (three steps of lead)
-  kExpPatch256NoA = 8,     // halo-patch 256 without the patch traffic / without the weight traffic / without either
-  kExpPatch256NoB = 9,
-  kExpPatch256NoAB = 10,
-  kExpIgemm256NoA = 11,    // row-gather 256 x 256 likewise
-  kExpIgemm256NoB = 12,
-  kExpIgemm256NoAB = 13,
-  kExpIgemm256A3 = 14,     // row-gather 256 x 256 with three activation stages (+ two weight stages = all 160 KB of LDS)
-  kExpIgemm256Early = 15,  // row-gather 256 x 256 with all pieces of a stage issued during its first k-step
-  kExpIgemm128A3 = 16,     // row-gather 128 x 128 with three activation stages (80 KB: still two workgroups per CU)
-  kExpIgemm256A3Early = 17,
+  kExpPatch128S4 = 8,      // halo-patch, 128 channels, 4 weight stages (three steps of lead)
+  kExpPatch256NoA = 9,     // halo-patch 256 without the patch traffic / without the weight traffic / without either
+  kExpPatch256NoB = 10,
+  kExpPatch256NoAB = 11,
+  kExpIgemm256NoA = 12,    // row-gather 256 x 256 likewise
+  kExpIgemm256NoB = 13,
+  kExpIgemm256NoAB = 14,
+  kExpIgemm256A3 = 15,     // row-gather 256 x 256 with three activation stages (+ two weight stages = all 160 KB of LDS)
+  kExpIgemm256Early = 16,  // row-gather 256 x 256 with all pieces of a stage issued during its first k-step
+  kExpIgemm128A3 = 17,     // row-gather 128 x 128 with three activation stages (80 KB: still two workgroups per CU)
+  kExpIgemm256A3Early = 18,
+  kExpIgemm256NtA = 19,    // row-gather 256 x 256 with non-temporal activation loads (the weights keep the L2)
 #ifdef RON_EXP
-  kNumCfgsBuilt = 18
+  kNumCfgsBuilt = 20
 #else
   kNumCfgsBuilt = kNumCfgs
 #endif

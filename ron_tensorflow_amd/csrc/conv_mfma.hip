@@ -30,14 +30,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // Tile configuration: BM x BN block tile, WM x WN waves (each wave owns (BM/WM) x (BN/WN)), S LDS stages.
 // SPREAD 1: the LDS-DMA pieces of a tile are shared out over the k-steps of the stage; 2: all go out during k-step 0.
 // EXP (experimental builds only, make EXP=1): 1 = the A descriptor has no records (only the weights move), 2 = the B
-// descriptor has none, 3 = neither moves.  Timing-only, results are wrong; 0 in everything the shipped library holds.
+// descriptor has none, 3 = neither moves (timing-only, results are wrong); 8 = non-temporal activation loads (results
+// valid, 10-20 % slower).  0 in everything the shipped library holds.
 // One tile of launch `p`: workgroup `bid` of the `nwg` that launch consists of (a launch of its own, or a range of the
 // workgroups of a grouped launch).
 // SA: stages of the A (activation) ring; the B (weight) ring has S.  SA = S + 1 gives the activation pieces two K steps to
 // land instead of one: the two operands of a 256 x 256 x 64 step are 32 KB each, so three A stages + two B stages are
 // exactly the CU's 160 KB of LDS.  The per-row tables then alias a weight stage during set-up and the output offsets are
 // recomputed after the K loop.
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S, bool TI = false>
 __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigned bid, const unsigned nwg, char* smem) {
   constexpr int kLanesPerRow = kRowBytes / 16;       // 16-byte chunks per row
   constexpr int MT = Tr::kMT;                        // MFMA output tile (16)
@@ -144,8 +145,17 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
 
   // K-step bookkeeping (wave-uniform): tap (ky, kx) and channel chunk cc of the NEXT tile to stage
   const int chunks_per_tap = p.Cin / kChunkElems;
-  const int tap0 = kt0 / chunks_per_tap;
-  int ky = tap0 / p.kw, kx = tap0 - (tap0 / p.kw) * p.kw, cc = (kt0 - tap0 * chunks_per_tap) * kChunkElems;
+  // TI ("taps innermost"): K runs chunk-major, step q = chunk * taps + tap (the weights of tap t, chunk c are block
+  // t * chunks + c whatever the order).  Consecutive steps then re-read almost the same input lines, one pixel over, instead of
+  // coming back to them a whole sweep of the channels later: the re-reads hit L2 without another workgroup's help.  Worth
+  // 1-6 % on layers with one or two column tiles (nobody else on the XCD stages the same input rows at the same time), nothing
+  // or -1 % on the wide ones (profiles/r02/sweep_conv_exp_v4_tapsinner.txt); conv_pick_igemm_cfg selects it accordingly.
+  static_assert(!TI || SA == S, "taps-innermost order: equal ring depths");
+  const int n_taps = p.KT / chunks_per_tap;
+  const int tap0 = TI ? kt0 % n_taps : kt0 / chunks_per_tap;
+  int ky = tap0 / p.kw, kx = tap0 - (tap0 / p.kw) * p.kw;
+  int cc = (TI ? kt0 / n_taps : kt0 - tap0 * chunks_per_tap) * kChunkElems;
+  int tb = TI ? kt0 % n_taps : 0, cb = TI ? kt0 / n_taps : 0;          // weight ring: tap / chunk of its next tile
   // One K step issues LPT LDS-DMA pieces per thread: the B_IT weight pieces of tile kt+S-1 first, then the A_IT
   // activation pieces of tile kt+SA-1 (a wave's vmcnt retires in issue order: the pieces that may stay in flight longest
   // go out last).  RON_STAGE_BEGIN computes the wave-uniform part once per step, RON_STAGE_PIECE issues piece j
@@ -158,13 +168,13 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
     const __amdgpu_buffer_rsrc_t rs_b =                                                                              \
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (ktb_ < kt1 && !(EXP & 2)) ? p.wgt_bytes : 0u, 0x00020000); \
     const int a_soff = ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz;                         \
-    const int b_soff = ktb_ * kWeightBlockBytes;                                                                     \
+    const int b_soff = (TI ? tb * chunks_per_tap + cb : ktb_) * kWeightBlockBytes;                                   \
     char* dst_a = s_a + ((kta_ - kt0) % SA) * kABytes + wave * 1024;                                                 \
     char* dst_b = s_b + ((ktb_ - kt0) % S) * kBBytes + wave * 1024;
 #define RON_STAGE_PIECE_B(i_)                                                                                        \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(dst_b + (i_) * kRowsPerIt * kRowBytes), 16, b_voff[i_], b_soff, 0, 0)
 #define RON_STAGE_PIECE_A(i_)                                                                                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst_a + (i_) * kRowsPerIt * kRowBytes), 16, a_voff[i_], a_soff, 0, 0)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst_a + (i_) * kRowsPerIt * kRowBytes), 16, a_voff[i_], a_soff, 0, (EXP & 8) ? 2 : 0)
 #define RON_STAGE_PIECE(j_)                                                                                          \
     do {                                                                                                             \
       if ((j_) < B_IT) RON_STAGE_PIECE_B((j_) < B_IT ? (j_) : 0);                                                    \
@@ -172,6 +182,11 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
     } while (0)
 #define RON_STAGE_END()                                                                                              \
     do {                                                                                                             \
+      if (TI) {                                                                                                      \
+        if (++kx == p.kw) { kx = 0; if (++ky * p.kw >= n_taps) { ky = 0; cc += kChunkElems; } }                       \
+        if (++tb == n_taps) { tb = 0; ++cb; }                                                                        \
+        break;                                                                                                       \
+      }                                                                                                              \
       cc += kChunkElems;                                                                                             \
       if (cc >= p.Cin) {                                                                                             \
         cc = 0;                                                                                                      \
@@ -312,10 +327,10 @@ constexpr int igemm_lds_bytes(int BM, int BN, int S, int SA) {
   return (SA * BM + S * BN) * kRowBytes + (SA > S ? 0 : 2 * BM * (int)sizeof(int));
 }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S, bool TI = false>
 __global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S, SA) > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA>(p, blockIdx.x, gridDim.x, smem);
+  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA, TI>(p, blockIdx.x, gridDim.x, smem);
 }
 
 // Several independent small convolutions in ONE launch (the per-scale head layers of the coarse scales, each of which
@@ -394,14 +409,14 @@ __global__ void splitk_finalize_group_kernel(ConvGroupArgs g) {
   if (p.splitk > 1) splitk_finalize_body<Tr>(p);
 }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S, bool TI = false>
 int launch_t(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, SA);
   static PerDeviceOnce once;
   if (once.first())
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA>),
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA, TI>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA, TI>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -413,11 +428,13 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case kCfgIgemm128: return launch_t<Tr, 128, 128, 2, 2, 2, 1>(a, s);
     case kCfgIgemm128Early: return launch_t<Tr, 128, 128, 2, 2, 2, 2>(a, s);
     case kCfgIgemm128x64: return launch_t<Tr, 128, 64, 2, 2, 2, 2>(a, s);
+    case kCfgIgemm256TapsInner: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 0, 2, true>(a, s);
 #ifdef RON_EXP
     case kExpIgemm256NoA: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 1>(a, s);
     case kExpIgemm256NoB: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 2>(a, s);
     case kExpIgemm256NoAB: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 3>(a, s);
     case kExpIgemm256A3: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 0, 3>(a, s);
+    case kExpIgemm256NtA: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 8>(a, s);
     case kExpIgemm256Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0>(a, s);
     case kExpIgemm128A3: return launch_t<Tr, 128, 128, 2, 2, 2, 1, 0, 3>(a, s);
     case kExpIgemm256A3Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0, 3>(a, s);
@@ -444,7 +461,10 @@ int conv_k_chunk(int dtype) { return kRowBytes / (int)dtype_size(dtype); }
 int conv_n_tile(int cout) { return cout <= 64 ? 64 : 128; }
 int conv_num_cfgs() { return kNumCfgsBuilt; }
 
-static bool igemm_is256(int cfg) { return cfg == kCfgIgemm256 || (cfg >= kExpIgemm256NoA && cfg <= kExpIgemm256Early) || cfg == kExpIgemm256A3Early; }
+static bool igemm_is256(int cfg) {
+  return cfg == kCfgIgemm256 || cfg == kCfgIgemm256TapsInner || (cfg >= kExpIgemm256NoA && cfg <= kExpIgemm256Early) ||
+         cfg == kExpIgemm256A3Early || cfg == kExpIgemm256NtA;
+}
 static int igemm_bm(int cfg) { return igemm_is256(cfg) ? 256 : 128; }
 static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : (cfg == kCfgIgemm128x64 ? 64 : 128); }
 // workgroups of a configuration the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
@@ -462,10 +482,10 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
 // Default tile of the row-gather kernel, from tools/sweep_conv.py on MI355X at batch 32 (profiles/r01/sweep_*.txt).
 // The 256x256 tile wins once it yields >= ~160 workgroups; below that the grid is the problem and the 128x128 /
 // 2-workgroups-per-CU form keeps more CUs busy.
-int conv_pick_igemm_cfg(int M, int Npad) {
+int conv_pick_igemm_cfg(int M, int Npad, int taps) {
   const int tm256 = (M + 255) / 256;
   if (Npad % 128 != 0) return kCfgIgemm128x64;
-  if (Npad % 256 == 0 && tm256 * (Npad / 256) >= 160) return kCfgIgemm256;
+  if (Npad % 256 == 0 && tm256 * (Npad / 256) >= 160) return (taps > 1 && Npad <= 512) ? kCfgIgemm256TapsInner : kCfgIgemm256;
   // many rounds of small tiles (conv2_x): issuing a tile's LDS-DMA pieces early in the stage wins a few per cent
   return ((M + 127) / 128) * (Npad / 128) >= 2048 ? kCfgIgemm128Early : kCfgIgemm128;
 }
@@ -477,13 +497,14 @@ int conv_pick_cfg(const ConvLaunch& c) {
     const int cfg = conv_patch_pick(c);
     if (cfg >= 0) return cfg;
   }
-  return conv_pick_igemm_cfg(M, c.Npad);
+  return conv_pick_igemm_cfg(M, c.Npad, c.kh * c.kw);
 }
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg(c);
   RON_REQUIRE(cfg >= 0 && cfg < kNumCfgsBuilt, "conv: tile config %d out of range [0, %d)", cfg, kNumCfgsBuilt);
   if (conv_cfg_is_patch(cfg)) return launch_conv_patch(c, cfg, stream);
+  RON_REQUIRE(cfg != kCfgIgemm256TapsInner || c.up == 0, "conv: the taps-innermost order is for plain convolutions");
   const int esz = (int)dtype_size(c.dtype);
   const int chunk = conv_k_chunk(c.dtype);
   RON_REQUIRE(c.in.C % chunk == 0, "conv: Cin %d is not a multiple of the K chunk %d", c.in.C, chunk);

@@ -16,7 +16,7 @@ bad = 0
 for cfg in cfgs:
     for dtype, rnd, eps in (('bf16', orf.round_bf16, 2 ** -7 * 1.5), ('fp32', lambda a: a, 3e-5)):
         for (n, h, w, cin, cout, k, st, splitk) in ((3, 13, 11, 128, 192, 3, 1, -1), (2, 9, 9, 64, 256, 1, 1, -1), (2, 10, 10, 128, 256, 3, 1, 1),
-                                                    (2, 20, 20, 192, 512, 3, 1, 1), (2, 5, 5, 256, 256, 3, 1, 3), (2, 10, 10, 128, 128, 2, 2, 1)):
+                                                    (2, 20, 20, 192, 512, 3, 1, 1), (2, 5, 5, 256, 256, 3, 1, 3), (2, 10, 10, 128, 256, 2, 2, 1), (1, 10, 10, 64, 256, 7, 1, 2)):
             rs = np.random.RandomState(cfg + n + h)
             x = rs.randn(n, h, w, cin).astype(np.float32)
             wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
