@@ -424,10 +424,24 @@ int make_anchors_ssd(ron_ctx* c) {
 // are time-neutral and only save launches).  Every braced set below only reads what earlier entries wrote, and its
 // members write disjoint tensors / channel slices.
 void plan_groups(ron_ctx* c) {
-  if (c->is_ssd() || (c->cfg.flags & (RON_CFG_MULTI_STREAM | RON_CFG_NO_GROUPS))) return;
+  if (c->cfg.flags & (RON_CFG_MULTI_STREAM | RON_CFG_NO_GROUPS)) return;
   struct Slot { int cfg; std::vector<const char*> names; };     // cfg < 0: launches of their own
   const int T64 = kCfgIgemm128x64, T128 = kCfgIgemm128;     // tiny convolutions / medium ones (Npad % 128 == 0)
-  const std::vector<Slot> order = {
+  // SSD-512 (nets/ssd_vgg_512.py:395-458): blocks 8-12 are a chain of 1x1 -> 3x3 stride-2 convolutions on 16x16 ... 1x1 maps,
+  // each a 13-20 us launch at batch 16; the two box convolutions of a block only need that block's output, so they share a
+  // launch with the next block's 1x1 (20 small launches -> 11).  The block4 / block7 heads are real work and stay alone.
+  const std::vector<Slot> ssd_order = {
+      {-1, {"conv6"}}, {-1, {"conv7"}},
+      {-1, {"block8_conv1x1"}}, {-1, {"block8_conv3x3"}},
+      {T64, {"block8_box_conv_loc", "block8_box_conv_cls", "block9_conv1x1"}}, {-1, {"block9_conv3x3"}},
+      {T64, {"block9_box_conv_loc", "block9_box_conv_cls", "block10_conv1x1"}}, {-1, {"block10_conv3x3"}},
+      {T64, {"block10_box_conv_loc", "block10_box_conv_cls", "block11_conv1x1"}}, {-1, {"block11_conv3x3"}},
+      {T64, {"block11_box_conv_loc", "block11_box_conv_cls", "block12_conv1x1"}}, {-1, {"block12_conv4x4"}},
+      {T64, {"block12_box_conv_loc", "block12_box_conv_cls"}},
+      {-1, {"block4_l2norm"}}, {-1, {"block4_box_conv_loc"}}, {-1, {"block4_box_conv_cls"}},
+      {-1, {"block7_box_conv_loc"}}, {-1, {"block7_box_conv_cls"}},
+  };
+  const std::vector<Slot> ron_order = {
       {-1, {"block7_conv_left"}},
       {T64, {"block7_trio3", "block7_inception1_1x1", "block6_deconv_right"}},
       {-1, {"block6_conv_left"}},
@@ -449,6 +463,7 @@ void plan_groups(ron_ctx* c) {
       {-1, {"block4_loc_pred"}},
       {-1, {"block4_cls_pred"}},
   };
+  const std::vector<Slot>& order = c->is_ssd() ? ssd_order : ron_order;
   std::map<std::string, int> at;
   for (size_t i = 0; i < c->ops.size(); ++i) at[c->ops[i].name] = (int)i;
   size_t first_head = c->ops.size(), n_named = 0;
