@@ -120,3 +120,69 @@ def test_bf16_vs_fp32_oracle_agreement(run):
     # the bf16-rounded ORACLE reproduces 98 % of the fp32 oracle's detections on these images (max score diff 3e-3, box 9e-4)
     assert min(a['reproduced'] for a in rates) >= 0.90
     assert max(a['max_score_diff'] for a in rates) <= 0.02 and max(a['max_box_diff'] for a in rates) <= 0.01
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs 4 and 5 at the sizes bench.py runs them
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config4_reducedfc_fp16_batch64_vs_oracle():
+    """Config 4: ron_net_reducedfc (nets/ron_vgg_320.py:510-580), fp16, batch 64, fused pools / stem, grouped heads, two slots:
+    head tensors and end points of two images vs the fp16-rounded oracle; records of both slots identical."""
+    from ron_tensorflow_amd import weights as W
+    from ron_tensorflow_amd.nets import nets_factory
+    from ron_tensorflow_amd.pipeline import DetectPipeline
+    weights = W.synthetic_weights('reducedfc', seed=1)
+    images = W.synthetic_images(64, seed=3)
+    net = nets_factory.get_network('ron_320_vgg')(variant='reducedfc', dtype='fp16', max_batch=64, fuse_pools=True)
+    net.load_weights(weights)
+    x = torch.from_numpy(images).cuda()
+    pipe = DetectPipeline(net, slots=2, top_k=400)
+    dets = [t.wait().to_lists() for t in [pipe.submit(x) for _ in range(2)]]
+    torch.cuda.synchronize()
+    for a, b in zip(dets[0], dets[1]):
+        assert np.array_equal(a['anchor_index'], b['anchor_index']) and np.array_equal(a['scores'], b['scores'])
+    cls, obj, loc = net.forward_heads(x)
+    for i in (5, 63):
+        col = {}
+        o = orf.ron_forward(images[i:i + 1], weights, 'reducedfc', backend='torch', round_fn=orf.round_f16, collect=col)
+        col.update(o[5])
+        for l in range(4):
+            assert _rel(cls[l][i:i + 1].cpu().numpy(), o[1][l]) < 0.006, ('cls', l, i)
+            assert _rel(obj[l][i:i + 1].cpu().numpy(), o[3][l]) < 0.006, ('obj', l, i)
+            assert _rel(loc[l][i:i + 1].cpu().numpy(), o[4][l]) < 0.006, ('loc', l, i)
+        for name in ('pool1', 'block4', 'block6', 'block7', 'block5_ref'):
+            assert _rel(net.end_point(name, 64).cpu().numpy()[i:i + 1], col[name]) < 0.006, (name, i)
+    pipe.close()
+    net.close()
+
+
+def test_config5_ssd512_bf16_batch16_vs_oracle():
+    """Config 5: SSD-512 (nets/ssd_vgg_512.py:364-460), bf16, batch 16, fused pools / stem, grouped box convolutions: head
+    tensors of two images vs the bf16-rounded oracle, detections vs the oracle's np_methods pipeline on the same heads."""
+    from oracle import ssd_forward as osf
+    from ron_tensorflow_amd import weights as W
+    from ron_tensorflow_amd.nets import nets_factory
+    weights = W.ssd_synthetic_weights(seed=5)
+    images = W.synthetic_images(16, seed=3, img_shape=(512, 512))
+    cls_ = nets_factory.get_network('ssd_512_vgg')
+    net = cls_(cls_.default_params._replace(num_classes=21), dtype='bf16', max_batch=16, fuse_pools=True).load_weights(weights)
+    x = torch.from_numpy(images).cuda()
+    logits, _, loc = net.forward_heads(x)
+    det = net.detect(x, select_threshold=0.01, nms_threshold=0.45).to_lists()
+    anchors = osf.anchors_all_layers()
+    for i in (0, 15):
+        ref = osf.ssd_forward(images[i:i + 1], weights, round_fn=orf.round_bf16, backend='torch')
+        for l in range(7):
+            assert _rel(logits[l][i:i + 1].cpu().numpy(), ref[2][l]) < 0.05, ('cls', l, i)
+            assert _rel(loc[l][i:i + 1].cpu().numpy(), ref[1][l]) < 0.08, ('loc', l, i)
+        # probabilities from the device softmax kernel (bit-identical to the one fused into the select kernel: numpy's may
+        # differ in the last bit, which reorders near-ties among thousands of candidates)
+        from ron_tensorflow_amd import ops
+        pred = [ops.softmax_last(t[i:i + 1]).cpu().numpy() for t in logits]
+        want = np_post.detect_from_predictions(pred, [t[i:i + 1].cpu().numpy() for t in loc], anchors, objness_pred=None,
+                                               prior_scaling=net.params.prior_scaling)[0]
+        g = det[i]
+        assert np.array_equal(g['classes'], want['classes']) and np.array_equal(g['anchor_index'], want['anchor_index'])
+        assert np.array_equal(g['scores'], want['scores'])
+        assert np.abs(g['bboxes'] - want['bboxes']).max() <= 1e-5
+    net.close()
