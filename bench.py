@@ -57,9 +57,10 @@ def parse():
                          'ron_tensorflow_amd/pipeline.py).  1 = strictly one launch at a time: per-launch durations are then '
                          "each kernel's alone, which is what profiles/*/kernel_stats are taken with")
     ap.add_argument('--layers', default='', help='write the per-launch timing table to this file')
-    ap.add_argument('--check-gather', action='store_true',
-                    help='under torch.distributed.run: after the timed region every rank compares the all-gathered records with '
-                         'its own local ones (and rank 0 the other ranks\' counts); the JSON line gets "gather_check"')
+    ap.add_argument('--check-gather', action='store_true', default=True,
+                    help='under torch.distributed.run (default on): after the timed region every rank compares the all-gathered '
+                         'records with its own local ones and checks every rank\'s counts; the JSON line gets "gather_check"')
+    ap.add_argument('--no-check-gather', dest='check_gather', action='store_false')
     return ap.parse_args()
 
 
