@@ -77,8 +77,10 @@ enum {
   kExpIgemm128A3 = 17,     // row-gather 128 x 128 with three activation stages (80 KB: still two workgroups per CU)
   kExpIgemm256A3Early = 18,
   kExpIgemm256NtA = 19,    // row-gather 256 x 256 with non-temporal activation loads (the weights keep the L2)
+  kExpIgemm256W4 = 20,     // row-gather 256 x 256 on 4 waves of 128 x 128 (a third fewer LDS fragment reads, one wave per SIMD)
+  kExpIgemm256W2x4 = 21,   // row-gather 256 x 256 on 2 x 4 waves of 128 x 64 (the shipped one is 4 x 2 of 64 x 128)
 #ifdef RON_EXP
-  kNumCfgsBuilt = 20
+  kNumCfgsBuilt = 22
 #else
   kNumCfgsBuilt = kNumCfgs
 #endif

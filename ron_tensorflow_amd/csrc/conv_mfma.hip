@@ -438,6 +438,8 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case kExpIgemm256Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0>(a, s);
     case kExpIgemm128A3: return launch_t<Tr, 128, 128, 2, 2, 2, 1, 0, 3>(a, s);
     case kExpIgemm256A3Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0, 3>(a, s);
+    case kExpIgemm256W4: return launch_t<Tr, 256, 256, 2, 2, 2, 1>(a, s);
+    case kExpIgemm256W2x4: return launch_t<Tr, 256, 256, 2, 4, 2, 1>(a, s);
 #endif
   }
   ron::set_error("conv: unknown tile config %d", cfg);
@@ -463,7 +465,7 @@ int conv_num_cfgs() { return kNumCfgsBuilt; }
 
 static bool igemm_is256(int cfg) {
   return cfg == kCfgIgemm256 || cfg == kCfgIgemm256TapsInner || (cfg >= kExpIgemm256NoA && cfg <= kExpIgemm256Early) ||
-         cfg == kExpIgemm256A3Early || cfg == kExpIgemm256NtA;
+         cfg == kExpIgemm256A3Early || cfg == kExpIgemm256NtA || cfg == kExpIgemm256W4 || cfg == kExpIgemm256W2x4;
 }
 static int igemm_bm(int cfg) { return igemm_is256(cfg) ? 256 : 128; }
 static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : (cfg == kCfgIgemm128x64 ? 64 : 128); }
