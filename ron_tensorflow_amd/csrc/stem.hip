@@ -153,20 +153,21 @@ constexpr int kS2W2Bytes = 9 * 64 * 128;                                        
 constexpr int kS2PatchBytes = kS2Rows * 128;
 constexpr int kS2ImgFloats = kS2IH * kS2IW * 3;
 constexpr int kS2PoolBytes = 8 * 16 * 128;
-constexpr int kS2Lds = kS2W2Bytes + kS2PatchBytes + kS2ImgFloats * 4 + kS2PoolBytes;
+constexpr int kS2DumpBytes = 512;                                                   // where the stores of lanes past the patch go
+constexpr int kS2Lds = kS2W2Bytes + kS2PatchBytes + kS2ImgFloats * 4 + kS2PoolBytes + kS2DumpBytes;
 
 template <class Tr>
 __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x, int n_img, int H, int W,
                                                     const u32x4* __restrict__ w1frag, const float* __restrict__ bias1,
                                                     const u32x4* __restrict__ w2img, const float* __restrict__ bias2,
-                                                    unsigned short* __restrict__ out, int out_Hp, int out_Wp, int out_pad,
-                                                    int abl) {
-  // abl (diagnostic, RON_STEM2_ABL): 1 = skip conv1_1 (phase B), 2 = skip the tap loop (phase C), 4 = skip pooling / stores
+                                                    unsigned short* __restrict__ out, int out_Hp, int out_Wp, int out_pad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_w2 = smem;
   char* s_p = s_w2 + kS2W2Bytes;
-  float* s_img = reinterpret_cast<float*>(s_p + kS2PatchBytes);
+  float* s_img = reinterpret_cast<float*>(s_p + kS2PatchBytes + kS2DumpBytes);   // the dump area sits behind the patch
   char* s_pool = reinterpret_cast<char*>(s_img + kS2ImgFloats);
+  constexpr unsigned kDumpOff = (unsigned)kS2PatchBytes;             // relative to s_p
+  static_assert(kDumpOff + kS2DumpBytes <= 0xFFFFu, "store offsets are 16 bits");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
@@ -188,12 +189,15 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
   for (int j = 0; j < 8; ++j) {
     const int k = 8 * kg + j;
     const int ty = k / 9, rem = k - ty * 9;
-    a_off[j] = k < 27 ? ty * (kS2IW * 3) + rem : -1;               // rem = tx*3 + c
+    a_off[j] = k < 27 ? ty * (kS2IW * 3) + rem : 0;                // rem = tx*3 + c; k >= 27: any address, the value is dropped
   }
+  const bool k_pad = kg == 3;                                       // this lane's elements j >= 3 are K padding (k = 27 .. 31)
   // phase B bookkeeping is the same for every tile: this wave's (up to three) groups of 16 patch pixels, the gather base of the
   // lane's pixel, and per accumulator register the LDS store offset + patch coordinates of the pixel it holds
-  // (bits 0-15 offset, 16-19 patch row, 20-25 patch column, 31 = past the patch)
-  constexpr int kGroups16 = (kS2Rows + 15) / 16;                    // 22
+  // (bits 0-15 offset, 16-19 patch row, 20-25 patch column).  No branches in phase B: the groups past the patch (22 groups
+  // of 16 over 8 waves x 3) and the pixels past its end compute like the others and store into a dump area, so the three
+  // groups of a wave are straight-line code the compiler interleaves.
+  static_assert((kS2Rows + 15) / 16 <= 3 * 8, "8 waves x 3 groups of 16 cover the patch");
   int gb[3];
   unsigned st[3][4];
 #pragma unroll
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
       const int qq = g * 16 + 4 * kg + e;
       const int qy = qq / kS2PW, qx = qq - qy * kS2PW;
       const unsigned off = (unsigned)(qq * 128 + ((((c16 >> 1) ^ ((qq >> 1) & 7))) << 4) + (c16 & 1) * 8);
-      st[gi][e] = qq < kS2Rows ? (off | ((unsigned)qy << 16) | ((unsigned)qx << 20)) : 0x80000000u;
+      st[gi][e] = qq < kS2Rows ? (off | ((unsigned)qy << 16) | ((unsigned)qx << 20)) : (kDumpOff + (unsigned)lane * 8u);
     }
   }
   const int tiles_x = W / kS2TW, tiles_y = H / kS2TH;
@@ -224,12 +228,14 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
   float pre[kImgPer];
 #define RON_S2_FETCH(tile_)                                                                                   \
   do {                                                                                                        \
-    const int t_ = (tile_);                                                                                   \
+    const int t_ = min((tile_), n_tiles - 1);      /* past the last tile: fetched again, never used */        \
     const int fx = t_ % tiles_x, fy = (t_ / tiles_x) % tiles_y, fimg = t_ / (tiles_x * tiles_y);              \
     _Pragma("unroll") for (int k = 0; k < kImgPer; ++k) {                                                     \
       const int yy = fy * kS2TH - 2 + i_iy[k], xc = (fx * kS2TW - 2) * 3 + i_ix[k];                           \
-      pre[k] = (t_ < n_tiles && yy >= 0 && yy < H && xc >= 0 && xc < W * 3)                                   \
-                   ? x[((long long)fimg * H + yy) * W * 3 + xc] : 0.f;                                        \
+      const int yc = min(max(yy, 0), H - 1), xcc = min(max(xc, 0), W * 3 - 1);   /* unconditional load */      \
+      const float v_ = x[((long long)fimg * H + yc) * W * 3 + xcc];                                           \
+      /* a bit mask, not a select: hipcc turns the select back into a branch around the load */               \
+      pre[k] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v_) & (unsigned)-(int)(yy == yc && xc == xcc)); \
     }                                                                                                         \
   } while (0)
 #define RON_S2_STORE()                                                                                        \
@@ -249,11 +255,13 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
     // ---- B: conv1_1 of the 340 patch pixels, 32 at a time
 #pragma unroll
     for (int gi = 0; gi < 3; ++gi) {
-      if (wave + 8 * gi >= kGroups16 || (abl & 1)) break;              // wave-uniform
       const float* base = s_img + gb[gi];
       unsigned short ev[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ev[j] = Tr::cvt(a_off[j] >= 0 ? base[a_off[j]] : 0.f);
+      for (int j = 0; j < 8; ++j) {
+        const float g = base[a_off[j]];
+        ev[j] = Tr::cvt(j >= 3 && k_pad ? 0.f : g);
+      }
       const u32x4 fa = u32x4{(unsigned)ev[0] | ((unsigned)ev[1] << 16), (unsigned)ev[2] | ((unsigned)ev[3] << 16),
                              (unsigned)ev[4] | ((unsigned)ev[5] << 16), (unsigned)ev[6] | ((unsigned)ev[7] << 16)};
       f32x4 acc[4];
@@ -265,13 +273,12 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const unsigned m = st[gi][e];
-        if (m & 0x80000000u) continue;
         const int iy = y0 - 1 + (int)((m >> 16) & 15u), ix = x0 - 1 + (int)((m >> 20) & 63u);
-        const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const unsigned inside = (unsigned)-(int)((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W);   // mask (no branch)
         unsigned v[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = Tr::cvt(inside ? fmaxf(acc[t][e] + b1[t], 0.f) : 0.f);
-        *reinterpret_cast<u32x2*>(s_p + (m & 0xFFFFu)) = u32x2{v[0] | (v[1] << 16), v[2] | (v[3] << 16)};
+        for (int t = 0; t < 4; ++t) v[t] = Tr::cvt(fmaxf(acc[t][e] + b1[t], 0.f));
+        *reinterpret_cast<u32x2*>(s_p + (m & 0xFFFFu)) = u32x2{(v[0] | (v[1] << 16)) & inside, (v[2] | (v[3] << 16)) & inside};
       }
     }
     __syncthreads();
@@ -285,7 +292,6 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
     const int key_b = (r >> 1) & 7;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      if (abl & 2) break;
       const int prow = (wave + tap / 3) * kS2PW + r + tap % 3;
       const char* pa = s_p + prow * 128;
       const int key_a = (prow >> 1) & 7;
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
         *reinterpret_cast<unsigned*>(s_pool + (wave * 16 + m) * 128 + r * 4) = (unsigned)Tr::cvt(m0) | ((unsigned)Tr::cvt(m1) << 16);
       }
     __syncthreads();
-    if (!(abl & 4)) {
+    {
       const int yp = tid >> 7, m = (tid >> 3) & 15, c8 = tid & 7;     // 4 pooled rows x 16 columns x 8 chunks of 8 channels
       const u32x4 a = *reinterpret_cast<const u32x4*>(s_pool + ((2 * yp) * 16 + m) * 128 + c8 * 16);
       const u32x4 b = *reinterpret_cast<const u32x4*>(s_pool + ((2 * yp + 1) * 16 + m) * 128 + c8 * 16);
@@ -403,7 +409,6 @@ int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w
               "stem2 kernel: bad shape");
   const int tiles = n * (h / kS2TH) * (w / kS2TW);
   const int grid = std::min(tiles, 256);
-  const int abl = 0;        // phase-skipping diagnostics of round 1 (kernel argument kept: 1 = no conv1_1, 2 = no tap loop, 4 = no stores)
   static PerDeviceOnce attr_set[2];                // the attribute is per device (common.h)
   const int which = dtype == RON_DTYPE_BF16 ? 0 : 1;
   if (attr_set[which].first()) {
@@ -412,10 +417,10 @@ int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w
   }
   if (which == 0)
     hipLaunchKernelGGL(stem2_kernel<StemBF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
-                       (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad, abl);
+                       (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad);
   else
     hipLaunchKernelGGL(stem2_kernel<StemF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
-                       (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad, abl);
+                       (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
