@@ -1,0 +1,285 @@
+// 3x3 / stride 1 / pad 1 convolution of a 64-channel map with the weights RESIDENT in LDS (gfx950, bf16 / f16).
+//
+// Cin = 64 means K = 576: nine K steps.  The row-gather kernel (conv_mfma.hip) re-stages 16 KB of weights per step and tile for
+// that little work and spends a third of a tile's time filling and draining its pipeline (conv2_1 at batch 32: 175 us,
+// 0.69 PFLOP/s, the L2 -> LDS path of a CU at the rate the wide layers reach with twice the arithmetic per byte).  Here the
+// loop of stem2_kernel's conv1_2 phase (stem.hip) is its own kernel:
+//   * a persistent workgroup owns one 64-channel slice of the outputs ("half": Cout / 64 of them) and keeps that slice's nine
+//     taps (72 KB, the exact LDS image packed by pack_conv_c64_weights) in LDS for its whole life;
+//   * per 8 x 32 pixel tile it stages the 10 x 34 x 64-channel input patch once (LDS-DMA, 43 KB, double buffered: the next
+//     tile's patch is in flight during this tile's taps) and runs the nine taps against it - a tap is an LDS address shift;
+//   * wave w owns tile row w: a fragment's 32 rows are 32 consecutive patch rows, conflict-free ds_read_b128 for every tap
+//     shift with the 32x32x16 MFMA and the (row >> 1) & 7 chunk swizzle (the LDS-DMA applies it on the source address);
+//   * one barrier per tile;
+//   * epilogue: + bias, ReLU, a lane holds two adjacent channels of 16 pixels: 4-byte stores, 32 lanes = one 128-B line.  The
+//     stores of tile t go out between the MFMAs of tile t+1, one per K step: the layer writes 210 MB at batch 32, and with every
+//     workgroup storing its tile at the same moment between two tap loops nothing computed while HBM took the burst (stores
+//     alone 36 us, patch staging alone 31 us, both 75 us of a 113 us launch: RON_C64_ABL in the experimental build);
+//   * a wave's vmcnt counts loads and stores, which do not retire in order with respect to each other: the one wait per tile
+//     (after the taps) is for everything - the next patch and the previous tile's stores, both issued a tap loop earlier.
+// The workgroups of the halves of one tile sequence share an XCD (they stage the same patches: the second read hits L2).
+// Activations: zero-halo NHWC (conv_mfma.h TensorView), so a patch never needs a bounds check.
+#include "conv_device.h"
+#include <stdlib.h>
+
+#include "pack.h"
+
+namespace ron {
+namespace detail {
+
+constexpr int kC6TH = 8, kC6TW = 32;
+constexpr int kC6PW = kC6TW + 2, kC6PH = kC6TH + 2, kC6Rows = kC6PW * kC6PH;     // 34 x 10 = 340 patch rows of 128 B
+constexpr int kC6Pieces = (kC6Rows * 128 + 1023) / 1024;                         // 43 wave-instructions of 1 KB
+constexpr int kC6PatchBytes = kC6Pieces * 1024;                                  // 44032: 340 rows + 4 rows of overshoot
+constexpr int kC6WBytes = 9 * 64 * 128;                                          // 72 KB
+constexpr int kC6Lds = kC6WBytes + 2 * kC6PatchBytes;                            // 161 792 of 163 840
+constexpr int kC6PiecesPerWave = (kC6Pieces + 7) / 8;                            // 6 (waves 0-2), 5 (waves 3-7)
+
+struct C64Args {
+  const void* in;
+  unsigned in_bytes;
+  int in_Hp, in_Wp, in_pad;
+  const u32x4* wimg;          // [halves][9 taps][64 rows][128 B]
+  const float* bias;
+  unsigned short* out;
+  unsigned out_bytes;
+  int out_Hp, out_Wp, out_pad, out_cstride, out_coff;
+  int n_img, H, W, halves, relu;
+  int n_slots;                // tile sequences (a multiple of 8): grid = n_slots * halves
+  int abl;                    // experimental builds only (RON_C64_ABL): 1 = no patch staging after the first, 2 = no taps, 4 = no stores
+};
+#ifdef RON_EXP
+#define RON_C64_ABL(bit_) (p.abl & (bit_))
+#else
+#define RON_C64_ABL(bit_) 0
+#endif
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_c64;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_c64;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_c64;
+// two fp32 -> one dword of two storage-type values (round to nearest even), low half = first argument
+struct C64BF16 : TraitsBF16 {
+  static __device__ __forceinline__ unsigned cvt2(float a, float b) {      // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_c64{a, b}, bf16x2_c64));
+  }
+};
+struct C64F16 : TraitsF16 {
+  static __device__ __forceinline__ unsigned cvt2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_c64{a, b}, f16x2_c64));
+  }
+};
+
+template <class Tr>
+__global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_w = smem;
+  char* s_p = smem + kC6WBytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  // workgroup -> (half, tile sequence): the halves of a sequence are neighbours on one XCD (blockIdx % 8)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int half = idx % p.halves;
+  const int slot = (idx / p.halves) * 8 + xcd;
+  const int tiles_x = p.W / kC6TW, tiles_y = p.H / kC6TH;
+  const int n_tiles = p.n_img * tiles_y * tiles_x;
+
+  // LDS-DMA pieces of a patch: piece i (1 KB = 8 patch rows) is issued by wave i % 8; lane -> (row 8i + lane / 8, slot lane % 8),
+  // source chunk = slot ^ key(row).  Offsets relative to the tile's first patch pixel; rows past the patch re-read its last row.
+  int voff[kC6PiecesPerWave];
+#pragma unroll
+  for (int k = 0; k < kC6PiecesPerWave; ++k) {
+    const int q = min((wave + 8 * k) * 8 + (lane >> 3), kC6Rows - 1);
+    const int chunk = (lane & 7) ^ ((q >> 1) & 7);
+    voff[k] = ((q / kC6PW) * p.in_Wp + q % kC6PW) * 128 + chunk * 16;
+  }
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+#define RON_C64_STAGE(tile_, buf_)                                                                                    \
+  do {                                                                                                                \
+    const int t_ = (tile_);                                                                                           \
+    const int fx = t_ % tiles_x, fy = (t_ / tiles_x) % tiles_y, fimg = t_ / (tiles_x * tiles_y);                      \
+    /* patch row 0 = input pixel (y0 - 1, x0 - 1) */                                                                  \
+    const int soff = ((fimg * p.in_Hp + p.in_pad + fy * kC6TH - 1) * p.in_Wp + p.in_pad + fx * kC6TW - 1) * 128;      \
+    char* dst_ = s_p + (buf_) * kC6PatchBytes + wave * 1024;                                                          \
+    _Pragma("unroll") for (int k = 0; k < kC6PiecesPerWave; ++k)                                                      \
+      if (wave + 8 * k < kC6Pieces)                                                                                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst_ + k * 8192), 16, voff[k], soff, 0, 0);          \
+  } while (0)
+
+  if (slot < n_tiles) RON_C64_STAGE(slot, 0);
+  // this half's weights: the host packed the exact LDS image
+  {
+    const u32x4* wsrc = p.wimg + (size_t)half * (kC6WBytes / 16);
+    for (int i = tid; i < kC6WBytes / 16; i += 512) reinterpret_cast<u32x4*>(s_w)[i] = wsrc[i];
+  }
+  const int n0 = half * 64;
+  const float b0 = p.bias[n0 + 2 * r], b1 = p.bias[n0 + 2 * r + 1];
+  const int key_b = (r >> 1) & 7;
+  // stores: buffer addressing, per-lane offset fixed for the life of the workgroup (pixel 4h of a row, channels n0 + 2r, 2r + 1),
+  // the tile / accumulator-register part is a scalar offset: no address arithmetic per store
+  const int st_voff = (4 * h * p.out_cstride + p.out_coff + n0 + 2 * r) * 2;
+  const int st_row = __builtin_amdgcn_readfirstlane(wave) * p.out_Wp * p.out_cstride * 2;
+  const float lo = p.relu ? 0.f : -__builtin_huge_valf();
+  // the previous tile's accumulators and where they go; before the first tile: a descriptor without records (stores dropped)
+  f32x16 prev[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) prev[t][e] = 0.f;
+  int prev_off = 0;
+  unsigned prev_records = 0;
+#define RON_C64_STORE(e_)                                                                                             \
+  do {                                                                                                                \
+    if (RON_C64_ABL(4)) break;                                                                                        \
+    const int m_ = ((e_) & 3) + 8 * ((e_) >> 2);          /* + 4h: pixel of the row this accumulator register holds */  \
+    const float v0_ = fmaxf(prev[0][e_] + b0, lo), v1_ = fmaxf(prev[1][e_] + b1, lo);                                 \
+    __builtin_amdgcn_raw_buffer_store_b32(Tr::cvt2(v0_, v1_), rs_st, st_voff, prev_off + m_ * p.out_cstride * 2, 0);  \
+  } while (0)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // first patch + the weight image (ds_write) of this wave
+
+#ifdef RON_EXP   // RON_C64_ABL & 8: where a wave's cycles go (barrier / taps / the wait / the rest), printed by two workgroups
+  unsigned long long t_bar = 0, t_taps = 0, t_wait = 0, t_rest = 0, c0 = __builtin_readcyclecounter();
+  int n_done = 0;
+#define RON_C64_T(acc_) do { const unsigned long long c1_ = __builtin_readcyclecounter(); acc_ += c1_ - c0; c0 = c1_; } while (0)
+#else
+#define RON_C64_T(acc_) do {} while (0)
+#endif
+  int buf = 0;
+  for (int tile = slot; tile < n_tiles; tile += p.n_slots, buf ^= 1) {
+    // every wave's pieces of this tile's patch have landed (each waited for its own before it got here), and nobody reads the
+    // other buffer any more.  A raw barrier: __syncthreads() would also wait for the previous tile's stores.
+    __builtin_amdgcn_s_barrier();
+    RON_C64_T(t_bar);
+    if (tile + p.n_slots < n_tiles && !RON_C64_ABL(1)) RON_C64_STAGE(tile + p.n_slots, buf ^ 1);
+    const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, prev_records, 0x00020000);
+    const char* sp = s_p + buf * kC6PatchBytes;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    // 36 k-steps (9 taps x 4 groups of 16 input channels), two MFMAs each.  The fragments of step i + 3 are read while step i
+    // multiplies (a ring of four register sets): left to itself hipcc reads each fragment right before the MFMA that needs it
+    // and every MFMA waits out an LDS round trip.  One of the previous tile's sixteen stores goes out behind each of the steps
+    // 2 .. 17 (early: the wait below is for them too).
+    u32x4 fa[4], fb0[4], fb1[4];
+    auto frag_read = [&](int i) {
+      const int tap = i >> 2, ks = i & 3, j = i & 3;
+      const int prow = (wave + tap / 3) * kC6PW + r + tap % 3;
+      const int key_a = (prow >> 1) & 7;
+      const char* pb = s_w + tap * 8192 + r * 128 + (((2 * ks + h) ^ key_b) << 4);
+      fa[j] = *reinterpret_cast<const u32x4*>(sp + prow * 128 + (((2 * ks + h) ^ key_a) << 4));
+      fb0[j] = *reinterpret_cast<const u32x4*>(pb);
+      fb1[j] = *reinterpret_cast<const u32x4*>(pb + 32 * 128);
+    };
+    if (!RON_C64_ABL(2)) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) frag_read(i);
+#pragma unroll
+      for (int i = 0; i < 36; ++i) {
+        if (i + 3 < 36) frag_read(i + 3);
+        Tr::mma(fa[i & 3], fb0[i & 3], acc[0]);
+        Tr::mma(fa[i & 3], fb1[i & 3], acc[1]);
+        if (i >= 2 && i < 18) RON_C64_STORE(i >= 2 && i < 18 ? i - 2 : 0);
+      }
+      // pin that order
+      __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+      for (int i = 0; i < 36; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i + 3 < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i + 3 < 36) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i >= 2 && i < 18) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+      }
+    }
+    // this wave's pieces of the next patch (and the stores above) are done
+    RON_C64_T(t_taps);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RON_C64_T(t_wait);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
+    prev_off = ((img * p.out_Hp + p.out_pad + ty * kC6TH) * p.out_Wp + p.out_pad + tx * kC6TW) * p.out_cstride * 2 + st_row;   // bytes
+    prev_records = p.out_bytes;
+    prev[0] = acc[0]; prev[1] = acc[1];
+#ifdef RON_EXP
+    RON_C64_T(t_rest);
+    ++n_done;
+#endif
+  }
+#ifdef RON_EXP
+  if ((p.abl & 8) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 101) && (wave == 0 || wave == 7))
+    printf("c64 wg %d wave %d: %d tiles, cycles per tile: barrier %llu taps %llu wait %llu rest %llu\n", (int)blockIdx.x, wave, n_done,
+           t_bar / n_done, t_taps / n_done, t_wait / n_done, t_rest / n_done);
+#endif
+  {   // the last tile's stores (no records if this workgroup had no tile)
+    const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, prev_records, 0x00020000);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) RON_C64_STORE(e);
+  }
+#undef RON_C64_STORE
+#undef RON_C64_STAGE
+}
+
+template <class Tr>
+int launch_c64_t(const C64Args& a, hipStream_t s) {
+  static PerDeviceOnce once;
+  if (once.first())
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<Tr>), hipFuncAttributeMaxDynamicSharedMemorySize, kC6Lds));
+  hipLaunchKernelGGL(conv3x3_c64_kernel<Tr>, dim3(a.n_slots * a.halves), dim3(512), kC6Lds, s, a);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+}  // namespace detail
+using namespace detail;
+
+// LDS images for conv3x3_c64_kernel from fp32 rows [npad][K = 9 * 64] (row n, k = tap * 64 + cin): per 64-channel half, tap-major,
+// row (j * 32 + r) of a tap holds output channel 64 * half + 2r + j, its 64 input channels as 8 chunks of 16 B, chunk c in slot
+// c ^ ((row >> 1) & 7).
+std::vector<uint8_t> pack_conv_c64_weights(const std::vector<float>& rows, int npad, int dtype) {
+  const int halves = npad / 64;
+  std::vector<uint16_t> img((size_t)halves * 9 * 64 * 64, 0);
+  for (int hf = 0; hf < halves; ++hf)
+    for (int tap = 0; tap < 9; ++tap)
+      for (int row = 0; row < 64; ++row) {
+        const int j = row / 32, r = row % 32, ch = 64 * hf + 2 * r + j;
+        for (int cin = 0; cin < 64; ++cin) {
+          const float v = rows[(size_t)ch * 576 + tap * 64 + cin];
+          const int chunk = cin / 8, slot = chunk ^ ((row >> 1) & 7);
+          img[(((size_t)hf * 9 + tap) * 64 + row) * 64 + slot * 8 + cin % 8] = dtype == RON_DTYPE_BF16 ? f32_to_bf16_rne(v) : f32_to_f16_rne(v);
+        }
+      }
+  std::vector<uint8_t> out(img.size() * 2);
+  memcpy(out.data(), img.data(), out.size());
+  return out;
+}
+
+bool conv_c64_applicable(const ConvLaunch& c) {
+  return c.wgt_c64 != nullptr && (c.dtype == RON_DTYPE_BF16 || c.dtype == RON_DTYPE_F16) && c.kh == 3 && c.kw == 3 && c.stride == 1 &&
+         c.dil == 1 && c.cpad == 1 && c.up == 0 && !c.pool && c.res == nullptr && !c.out_f32 && c.in.C == 64 && c.in.cstride == 64 &&
+         c.in.coff == 0 && c.in.pad >= 1 && c.Npad == c.Cout && c.Cout % 64 == 0 && (c.Cout / 64 == 1 || c.Cout / 64 == 2 || c.Cout / 64 == 4) &&
+         c.Ho % kC6TH == 0 && c.Wo % kC6TW == 0 && c.Ho == c.in.H && c.Wo == c.in.W && c.out.cstride % 2 == 0 && c.out.coff % 2 == 0;
+}
+
+int launch_conv_c64(const ConvLaunch& c, hipStream_t stream) {
+  RON_REQUIRE(conv_c64_applicable(c), "resident-weight kernel: 3x3 / stride 1 / pad 1 on a 64-channel bf16 / f16 map whose size the 8 x 32 tile "
+              "divides, 64 / 128 / 256 outputs, packed weight image present");
+  RON_REQUIRE(c.in.bytes > 0 && c.in.bytes < (int64_t)1 << 31 && c.out.bytes > 0 && c.out.bytes < (int64_t)1 << 31,
+              "resident-weight kernel: input and output allocations must be < 2 GiB for buffer addressing");
+  C64Args a;
+  a.in = c.in.base; a.in_bytes = (unsigned)c.in.bytes;
+  a.in_Hp = c.in.Hp(); a.in_Wp = c.in.Wp(); a.in_pad = c.in.pad;
+  a.wimg = (const u32x4*)c.wgt_c64; a.bias = c.bias;
+  a.out = (unsigned short*)c.out.base; a.out_bytes = (unsigned)c.out.bytes;
+  a.out_Hp = c.out.Hp(); a.out_Wp = c.out.Wp(); a.out_pad = c.out.pad; a.out_cstride = c.out.cstride; a.out_coff = c.out.coff;
+  a.n_img = c.in.N; a.H = c.Ho; a.W = c.Wo; a.halves = c.Cout / 64; a.relu = c.relu;
+  const int n_tiles = c.in.N * (c.Ho / kC6TH) * (c.Wo / kC6TW);
+  a.n_slots = std::min(256 / a.halves, (n_tiles + 7) / 8 * 8);
+  a.abl = 0;
+#ifdef RON_EXP
+  if (const char* e = getenv("RON_C64_ABL")) a.abl = atoi(e);
+#endif
+  if (c.dtype == RON_DTYPE_BF16) return launch_c64_t<C64BF16>(a, stream);
+  return launch_c64_t<C64F16>(a, stream);
+}
+
+}  // namespace ron

@@ -33,6 +33,7 @@ struct ConvLaunch {
   const void* res = nullptr;     // residual with the geometry of `out` (same dtype), or null
   const void* wgt = nullptr;     // packed [Npad][K] (K = kh*kw*Cin contiguous), dtype elements
   int64_t wgt_bytes = 0;
+  const void* wgt_c64 = nullptr; // the same weights as LDS images for the resident-weight kernel (conv_c64.hip), or null
   const float* bias = nullptr;   // [Npad] fp32 (never null; zeros when the layer has none)
   int Cout = 0;                  // GEMM N that is stored (<= Npad)
   int Npad = 0;                  // rows of wgt, multiple of the N tile
@@ -63,24 +64,25 @@ enum {
   kCfgPatch128 = 5,        // ... x 128 channels, 3 weight stages
   kCfgPatch64 = 6,         // ... x 64 channels, 3 weight stages
   kCfgIgemm256TapsInner = 7,   // 256 x 256 with K ordered chunk-major, taps innermost (layers with <= 2 column tiles)
-  kNumCfgs = 8,
+  kCfgC64Resident = 8,     // 3x3 on a 64-channel map with the weights resident in LDS (conv_c64.hip)
+  kNumCfgs = 9,
   // experimental builds only (make EXP=1 -> libron_hip_exp.so, tools/sweep_conv.py): timing variants, some with wrong results
-  kExpPatch128S4 = 8,      // halo-patch, 128 channels, 4 weight stages (three steps of lead)
-  kExpPatch256NoA = 9,     // halo-patch 256 without the patch traffic / without the weight traffic / without either
-  kExpPatch256NoB = 10,
-  kExpPatch256NoAB = 11,
-  kExpIgemm256NoA = 12,    // row-gather 256 x 256 likewise
-  kExpIgemm256NoB = 13,
-  kExpIgemm256NoAB = 14,
-  kExpIgemm256A3 = 15,     // row-gather 256 x 256 with three activation stages (+ two weight stages = all 160 KB of LDS)
-  kExpIgemm256Early = 16,  // row-gather 256 x 256 with all pieces of a stage issued during its first k-step
-  kExpIgemm128A3 = 17,     // row-gather 128 x 128 with three activation stages (80 KB: still two workgroups per CU)
-  kExpIgemm256A3Early = 18,
-  kExpIgemm256NtA = 19,    // row-gather 256 x 256 with non-temporal activation loads (the weights keep the L2)
-  kExpIgemm256W4 = 20,     // row-gather 256 x 256 on 4 waves of 128 x 128 (a third fewer LDS fragment reads, one wave per SIMD)
-  kExpIgemm256W2x4 = 21,   // row-gather 256 x 256 on 2 x 4 waves of 128 x 64 (the shipped one is 4 x 2 of 64 x 128)
+  kExpPatch128S4 = 9,      // halo-patch, 128 channels, 4 weight stages (three steps of lead)
+  kExpPatch256NoA = 10,     // halo-patch 256 without the patch traffic / without the weight traffic / without either
+  kExpPatch256NoB = 11,
+  kExpPatch256NoAB = 12,
+  kExpIgemm256NoA = 13,    // row-gather 256 x 256 likewise
+  kExpIgemm256NoB = 14,
+  kExpIgemm256NoAB = 15,
+  kExpIgemm256A3 = 16,     // row-gather 256 x 256 with three activation stages (+ two weight stages = all 160 KB of LDS)
+  kExpIgemm256Early = 17,  // row-gather 256 x 256 with all pieces of a stage issued during its first k-step
+  kExpIgemm128A3 = 18,     // row-gather 128 x 128 with three activation stages (80 KB: still two workgroups per CU)
+  kExpIgemm256A3Early = 19,
+  kExpIgemm256NtA = 20,    // row-gather 256 x 256 with non-temporal activation loads (the weights keep the L2)
+  kExpIgemm256W4 = 21,     // row-gather 256 x 256 on 4 waves of 128 x 128 (a third fewer LDS fragment reads, one wave per SIMD)
+  kExpIgemm256W2x4 = 22,   // row-gather 256 x 256 on 2 x 4 waves of 128 x 64 (the shipped one is 4 x 2 of 64 x 128)
 #ifdef RON_EXP
-  kNumCfgsBuilt = 22
+  kNumCfgsBuilt = 23
 #else
   kNumCfgsBuilt = kNumCfgs
 #endif
@@ -90,6 +92,10 @@ inline bool conv_cfg_is_patch(int cfg) {
 }
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream);
+// 3x3 / stride 1 / pad 1 on a 64-channel map, weights resident in LDS (conv_c64.hip); pack_conv_c64_weights builds wgt_c64
+bool conv_c64_applicable(const ConvLaunch& c);
+int launch_conv_c64(const ConvLaunch& c, hipStream_t stream);
+std::vector<uint8_t> pack_conv_c64_weights(const std::vector<float>& rows, int npad, int dtype);
 // 3x3 / stride 1 / pad 1 with the input halo patch staged once per channel chunk (conv_patch.hip)
 bool conv_patch_applicable(const ConvLaunch& c);
 int conv_patch_pick(const ConvLaunch& c);          // kCfgPatch* when the patch kernel is the better choice for this launch, else -1

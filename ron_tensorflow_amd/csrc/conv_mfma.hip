@@ -495,6 +495,7 @@ int conv_pick_igemm_cfg(int M, int Npad, int taps) {
 // The halo-patch kernel (conv_patch.hip) where it applies and wins (conv_patch_pick), else the row-gather kernel.
 int conv_pick_cfg(const ConvLaunch& c) {
   const int M = c.in.N * c.Ho * c.Wo;
+  if (conv_c64_applicable(c)) return kCfgC64Resident;
   if (conv_patch_applicable(c)) {
     const int cfg = conv_patch_pick(c);
     if (cfg >= 0) return cfg;
@@ -506,6 +507,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   const int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg(c);
   RON_REQUIRE(cfg >= 0 && cfg < kNumCfgsBuilt, "conv: tile config %d out of range [0, %d)", cfg, kNumCfgsBuilt);
   if (conv_cfg_is_patch(cfg)) return launch_conv_patch(c, cfg, stream);
+  if (cfg == kCfgC64Resident) return launch_conv_c64(c, stream);
   RON_REQUIRE(cfg != kCfgIgemm256TapsInner || c.up == 0, "conv: the taps-innermost order is for plain convolutions");
   const int esz = (int)dtype_size(c.dtype);
   const int chunk = conv_k_chunk(c.dtype);

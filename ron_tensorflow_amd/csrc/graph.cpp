@@ -51,6 +51,7 @@ struct Tensor {
 struct PackedConv {
   void* d_w = nullptr;
   int64_t w_bytes = 0;
+  void* d_w_c64 = nullptr;    // 3x3 on 64 input channels (conv2_1): the weights once more as LDS images for conv_c64.hip
   float* d_bias = nullptr;
   int Npad = 0, Cout = 0;
 };
@@ -254,6 +255,11 @@ int upload(ron_ctx* c, const Rows& r, int cout) {
   p.Npad = r.npad; p.Cout = cout;
   RON_HIP_CHECK(hipMalloc(&p.d_w, bytes.size()));
   RON_HIP_CHECK(hipMemcpy(p.d_w, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  if (c->cfg.dtype != RON_DTYPE_F32 && r.kh == 3 && r.kw == 3 && r.cin == 64 && r.npad == cout && cout % 64 == 0) {
+    const std::vector<uint8_t> img = pack_conv_c64_weights(r.w, r.npad, c->cfg.dtype);
+    RON_HIP_CHECK(hipMalloc(&p.d_w_c64, img.size()));
+    RON_HIP_CHECK(hipMemcpy(p.d_w_c64, img.data(), img.size(), hipMemcpyHostToDevice));
+  }
   RON_HIP_CHECK(hipMalloc((void**)&p.d_bias, r.b.size() * sizeof(float)));
   RON_HIP_CHECK(hipMemcpy(p.d_bias, r.b.data(), r.b.size() * sizeof(float), hipMemcpyHostToDevice));
   c->packed.push_back(p);
@@ -598,7 +604,7 @@ extern "C" int ron_destroy(ron_ctx* c) {
     c->d_l2_gamma = nullptr; c->d_stem_w = nullptr; c->d_stem_b = nullptr; c->d_stem2_w = nullptr; c->d_stem2_b = nullptr; c->d_stem2_w1 = nullptr;
   }
   for (auto& t : c->tensors) if (t.d) (void)hipFree(t.d);
-  for (auto& p : c->packed) { if (p.d_w) (void)hipFree(p.d_w); if (p.d_bias) (void)hipFree(p.d_bias); }
+  for (auto& p : c->packed) { if (p.d_w) (void)hipFree(p.d_w); if (p.d_w_c64) (void)hipFree(p.d_w_c64); if (p.d_bias) (void)hipFree(p.d_bias); }
   for (int i = 0; i < RON_MAX_LAYERS; ++i) for (int k = 0; k < 4; ++k) if (c->d_anchor[i][k]) (void)hipFree(c->d_anchor[i][k]);
   for (int k = 0; k < 3; ++k) for (int i = 0; i < RON_MAX_LAYERS; ++i) if (c->d_head[k][i]) (void)hipFree(c->d_head[k][i]);
   if (c->d_l2_gamma) (void)hipFree(c->d_l2_gamma);
@@ -912,7 +918,7 @@ static int describe_conv(const ron_ctx* c, const Op& o, int n, const ron_heads* 
     L.out = c->view(o.out, n, o.out_coff, o.out_C > 0 ? o.out_C : -1);
   }
   L.res = o.res >= 0 ? c->tensors[o.res].d : nullptr;
-  L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.bias = p.d_bias; L.Cout = p.Cout; L.Npad = p.Npad;
+  L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.wgt_c64 = p.d_w_c64; L.bias = p.d_bias; L.Cout = p.Cout; L.Npad = p.Npad;
   L.kh = o.kh; L.kw = o.kw; L.stride = o.stride; L.dil = o.dil; L.cpad = o.cpad; L.relu = o.relu;
   L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo; L.pool = o.pool;
   L.scratch = c->d_splitk[o.lane]; L.scratch_bytes = c->splitk_bytes[o.lane];

@@ -29,7 +29,7 @@ ron::TensorView make_view(void* base, int n, int h, int w, int c, int pad, int e
 
 struct ConvSetup {
   ron::ConvLaunch c;
-  DevBuf d_w, d_b, d_in, d_out, d_res, d_scratch;
+  DevBuf d_w, d_w_c64, d_b, d_in, d_out, d_res, d_scratch;
   int ho = 0, wo = 0;
   bool is_c3 = false;
 };
@@ -92,6 +92,13 @@ int setup_conv(const ron_conv_desc* d, const float* w, const float* bias, bool w
   RON_HIP_CHECK(hipMemcpy(S->d_w.p, wbytes.data(), wbytes.size(), hipMemcpyHostToDevice));
   RON_HIP_CHECK(hipMemcpy(S->d_b.p, bias_pad.data(), bias_pad.size() * 4, hipMemcpyHostToDevice));
   c.wgt = S->d_w.p; c.wgt_bytes = (int64_t)wbytes.size(); c.bias = (const float*)S->d_b.p;
+  if (!d->transpose && !S->is_c3 && d->dtype != RON_DTYPE_F32 && d->kh == 3 && d->kw == 3 && d->cin == 64 && c.Npad == d->cout && d->cout % 64 == 0) {
+    // what ron_finalize_weights adds for such a layer: the weights once more as LDS images for the resident-weight kernel
+    const std::vector<uint8_t> img = pack_conv_c64_weights(rows, c.Npad, d->dtype);
+    if ((rc = S->d_w_c64.alloc((int64_t)img.size(), false))) return rc;
+    RON_HIP_CHECK(hipMemcpy(S->d_w_c64.p, img.data(), img.size(), hipMemcpyHostToDevice));
+    c.wgt_c64 = S->d_w_c64.p;
+  }
   if (S->is_c3) c.in = make_view(nullptr, d->n, d->h, d->w, chunk, 0, esz);
   else {
     const int cs = d->in_cstride > 0 ? d->in_cstride : d->cin;

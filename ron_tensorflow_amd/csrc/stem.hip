@@ -27,9 +27,14 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
+// cvt2: two fp32 -> one dword of two storage-type values (round to nearest even; bf16: ONE v_cvt_pk_bf16_f32), low half first
 struct StemBF16 {
   static __device__ __forceinline__ unsigned short cvt(float v) { return __builtin_bit_cast(unsigned short, __float2bfloat16(v)); }
+  static __device__ __forceinline__ unsigned cvt2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2)); }
   static __device__ __forceinline__ float tof(unsigned v) { return __uint_as_float(v << 16); }
   static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
@@ -40,6 +45,7 @@ struct StemBF16 {
 };
 struct StemF16 {
   static __device__ __forceinline__ unsigned short cvt(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+  static __device__ __forceinline__ unsigned cvt2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2)); }
   static __device__ __forceinline__ float tof(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)v); }
   static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
@@ -256,14 +262,13 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
 #pragma unroll
     for (int gi = 0; gi < 3; ++gi) {
       const float* base = s_img + gb[gi];
-      unsigned short ev[8];
+      float gv[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float g = base[a_off[j]];
-        ev[j] = Tr::cvt(j >= 3 && k_pad ? 0.f : g);
+        gv[j] = j >= 3 && k_pad ? 0.f : g;
       }
-      const u32x4 fa = u32x4{(unsigned)ev[0] | ((unsigned)ev[1] << 16), (unsigned)ev[2] | ((unsigned)ev[3] << 16),
-                             (unsigned)ev[4] | ((unsigned)ev[5] << 16), (unsigned)ev[6] | ((unsigned)ev[7] << 16)};
+      const u32x4 fa = u32x4{Tr::cvt2(gv[0], gv[1]), Tr::cvt2(gv[2], gv[3]), Tr::cvt2(gv[4], gv[5]), Tr::cvt2(gv[6], gv[7])};
       f32x4 acc[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -275,10 +280,10 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
         const unsigned m = st[gi][e];
         const int iy = y0 - 1 + (int)((m >> 16) & 15u), ix = x0 - 1 + (int)((m >> 20) & 63u);
         const unsigned inside = (unsigned)-(int)((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W);   // mask (no branch)
-        unsigned v[4];
+        float v[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = Tr::cvt(fmaxf(acc[t][e] + b1[t], 0.f));
-        *reinterpret_cast<u32x2*>(s_p + (m & 0xFFFFu)) = u32x2{(v[0] | (v[1] << 16)) & inside, (v[2] | (v[3] << 16)) & inside};
+        for (int t = 0; t < 4; ++t) v[t] = fmaxf(acc[t][e] + b1[t], 0.f);
+        *reinterpret_cast<u32x2*>(s_p + (m & 0xFFFFu)) = u32x2{Tr::cvt2(v[0], v[1]) & inside, Tr::cvt2(v[2], v[3]) & inside};
       }
     }
     __syncthreads();
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
         const float m0 = fmaxf(fmaxf(acc2[0][e0], acc2[0][e0 + 1]) + b2_0, 0.f);
         const float m1 = fmaxf(fmaxf(acc2[1][e0], acc2[1][e0 + 1]) + b2_1, 0.f);
         const int m = 4 * qd + 2 * h + half;                          // pooled column 0..15
-        *reinterpret_cast<unsigned*>(s_pool + (wave * 16 + m) * 128 + r * 4) = (unsigned)Tr::cvt(m0) | ((unsigned)Tr::cvt(m1) << 16);
+        *reinterpret_cast<unsigned*>(s_pool + (wave * 16 + m) * 128 + r * 4) = Tr::cvt2(m0, m1);
       }
     __syncthreads();
     {
@@ -324,9 +329,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
       u32x4 o;
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const unsigned lo = Tr::cvt(fmaxf(Tr::tof(a[d] & 0xFFFFu), Tr::tof(b[d] & 0xFFFFu)));
-        const unsigned hi = Tr::cvt(fmaxf(Tr::tof(a[d] >> 16), Tr::tof(b[d] >> 16)));
-        o[d] = lo | (hi << 16);
+        o[d] = Tr::cvt2(fmaxf(Tr::tof(a[d] & 0xFFFFu), Tr::tof(b[d] & 0xFFFFu)), fmaxf(Tr::tof(a[d] >> 16), Tr::tof(b[d] >> 16)));
       }
       const long long opix = ((long long)img * out_Hp + (y0 >> 1) + yp + out_pad) * out_Wp + (x0 >> 1) + m + out_pad;
       *reinterpret_cast<u32x4*>(out + opix * 64 + c8 * 8) = o;

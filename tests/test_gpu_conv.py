@@ -128,7 +128,7 @@ def test_every_tile_configuration(ops, dev, cfg, dtype):
     """Each tile configuration of the row-gather kernel on a ragged multi-tile problem, K = 18 steps.  The shipped library
     holds exactly the configurations conv_pick_cfg() can select (the ablation builds live in libron_hip_diag.so)."""
     from ron_tensorflow_amd import _lib
-    assert _lib.lib().ron_conv_num_tile_cfgs() == 8
+    assert _lib.lib().ron_conv_num_tile_cfgs() == 9
     rs = np.random.RandomState(40 + cfg)
     x = rs.randn(3, 13, 11, 128).astype(np.float32)            # M = 429: two 256-row or four 128-row tiles, ragged
     wt = (rs.randn(3, 3, 128, 192) * 0.03).astype(np.float32)  # Cout 192 -> padded to 256
@@ -152,13 +152,17 @@ def test_no_entry_accepts_a_configuration_it_cannot_run(ops, dev):
     from ron_tensorflow_amd._lib import RonError
     x = torch.zeros((1, 10, 10, 64), device=dev)
     w3 = np.zeros((3, 3, 64, 64), np.float32)
-    for cfg in (8, 30, 100):
+    for cfg in (9, 30, 100):
         with pytest.raises(RonError):
             ops.conv2d_nhwc(x, w3, None, dtype='bf16', tile_cfg=cfg)
     with pytest.raises(RonError):                                        # 1x1 conv through the 3x3 patch kernel
         ops.conv2d_nhwc(x, np.zeros((1, 1, 64, 64), np.float32), None, dtype='bf16', tile_cfg=6)
     with pytest.raises(RonError):                                        # N tile 256 on 64 output channels
         ops.conv2d_nhwc(x, w3, None, dtype='bf16', tile_cfg=4)
+    with pytest.raises(RonError):                                        # resident-weight kernel: the 8 x 32 tile does not divide 10 x 10
+        ops.conv2d_nhwc(x, w3, None, dtype='bf16', tile_cfg=8)
+    with pytest.raises(RonError):                                        # ... and it has no fp32 form
+        ops.conv2d_nhwc(torch.zeros((1, 8, 32, 64), device=dev), w3, None, dtype='fp32', tile_cfg=8)
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
@@ -260,3 +264,36 @@ def test_patch_kernel_channel_slice_residual_and_pool(ops, dev, dtype):
         got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=5, pool=True).cpu().numpy()
         assert got.shape == ref.shape
         _check(got, ref, dtype)
+
+
+C64_SHAPES = [  # n, h, w, cout (Cin = 64): the 3x3 kernel with resident weights (csrc/conv_c64.hip), 8 x 32 pixel tiles
+    (1, 8, 32, 64),       # one tile, one 64-channel slice
+    (2, 16, 64, 128),     # conv2_1-like: two slices, 8 tiles
+    (3, 24, 96, 128),     # 27 tiles
+    (1, 40, 32, 256),     # four slices
+    (40, 32, 64, 128),    # 320 tiles on 128 tile sequences: every workgroup loops (double-buffered patches)
+    (67, 8, 32, 64),      # 67 tiles on 72 sequences: some workgroups have nothing to do
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('shape', C64_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_resident_weight_kernel_conv3x3_c64(ops, dev, shape, dtype):
+    """conv2_1's kernel vs the oracle conv, chosen explicitly (tile_cfg 8) and by conv_pick_cfg (-1): the same launch."""
+    n, h, w, cout = shape
+    rs = np.random.RandomState(sum(shape))
+    x = rs.randn(n, h, w, 64).astype(np.float32)
+    wt = (rs.randn(3, 3, 64, cout) * np.sqrt(2.0 / 576)).astype(np.float32)
+    b = (rs.randn(cout) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0)
+    xd = torch.from_numpy(x).to(dev)
+    got = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=8).cpu().numpy()
+    _check(got, ref, dtype)
+    auto = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype).cpu().numpy()
+    assert np.array_equal(auto, got)
+    # the row-gather kernel on the same problem: same sum in another order
+    _check(got, ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=3 if cout == 64 else 1).cpu().numpy(), dtype)
+    # no bias, no ReLU
+    ref2 = orf.conv2d_np(rnd(x), rnd(wt))
+    _check(ops.conv2d_nhwc(xd, wt, None, relu=False, dtype=dtype, tile_cfg=8).cpu().numpy(), ref2, dtype)

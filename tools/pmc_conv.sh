@@ -19,7 +19,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + '/p*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if "conv_igemm" not in r["Kernel_Name"] and "conv3x3_patch" not in r["Kernel_Name"]: continue
+        if not any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv3x3_patch", "conv3x3_c64")): continue
         agg[r['Counter_Name']]['v'].append(float(r['Counter_Value']))
 for k in sorted(agg):
     v = agg[k]['v']
