@@ -343,7 +343,8 @@ typedef struct {
   int32_t transpose;
   int32_t dtype;            /* ron_dtype */
   int32_t tile_cfg;         /* -1 = by shape (what the graph does), else one of the ron_conv_num_tile_cfgs() selectable
-                               configurations (csrc/conv_mfma.h kCfg*: 0-3 and 7 row-gather tiles, 4-6 halo-patch N tiles);
+                               configurations (csrc/conv_mfma.h kCfg*: 0-3 and 7 row-gather tiles, 4-6 halo-patch N tiles,
+                               8 the resident-weight 3x3 kernel for 64-channel maps);
                                anything else, or one that does not cover this conv, is RON_ERR_INVALID             */
   int32_t in_cstride;       /* tooling: input laid out as a channel slice: elements per pixel (0 = cin) ...   */
   int32_t in_coff;          /* ... and first channel of the slice                                              */

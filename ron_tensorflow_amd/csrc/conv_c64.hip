@@ -69,8 +69,12 @@ struct C64F16 : TraitsF16 {
   }
 };
 
-template <class Tr>
-__global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Args p) {
+// RW = tile rows per wave: 1 (8 waves; shipped) or 2 (experimental builds: 4 waves, one per SIMD, a weight fragment feeds two pixel
+// rows, 1.0 instead of 1.5 ds_read_b128 per MFMA - measured: the same run time, the fragment reads are not what bounds the loop).
+template <class Tr, int RW>
+__global__ __launch_bounds__(512 / RW) void conv3x3_c64_kernel(C64Args p) {
+  constexpr int NW = 8 / RW, kThreads = 64 * NW;
+  constexpr int kPiecesPerWave = (kC6Pieces + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_w = smem;
   char* s_p = smem + kC6WBytes;
@@ -83,12 +87,15 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Args p) {
   const int tiles_x = p.W / kC6TW, tiles_y = p.H / kC6TH;
   const int n_tiles = p.n_img * tiles_y * tiles_x;
 
-  // LDS-DMA pieces of a patch: piece i (1 KB = 8 patch rows) is issued by wave i % 8; lane -> (row 8i + lane / 8, slot lane % 8),
+  // LDS-DMA pieces of a patch: piece i (1 KB = 8 patch rows) is issued by wave i % NW; lane -> (row 8i + lane / 8, slot lane % 8),
   // source chunk = slot ^ key(row).  Offsets relative to the tile's first patch pixel; rows past the patch re-read its last row.
-  int voff[kC6PiecesPerWave];
+  // fixed-size array on purpose: with a template-dependent bound the LDS-DMA builtin's voffset becomes a type-dependent expression
+  // and hipcc (ROCm 7.2) silently drops the kernel
+  int voff[11];
+  static_assert(kPiecesPerWave <= 11, "pieces per wave");
 #pragma unroll
-  for (int k = 0; k < kC6PiecesPerWave; ++k) {
-    const int q = min((wave + 8 * k) * 8 + (lane >> 3), kC6Rows - 1);
+  for (int k = 0; k < kPiecesPerWave; ++k) {
+    const int q = min((wave + NW * k) * 8 + (lane >> 3), kC6Rows - 1);
     const int chunk = (lane & 7) ^ ((q >> 1) & 7);
     voff[k] = ((q / kC6PW) * p.in_Wp + q % kC6PW) * 128 + chunk * 16;
   }
@@ -100,39 +107,42 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Args p) {
     /* patch row 0 = input pixel (y0 - 1, x0 - 1) */                                                                  \
     const int soff = ((fimg * p.in_Hp + p.in_pad + fy * kC6TH - 1) * p.in_Wp + p.in_pad + fx * kC6TW - 1) * 128;      \
     char* dst_ = s_p + (buf_) * kC6PatchBytes + wave * 1024;                                                          \
-    _Pragma("unroll") for (int k = 0; k < kC6PiecesPerWave; ++k)                                                      \
-      if (wave + 8 * k < kC6Pieces)                                                                                   \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst_ + k * 8192), 16, voff[k], soff, 0, 0);          \
+    _Pragma("unroll") for (int k = 0; k < kPiecesPerWave; ++k)                                                        \
+      if (wave + NW * k < kC6Pieces)                                                                                  \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst_ + k * NW * 1024), 16, voff[k], soff, 0, 0);     \
   } while (0)
 
   if (slot < n_tiles) RON_C64_STAGE(slot, 0);
   // this half's weights: the host packed the exact LDS image
   {
     const u32x4* wsrc = p.wimg + (size_t)half * (kC6WBytes / 16);
-    for (int i = tid; i < kC6WBytes / 16; i += 512) reinterpret_cast<u32x4*>(s_w)[i] = wsrc[i];
+    for (int i = tid; i < kC6WBytes / 16; i += kThreads) reinterpret_cast<u32x4*>(s_w)[i] = wsrc[i];
   }
   const int n0 = half * 64;
   const float b0 = p.bias[n0 + 2 * r], b1 = p.bias[n0 + 2 * r + 1];
   const int key_b = (r >> 1) & 7;
   // stores: buffer addressing, per-lane offset fixed for the life of the workgroup (pixel 4h of a row, channels n0 + 2r, 2r + 1),
-  // the tile / accumulator-register part is a scalar offset: no address arithmetic per store
+  // the tile / row / accumulator-register part is a scalar offset: no address arithmetic per store
   const int st_voff = (4 * h * p.out_cstride + p.out_coff + n0 + 2 * r) * 2;
-  const int st_row = __builtin_amdgcn_readfirstlane(wave) * p.out_Wp * p.out_cstride * 2;
+  const int st_rowb = p.out_Wp * p.out_cstride * 2;                                  // bytes from one output row to the next
+  const int st_row = __builtin_amdgcn_readfirstlane(wave) * RW * st_rowb;
   const float lo = p.relu ? 0.f : -__builtin_huge_valf();
   // the previous tile's accumulators and where they go; before the first tile: a descriptor without records (stores dropped)
-  f32x16 prev[2];
+  f32x16 prev[RW][2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int w = 0; w < RW; ++w)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) prev[t][e] = 0.f;
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) prev[w][t][e] = 0.f;
   int prev_off = 0;
   unsigned prev_records = 0;
-#define RON_C64_STORE(e_)                                                                                             \
+#define RON_C64_STORE(w_, e_)                                                                                         \
   do {                                                                                                                \
     if (RON_C64_ABL(4)) break;                                                                                        \
     const int m_ = ((e_) & 3) + 8 * ((e_) >> 2);          /* + 4h: pixel of the row this accumulator register holds */  \
-    const float v0_ = fmaxf(prev[0][e_] + b0, lo), v1_ = fmaxf(prev[1][e_] + b1, lo);                                 \
-    __builtin_amdgcn_raw_buffer_store_b32(Tr::cvt2(v0_, v1_), rs_st, st_voff, prev_off + m_ * p.out_cstride * 2, 0);  \
+    const float v0_ = fmaxf(prev[w_][0][e_] + b0, lo), v1_ = fmaxf(prev[w_][1][e_] + b1, lo);                         \
+    __builtin_amdgcn_raw_buffer_store_b32(Tr::cvt2(v0_, v1_), rs_st, st_voff, prev_off + (w_) * st_rowb + m_ * p.out_cstride * 2, 0); \
   } while (0)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // first patch + the weight image (ds_write) of this wave
 
@@ -152,22 +162,27 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Args p) {
     if (tile + p.n_slots < n_tiles && !RON_C64_ABL(1)) RON_C64_STAGE(tile + p.n_slots, buf ^ 1);
     const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, prev_records, 0x00020000);
     const char* sp = s_p + buf * kC6PatchBytes;
-    f32x16 acc[2];
+    f32x16 acc[RW][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int w = 0; w < RW; ++w)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    // 36 k-steps (9 taps x 4 groups of 16 input channels), two MFMAs each.  The fragments of step i + 3 are read while step i
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[w][t][e] = 0.f;
+    // 36 k-steps (9 taps x 4 groups of 16 input channels), 2 RW MFMAs each.  The fragments of step i + 3 are read while step i
     // multiplies (a ring of four register sets): left to itself hipcc reads each fragment right before the MFMA that needs it
-    // and every MFMA waits out an LDS round trip.  One of the previous tile's sixteen stores goes out behind each of the steps
-    // 2 .. 17 (early: the wait below is for them too).
-    u32x4 fa[4], fb0[4], fb1[4];
+    // and every MFMA waits out an LDS round trip.  The previous tile's 16 RW stores go out behind the steps 2 .. 17, RW each
+    // (early: the wait below is for them too).
+    u32x4 fa[4][RW], fb0[4], fb1[4];
     auto frag_read = [&](int i) {
       const int tap = i >> 2, ks = i & 3, j = i & 3;
-      const int prow = (wave + tap / 3) * kC6PW + r + tap % 3;
-      const int key_a = (prow >> 1) & 7;
       const char* pb = s_w + tap * 8192 + r * 128 + (((2 * ks + h) ^ key_b) << 4);
-      fa[j] = *reinterpret_cast<const u32x4*>(sp + prow * 128 + (((2 * ks + h) ^ key_a) << 4));
+#pragma unroll
+      for (int w = 0; w < RW; ++w) {
+        const int prow = (wave * RW + w + tap / 3) * kC6PW + r + tap % 3;
+        const int key_a = (prow >> 1) & 7;
+        fa[j][w] = *reinterpret_cast<const u32x4*>(sp + prow * 128 + (((2 * ks + h) ^ key_a) << 4));
+      }
       fb0[j] = *reinterpret_cast<const u32x4*>(pb);
       fb1[j] = *reinterpret_cast<const u32x4*>(pb + 32 * 128);
     };
@@ -177,19 +192,30 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Args p) {
 #pragma unroll
       for (int i = 0; i < 36; ++i) {
         if (i + 3 < 36) frag_read(i + 3);
-        Tr::mma(fa[i & 3], fb0[i & 3], acc[0]);
-        Tr::mma(fa[i & 3], fb1[i & 3], acc[1]);
-        if (i >= 2 && i < 18) RON_C64_STORE(i >= 2 && i < 18 ? i - 2 : 0);
+#pragma unroll
+        for (int w = 0; w < RW; ++w) {
+          Tr::mma(fa[i & 3][w], fb0[i & 3], acc[w][0]);
+          Tr::mma(fa[i & 3][w], fb1[i & 3], acc[w][1]);
+        }
+        if (i >= 2 && i < 18) {
+#pragma unroll
+          for (int w = 0; w < RW; ++w) RON_C64_STORE(w, i >= 2 && i < 18 ? i - 2 : 0);
+        }
       }
-      // pin that order
-      __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+      // pin that order: the reads of a step spread between its MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (RW + 2), 0);
 #pragma unroll
       for (int i = 0; i < 36; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i + 3 < 36) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i + 3 < 36) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (i >= 2 && i < 18) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+#pragma unroll
+        for (int q = 0; q < 2 * RW; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i + 3 < 36) {
+            // RW + 2 reads over 2 RW MFMAs: RW = 1: 2 + 1, RW = 2: 1 each
+            if (RW == 1 && q == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+        if (i >= 2 && i < 18) __builtin_amdgcn_sched_group_barrier(0x040, RW, 0);
       }
     }
     // this wave's pieces of the next patch (and the stores above) are done
@@ -199,32 +225,35 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Args p) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
     prev_off = ((img * p.out_Hp + p.out_pad + ty * kC6TH) * p.out_Wp + p.out_pad + tx * kC6TW) * p.out_cstride * 2 + st_row;   // bytes
     prev_records = p.out_bytes;
-    prev[0] = acc[0]; prev[1] = acc[1];
+#pragma unroll
+    for (int w = 0; w < RW; ++w) { prev[w][0] = acc[w][0]; prev[w][1] = acc[w][1]; }
 #ifdef RON_EXP
     RON_C64_T(t_rest);
     ++n_done;
 #endif
   }
 #ifdef RON_EXP
-  if ((p.abl & 8) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 101) && (wave == 0 || wave == 7))
+  if ((p.abl & 8) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 101) && (wave == 0 || wave == NW - 1))
     printf("c64 wg %d wave %d: %d tiles, cycles per tile: barrier %llu taps %llu wait %llu rest %llu\n", (int)blockIdx.x, wave, n_done,
            t_bar / n_done, t_taps / n_done, t_wait / n_done, t_rest / n_done);
 #endif
   {   // the last tile's stores (no records if this workgroup had no tile)
     const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, prev_records, 0x00020000);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) RON_C64_STORE(e);
+    for (int w = 0; w < RW; ++w)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) RON_C64_STORE(w, e);
   }
 #undef RON_C64_STORE
 #undef RON_C64_STAGE
 }
 
-template <class Tr>
+template <class Tr, int RW>
 int launch_c64_t(const C64Args& a, hipStream_t s) {
   static PerDeviceOnce once;
   if (once.first())
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<Tr>), hipFuncAttributeMaxDynamicSharedMemorySize, kC6Lds));
-  hipLaunchKernelGGL(conv3x3_c64_kernel<Tr>, dim3(a.n_slots * a.halves), dim3(512), kC6Lds, s, a);
+    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<Tr, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, kC6Lds));
+  hipLaunchKernelGGL((conv3x3_c64_kernel<Tr, RW>), dim3(a.n_slots * a.halves), dim3(512 / RW), kC6Lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -278,8 +307,12 @@ int launch_conv_c64(const ConvLaunch& c, hipStream_t stream) {
 #ifdef RON_EXP
   if (const char* e = getenv("RON_C64_ABL")) a.abl = atoi(e);
 #endif
-  if (c.dtype == RON_DTYPE_BF16) return launch_c64_t<C64BF16>(a, stream);
-  return launch_c64_t<C64F16>(a, stream);
+#ifdef RON_EXP   // RON_C64_RW=2: four waves of two tile rows each (a third fewer fragment reads): same run time, not shipped
+  if (const char* e = getenv("RON_C64_RW"))
+    if (atoi(e) == 2) return c.dtype == RON_DTYPE_BF16 ? launch_c64_t<C64BF16, 2>(a, stream) : launch_c64_t<C64F16, 2>(a, stream);
+#endif
+  if (c.dtype == RON_DTYPE_BF16) return launch_c64_t<C64BF16, 1>(a, stream);
+  return launch_c64_t<C64F16, 1>(a, stream);
 }
 
 }  // namespace ron
