@@ -362,7 +362,7 @@ def main():
                        'gflop_per_image': net.flops_per_image() / 1e9,
                        'conv_stack_tflops_per_gpu': net.flops_per_image() * args.batch * args.steps / dt / 1e12,
                        'mean_detections_per_image': float(det.count.float().mean().item())},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv kernels: conv_igemm_kernel (+ its grouped form conv_igemm_group_kernel) and conv3x3_patch_kernel', 'achieved': achieved, 'peak': peak,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv kernels: conv_igemm_kernel (+ its grouped form conv_igemm_group_kernel), conv3x3_patch_kernel and conv3x3_c64_kernel', 'achieved': achieved, 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_source,
                          'basis': basis,
                          # the per-kernel definition: conv FLOPs per launch / that launch's own duration, one launch at a

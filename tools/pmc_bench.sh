@@ -21,7 +21,7 @@ for which in ('fetch', 'write'):
     vals = []
     for f in glob.glob('%s/pmc_%s/*/*counter_collection.csv' % (out, which)):
         for r in csv.DictReader(open(f)):
-            if 'conv_igemm' in r['Kernel_Name'] or 'conv3x3_patch' in r['Kernel_Name']:      # every conv launch, grouped ones included
+            if any(k in r['Kernel_Name'] for k in ('conv_igemm', 'conv3x3_patch', 'conv3x3_c64')):      # every conv launch, grouped ones included
                 vals.append(float(r['Counter_Value']))
     tot[which] = (sum(vals) / max(len(vals), 1), len(vals))
 fetch_kib, n1 = tot['fetch']
