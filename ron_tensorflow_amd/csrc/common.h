@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <atomic>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -35,14 +36,21 @@ void set_error(const char* fmt, ...);
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 // hipFuncSetAttribute applies to the current device only: one of these per kernel instantiation remembers on which
-// devices (id < 64) it has been done.  first() is true once per device, from whichever host thread gets there first.
+// devices (id < 64) the dynamic-LDS limit has been raised.  Safe from several host threads: nobody returns before the
+// attribute is set on his device.
 struct PerDeviceOnce {
   std::atomic<uint64_t> done{0};
-  bool first() {
+  std::mutex mu;
+  hipError_t max_dynamic_lds(const void* kernel, int bytes) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;      // unknown device: just set it again
-    const uint64_t bit = 1ull << dev;
-    return (done.fetch_or(bit) & bit) == 0;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev <= 63;     // unknown device: just set it again
+    const uint64_t bit = known ? 1ull << dev : 0;
+    if (known && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    std::lock_guard<std::mutex> lock(mu);
+    if (known && (done.load(std::memory_order_relaxed) & bit)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && known) done.fetch_or(bit, std::memory_order_release);
+    return e;
   }
 };
 

@@ -251,8 +251,7 @@ __global__ __launch_bounds__(512 / RW) void conv3x3_c64_kernel(C64Args p) {
 template <class Tr, int RW>
 int launch_c64_t(const C64Args& a, hipStream_t s) {
   static PerDeviceOnce once;
-  if (once.first())
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<Tr, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, kC6Lds));
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_c64_kernel<Tr, RW>), kC6Lds));
   hipLaunchKernelGGL((conv3x3_c64_kernel<Tr, RW>), dim3(a.n_slots * a.halves), dim3(512 / RW), kC6Lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;

@@ -413,9 +413,7 @@ template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP =
 int launch_t(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, SA);
   static PerDeviceOnce once;
-  if (once.first())
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA, TI>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA, TI>), (int)lds));
   hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA, TI>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
@@ -557,9 +555,7 @@ template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 int launch_group_t(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
   const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, S);
   static PerDeviceOnce once;
-  if (once.first())
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), (int)lds));
   hipLaunchKernelGGL((conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(g.first[g.n]), dim3(WM * WN * 64), lds, s, g);
   if (any_split) {
     long long most = 0;

@@ -609,10 +609,7 @@ template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int ABL =
 int launch_t(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)S * (BM + BN) * RB + 2 * BM * sizeof(int) + (ROT == 2 ? WM * WN * 256 : 0);
   static PerDeviceOnce once;
-  if (once.first()) {
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB, ROT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB, ROT>), (int)lds));
   hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, ABL, RB, ROT>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;

@@ -319,10 +319,7 @@ template <class Tr, int BN, int WN, int SB>
 int launch_patch_t(const PatchArgs& a, int grid, hipStream_t s) {
   const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
   static PerDeviceOnce once;
-  if (once.first()) {
-    RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN, SB>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN, SB>), (int)lds));
   hipLaunchKernelGGL((conv3x3_patch_kernel<Tr, BN, WN, SB>), dim3(grid), dim3(512), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;

@@ -414,10 +414,8 @@ int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w
   const int grid = std::min(tiles, 256);
   static PerDeviceOnce attr_set[2];                // the attribute is per device (common.h)
   const int which = dtype == RON_DTYPE_BF16 ? 0 : 1;
-  if (attr_set[which].first()) {
-    if (which == 0) RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem2_kernel<StemBF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kS2Lds));
-    else RON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem2_kernel<StemF16>), hipFuncAttributeMaxDynamicSharedMemorySize, kS2Lds));
-  }
+  RON_HIP_CHECK(attr_set[which].max_dynamic_lds(which == 0 ? reinterpret_cast<const void*>(&stem2_kernel<StemBF16>)
+                                                           : reinterpret_cast<const void*>(&stem2_kernel<StemF16>), kS2Lds));
   if (which == 0)
     hipLaunchKernelGGL(stem2_kernel<StemBF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
                        (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad);
