@@ -81,8 +81,10 @@ enum {
   kExpIgemm256NtA = 20,    // row-gather 256 x 256 with non-temporal activation loads (the weights keep the L2)
   kExpIgemm256W4 = 21,     // row-gather 256 x 256 on 4 waves of 128 x 128 (a third fewer LDS fragment reads, one wave per SIMD)
   kExpIgemm256W2x4 = 22,   // row-gather 256 x 256 on 2 x 4 waves of 128 x 64 (the shipped one is 4 x 2 of 64 x 128)
+  kExpIgemm256H = 23,      // row-gather 256 x 256 with half-chunk stages: four stages of 32 KB, three in flight
+  kExpIgemm256HTapsInner = 24,
 #ifdef RON_EXP
-  kNumCfgsBuilt = 23
+  kNumCfgsBuilt = 25
 #else
   kNumCfgsBuilt = kNumCfgs
 #endif

@@ -323,6 +323,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n_base + nloc, tap_off);
 }
 
+#ifdef RON_EXP
+#include "exp/conv_igemm_h.h"   // kExpIgemm256H: four half-chunk stages, three in flight (slower; see the header)
+#endif
+
 constexpr int igemm_lds_bytes(int BM, int BN, int S, int SA) {
   return (SA * BM + S * BN) * kRowBytes + (SA > S ? 0 : 2 * BM * (int)sizeof(int));
 }
@@ -419,6 +423,18 @@ int launch_t(const ConvArgs& a, hipStream_t s) {
   return RON_OK;
 }
 
+#ifdef RON_EXP
+template <class Tr, int BM, int BN, int WM, int WN, int S, bool TI>
+int launch_h_t(const ConvArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)igemm_h_lds_bytes(BM, BN, S);
+  static PerDeviceOnce once;
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_h_kernel<Tr, BM, BN, WM, WN, S, TI>), (int)lds));
+  hipLaunchKernelGGL((conv_igemm_h_kernel<Tr, BM, BN, WM, WN, S, TI>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+#endif
+
 template <class Tr>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   switch (cfg) {
@@ -438,6 +454,8 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case kExpIgemm256A3Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0, 3>(a, s);
     case kExpIgemm256W4: return launch_t<Tr, 256, 256, 2, 2, 2, 1>(a, s);
     case kExpIgemm256W2x4: return launch_t<Tr, 256, 256, 2, 4, 2, 1>(a, s);
+    case kExpIgemm256H: return launch_h_t<Tr, 256, 256, 4, 2, 4, false>(a, s);
+    case kExpIgemm256HTapsInner: return launch_h_t<Tr, 256, 256, 4, 2, 4, true>(a, s);
 #endif
   }
   ron::set_error("conv: unknown tile config %d", cfg);
@@ -463,7 +481,7 @@ int conv_num_cfgs() { return kNumCfgsBuilt; }
 
 static bool igemm_is256(int cfg) {
   return cfg == kCfgIgemm256 || cfg == kCfgIgemm256TapsInner || (cfg >= kExpIgemm256NoA && cfg <= kExpIgemm256Early) ||
-         cfg == kExpIgemm256A3Early || cfg == kExpIgemm256NtA || cfg == kExpIgemm256W4 || cfg == kExpIgemm256W2x4;
+         cfg == kExpIgemm256A3Early || cfg == kExpIgemm256NtA || cfg == kExpIgemm256W4 || cfg == kExpIgemm256W2x4 || cfg == kExpIgemm256H || cfg == kExpIgemm256HTapsInner;
 }
 static int igemm_bm(int cfg) { return igemm_is256(cfg) ? 256 : 128; }
 static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : (cfg == kCfgIgemm128x64 ? 64 : 128); }
