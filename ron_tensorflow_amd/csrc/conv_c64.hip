@@ -285,14 +285,13 @@ bool conv_c64_applicable(const ConvLaunch& c) {
   return c.wgt_c64 != nullptr && (c.dtype == RON_DTYPE_BF16 || c.dtype == RON_DTYPE_F16) && c.kh == 3 && c.kw == 3 && c.stride == 1 &&
          c.dil == 1 && c.cpad == 1 && c.up == 0 && !c.pool && c.res == nullptr && !c.out_f32 && c.in.C == 64 && c.in.cstride == 64 &&
          c.in.coff == 0 && c.in.pad >= 1 && c.Npad == c.Cout && c.Cout % 64 == 0 && (c.Cout / 64 == 1 || c.Cout / 64 == 2 || c.Cout / 64 == 4) &&
-         c.Ho % kC6TH == 0 && c.Wo % kC6TW == 0 && c.Ho == c.in.H && c.Wo == c.in.W && c.out.cstride % 2 == 0 && c.out.coff % 2 == 0;
+         c.Ho % kC6TH == 0 && c.Wo % kC6TW == 0 && c.Ho == c.in.H && c.Wo == c.in.W && c.out.cstride % 2 == 0 && c.out.coff % 2 == 0 &&
+         c.in.bytes > 0 && c.in.bytes < (int64_t)1 << 31 && c.out.bytes > 0 && c.out.bytes < (int64_t)1 << 31;   // 32-bit buffer offsets
 }
 
 int launch_conv_c64(const ConvLaunch& c, hipStream_t stream) {
   RON_REQUIRE(conv_c64_applicable(c), "resident-weight kernel: 3x3 / stride 1 / pad 1 on a 64-channel bf16 / f16 map whose size the 8 x 32 tile "
-              "divides, 64 / 128 / 256 outputs, packed weight image present");
-  RON_REQUIRE(c.in.bytes > 0 && c.in.bytes < (int64_t)1 << 31 && c.out.bytes > 0 && c.out.bytes < (int64_t)1 << 31,
-              "resident-weight kernel: input and output allocations must be < 2 GiB for buffer addressing");
+              "divides, 64 / 128 / 256 outputs, tensors < 2 GiB, packed weight image present");
   C64Args a;
   a.in = c.in.base; a.in_bytes = (unsigned)c.in.bytes;
   a.in_Hp = c.in.Hp(); a.in_Wp = c.in.Wp(); a.in_pad = c.in.pad;
