@@ -33,7 +33,6 @@ constexpr int kC6Pieces = (kC6Rows * 128 + 1023) / 1024;                        
 constexpr int kC6PatchBytes = kC6Pieces * 1024;                                  // 44032: 340 rows + 4 rows of overshoot
 constexpr int kC6WBytes = 9 * 64 * 128;                                          // 72 KB
 constexpr int kC6Lds = kC6WBytes + 2 * kC6PatchBytes;                            // 161 792 of 163 840
-constexpr int kC6PiecesPerWave = (kC6Pieces + 7) / 8;                            // 6 (waves 0-2), 5 (waves 3-7)
 
 struct C64Args {
   const void* in;
