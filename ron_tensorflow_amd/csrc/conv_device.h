@@ -50,6 +50,9 @@ struct ConvArgs {
   // fused 2x2 / stride-2 max-pool: tile rows are ordered window-major (rows 4q..4q+3 = the four conv outputs of
   // pooled pixel q), which puts a window into four consecutive accumulator registers of one lane.
   int pool;
+  // tile order inside an XCD's run of workgroups: 0 = N fastest (the column tiles that re-read one activation tile share an L2),
+  // 1 = M fastest (the row tiles that re-read one weight slice do: fc6's 205 MB of weights are then fetched once, not once per XCD)
+  int m_fastest;
   // diagnostic builds only (ABL 5): per-wave cycle sums {wait, barrier, compute, K steps}, 4 x u64 per wave
   unsigned long long* dbg;
 };
@@ -270,6 +273,7 @@ inline void fill_conv_args(const ConvLaunch& c, ConvArgs* out) {
   a.Npad = c.Npad;
   a.splitk = 1; a.kt_split = a.KT; a.partial = nullptr;
   a.pool = c.pool;
+  a.m_fastest = 0;
   a.dbg = c.dbg;
   *out = a;
 }

@@ -79,8 +79,9 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   const unsigned wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
   const int zsplit = (int)(wgid / (unsigned)p.tiles_total);
   const unsigned tile = wgid - (unsigned)zsplit * (unsigned)p.tiles_total;
-  const int tile_n = (int)(tile % (unsigned)p.tiles_n);
-  const int tile_m = (int)(tile / (unsigned)p.tiles_n);
+  const unsigned tiles_m = (unsigned)p.tiles_total / (unsigned)p.tiles_n;
+  const int tile_n = (int)(p.m_fastest ? tile / tiles_m : tile % (unsigned)p.tiles_n);
+  const int tile_m = (int)(p.m_fastest ? tile % tiles_m : tile / (unsigned)p.tiles_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kt0 = zsplit * p.kt_split;
   const int kt1 = min(p.KT, kt0 + p.kt_split);
@@ -508,6 +509,25 @@ int conv_pick_igemm_cfg(int M, int Npad, int taps) {
   return ((M + 127) / 128) * (Npad / 128) >= 2048 ? kCfgIgemm128Early : kCfgIgemm128;
 }
 
+// Order of the tiles inside the run of workgroups that shares an XCD's L2 (1/8 of the launch): N fastest re-reads few activation
+// tiles and every weight slice of those columns, M fastest the other way round.  Estimated bytes an XCD has to fetch once:
+// activation tiles it touches x their size + weight slices it touches x theirs; M fastest when that is less (fc6: 13 row tiles x
+// 16 column tiles of 12.8 MB of weights each - N fastest makes every XCD stream all 205 MB: 1.66 GB fetched per launch, 0.65 GB
+// M fastest, 566 -> 541 us; fc7 113 -> 102 us).  Forced on every launch it costs the activation-heavy layers 2-4 %; walking the
+// column tiles of an XCD's rows in blocks of 1-3 instead changed nothing (both measured, not kept).
+static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int tiles_n, int splitk) {
+  // split-K: the workgroups of one K slice are consecutive, an XCD's run then covers (nearly) every tile of its slices either way
+  if (tiles_m < 2 || tiles_n < 2 || splitk > 1) return 0;
+  const double esz = (double)dtype_size(c.dtype);
+  const int taps = c.kh * c.kw;
+  const double a_tile = (double)BM * c.in.C * esz * (c.stride > 1 ? taps : (taps > 1 ? 2 : 1));   // unique input bytes of a row tile
+  const double b_tile = (double)BN * taps * c.in.C * esz;
+  const int per_xcd = std::max(1, tiles_m * tiles_n / 8);
+  const double cost_n = (per_xcd / tiles_n + 1) * a_tile + std::min(tiles_n, per_xcd) * b_tile;
+  const double cost_m = std::min(tiles_m, per_xcd) * a_tile + (per_xcd / tiles_m + 1) * b_tile;
+  return cost_m < 0.95 * cost_n ? 1 : 0;
+}
+
 // The halo-patch kernel (conv_patch.hip) where it applies and wins (conv_patch_pick), else the row-gather kernel.
 int conv_pick_cfg(const ConvLaunch& c) {
   const int M = c.in.N * c.Ho * c.Wo;
@@ -554,6 +574,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
     a.partial = (float*)c.scratch;
     if (a.splitk == 1) { a.kt_split = a.KT; a.partial = nullptr; }
   }
+  a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
   RON_REQUIRE((int64_t)c.Npad * K * esz == c.wgt_bytes, "conv: packed weight size mismatch");
   int rc;
   if (c.dtype == RON_DTYPE_BF16) rc = launch_cfg<TraitsBF16S>(cfg, a, stream);
@@ -656,6 +677,7 @@ int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64
       if (a.splitk == 1) { a.kt_split = a.KT; a.partial = nullptr; }
       else { used += need; any_split = true; }
     }
+    a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
     g.first[k + 1] = g.first[k] + a.tiles_total * a.splitk;
   }
   if (ls[0].dtype == RON_DTYPE_BF16) return launch_group_cfg<TraitsBF16S>(cfg, g, any_split, stream);

@@ -297,3 +297,20 @@ def test_resident_weight_kernel_conv3x3_c64(ops, dev, shape, dtype):
     # no bias, no ReLU
     ref2 = orf.conv2d_np(rnd(x), rnd(wt))
     _check(ops.conv2d_nhwc(xd, wt, None, relu=False, dtype=dtype, tile_cfg=8).cpu().numpy(), ref2, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+@pytest.mark.parametrize('cfg', [-1, 0, 1])
+def test_weight_heavy_layer_runs_its_tiles_row_fastest(ops, dev, cfg, dtype):
+    """fc6-like: few row tiles, several column tiles, K = 6272: without split-K conv_mfma.hip walks the tiles M fastest (the row tiles
+    that share a weight slice share an XCD).  Same result as the oracle and as the split-K form (which keeps the N-fastest order)."""
+    rs = np.random.RandomState(17)
+    x = rs.randn(6, 10, 10, 128).astype(np.float32)             # M = 600: three 256-row / five 128-row tiles
+    wt = (rs.randn(7, 7, 128, 512) * np.sqrt(2.0 / (49 * 128))).astype(np.float32)
+    b = (rs.randn(512) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0)
+    xd = torch.from_numpy(x).to(dev)
+    got = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=cfg, splitk=1).cpu().numpy()
+    _check(got, ref, dtype)
+    _check(ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=cfg, splitk=4).cpu().numpy(), ref, dtype)
