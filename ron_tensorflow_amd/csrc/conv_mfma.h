@@ -83,8 +83,11 @@ enum {
   kExpIgemm256W2x4 = 22,   // row-gather 256 x 256 on 2 x 4 waves of 128 x 64 (the shipped one is 4 x 2 of 64 x 128)
   kExpIgemm256H = 23,      // row-gather 256 x 256 with half-chunk stages: four stages of 32 KB, three in flight
   kExpIgemm256HTapsInner = 24,
+  kExpIgemm128x64S3 = 25,  // 128 x 64 with three / four stages (two / three K steps in flight): the latency-bound small layers
+  kExpIgemm128x64S4 = 26,
+  kExpIgemm128S3 = 27,     // 128 x 128 with three stages
 #ifdef RON_EXP
-  kNumCfgsBuilt = 25
+  kNumCfgsBuilt = 28
 #else
   kNumCfgsBuilt = kNumCfgs
 #endif

@@ -455,6 +455,9 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case kExpIgemm256A3Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0, 3>(a, s);
     case kExpIgemm256W4: return launch_t<Tr, 256, 256, 2, 2, 2, 1>(a, s);
     case kExpIgemm256W2x4: return launch_t<Tr, 256, 256, 2, 4, 2, 1>(a, s);
+    case kExpIgemm128x64S3: return launch_t<Tr, 128, 64, 2, 2, 3, 2>(a, s);
+    case kExpIgemm128x64S4: return launch_t<Tr, 128, 64, 2, 2, 4, 2>(a, s);
+    case kExpIgemm128S3: return launch_t<Tr, 128, 128, 2, 2, 3, 1>(a, s);
     case kExpIgemm256H: return launch_h_t<Tr, 256, 256, 4, 2, 4, false>(a, s);
     case kExpIgemm256HTapsInner: return launch_h_t<Tr, 256, 256, 4, 2, 4, true>(a, s);
 #endif
@@ -485,9 +488,9 @@ static bool igemm_is256(int cfg) {
          cfg == kExpIgemm256A3Early || cfg == kExpIgemm256NtA || cfg == kExpIgemm256W4 || cfg == kExpIgemm256W2x4 || cfg == kExpIgemm256H || cfg == kExpIgemm256HTapsInner;
 }
 static int igemm_bm(int cfg) { return igemm_is256(cfg) ? 256 : 128; }
-static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : (cfg == kCfgIgemm128x64 ? 64 : 128); }
+static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : ((cfg == kCfgIgemm128x64 || cfg == kExpIgemm128x64S3 || cfg == kExpIgemm128x64S4) ? 64 : 128); }
 // workgroups of a configuration the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
-static int igemm_slots(int cfg) { return igemm_is256(cfg) ? 256 : 512; }
+static int igemm_slots(int cfg) { return (igemm_is256(cfg) || cfg == kExpIgemm128x64S4 || cfg == kExpIgemm128S3) ? 256 : 512; }
 
 // Split-K factor for grids that leave most CUs idle: such launches are a serial chain of KT dependent
 // HBM round trips per workgroup, so the K loop is spread over enough workgroups to fill the chip (>= 8 steps each).
