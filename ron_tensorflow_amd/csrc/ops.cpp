@@ -3,6 +3,7 @@
 // can pin each kernel against the oracle.  They allocate scratch and synchronise: test/tool use.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -180,12 +181,15 @@ extern "C" int ron_conv2d_bench(const ron_conv_desc* d, int warmup, int iters, f
   uint32_t st = 12345u;
   auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.f - 1.f; };
   const float scale = 1.f / sqrtf((float)(d->kh * d->kw * d->cin));
-  for (auto& v : w) v = rnd() * scale;
-  for (auto& v : b) v = rnd() * 0.1f;
+  // RON_BENCH_ZERO=1 (tools/sweep_conv.py --zeros): all-zero operands instead of random ones - the same instruction stream at the
+  // clock the chip holds when the data paths do not toggle (MI355X_MICROARCH.md, DVFS): how much of a kernel's time is power
+  const bool zeros = getenv("RON_BENCH_ZERO") != nullptr;
+  for (auto& v : w) v = zeros ? 0.f : rnd() * scale;
+  for (auto& v : b) v = zeros ? 0.f : rnd() * 0.1f;
   ConvSetup S;
   int rc;
   if ((rc = setup_conv(d, w.data(), b.data(), false, &S))) return rc;
-  if ((rc = launch_fill_random(S.c.in, d->dtype, 777u, nullptr))) return rc;
+  if (!zeros && (rc = launch_fill_random(S.c.in, d->dtype, 777u, nullptr))) return rc;
   hipEvent_t e0, e1;
   RON_HIP_CHECK(hipEventCreate(&e0));
   RON_HIP_CHECK(hipEventCreate(&e1));

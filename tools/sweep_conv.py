@@ -10,6 +10,9 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # --exp / --diag: the experimental (make EXP=1) or the round-1 diagnostic (make DIAG=1) build of the library
+if '--zeros' in sys.argv:       # all-zero operands: the clock-limited share of a kernel's time (csrc/ops.cpp, ron_conv2d_bench)
+    sys.argv.remove('--zeros')
+    os.environ['RON_BENCH_ZERO'] = '1'
 for flag, so in (('--exp', 'libron_hip_exp.so'), ('--diag', 'libron_hip_diag.so')):
     if flag in sys.argv:
         sys.argv.remove(flag)
