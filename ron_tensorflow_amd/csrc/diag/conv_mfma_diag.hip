@@ -790,6 +790,13 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   return launch_finalize<TraitsF32>(a, stream);
 }
 
+// the round-1 kernels know no grouped launches (graph.cpp plans none under RON_DIAG)
+int launch_conv_group(const ConvLaunch*, int, int, void*, int64_t, hipStream_t) {
+  ron::set_error("the diagnostic library has no grouped launches");
+  return RON_ERR_UNSUPPORTED;
+}
+int64_t conv_group_scratch_bytes(const ConvLaunch*, int, int) { return 0; }
+
 int64_t conv_scratch_bytes(const ConvLaunch& l) {
   const int cfg = l.cfg;
   if (cfg == kCfgPatchDiag || cfg == kCfgPatchDiag + 1 || l.up > 0 || l.pool) return 0;   // the halo-patch kernel never splits K
