@@ -140,9 +140,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 //   A. the 12 x 36 x 3 fp32 image patch goes to LDS (zero outside the image);
 //   B. conv1_1 (+bias, ReLU) of the 10 x 34 halo patch is computed with MFMAs (K = 27 -> 32) and stored as bf16 rows of
 //      128 B (64 channels) in LDS, swizzled like the generic kernel's stages, zero outside the image (= conv1_2's padding);
-//   C. conv1_2 runs its 9 taps straight from that patch: wave w owns tile row w (32 consecutive pixels, so a fragment's
-//      rows are consecutive patch rows: conflict-free ds_read_b128 for any tap shift with the 32x32 MFMA), the weights
-//      of all 9 taps (72 KB) stay resident in LDS for the life of the (persistent) workgroup -- no staging in the loop;
+//   C. conv1_2 runs its 9 taps straight from that patch: wave w owns tile row w (32 consecutive pixels = two 16-row fragments
+//      of consecutive patch rows; chunk swizzle ((row >> 1) & 3) << 1: conflict-free ds_read_b128 for any tap shift), on
+//      16x16x32 MFMAs (the chip holds a higher clock under them than under the 32x32x16 form this loop started with: same
+//      cycles, conv_c64.hip), the weights of all 9 taps (72 KB) stay resident in LDS for the life of the (persistent)
+//      workgroup -- no staging in the loop;
 //   D. + bias, ReLU, 2x2 max-pool (horizontal pairs are adjacent accumulator registers, vertical pairs meet in LDS),
 //      16-byte stores of the pooled 4 x 16 tile.
 // HBM traffic: image in (1.2 MB / image), pool1 out (3.3 MB / image).
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
   constexpr unsigned kDumpOff = (unsigned)kS2PatchBytes;             // relative to s_p
   static_assert(kDumpOff + kS2DumpBytes <= 0xFFFFu, "store offsets are 16 bits");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
+  // (lane -> c16 = lane & 15, kg = lane >> 4 below: the 16x16x32 fragment and accumulator layout)
 
   // conv1_2 weights: the host packed the exact LDS image (tap, permuted output row, swizzled 16-byte chunks)
   for (int i = tid; i < kS2W2Bytes / 16; i += 512) reinterpret_cast<u32x4*>(s_w2)[i] = w2img[i];
@@ -189,7 +191,9 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
   float b1[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) b1[t] = bias1[4 * c16 + t];
-  const float b2_0 = bias2[2 * r], b2_1 = bias2[2 * r + 1];
+  float b2[4];                                   // conv1_2 bias of this lane's four adjacent output channels 4 c16 .. 4 c16 + 3
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b2[j] = bias2[4 * (lane & 15) + j];
   int a_off[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
     for (int e = 0; e < 4; ++e) {
       const int qq = g * 16 + 4 * kg + e;
       const int qy = qq / kS2PW, qx = qq - qy * kS2PW;
-      const unsigned off = (unsigned)(qq * 128 + ((((c16 >> 1) ^ ((qq >> 1) & 7))) << 4) + (c16 & 1) * 8);
+      const unsigned off = (unsigned)(qq * 128 + ((((c16 >> 1) ^ (((qq >> 1) & 3) << 1))) << 4) + (c16 & 1) * 8);
       st[gi][e] = qq < kS2Rows ? (off | ((unsigned)qy << 16) | ((unsigned)qx << 20)) : (kDumpOff + (unsigned)lane * 8u);
     }
   }
@@ -289,37 +293,42 @@ __global__ __launch_bounds__(512) void stem2_kernel(const float* __restrict__ x,
     __syncthreads();
     RON_S2_STORE();                                   // s_img is free: the next tile's patch (read after two more barriers)
     // ---- C: conv1_2, wave = tile row, 9 taps x 4 k-steps x 2 column tiles
-    f32x16 acc2[2];
+    f32x4 acc2[2][4];                                  // [16-pixel block of the row][16-channel block]
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc2[t][e] = 0.f;
-    const int key_b = (r >> 1) & 7;
+      for (int j = 0; j < 4; ++j) acc2[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int key_b = ((c16 >> 1) & 3) << 1;           // weight-image rows j * 16 + c16: the key of c16
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int prow = (wave + tap / 3) * kS2PW + r + tap % 3;
-      const char* pa = s_p + prow * 128;
-      const int key_a = (prow >> 1) & 7;
-      const char* pb = s_w2 + tap * 8192 + r * 128;
+      const char* pb = s_w2 + tap * 8192 + c16 * 128;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const u32x4 fa = *reinterpret_cast<const u32x4*>(pa + (((2 * s + h) ^ key_a) << 4));
-        const u32x4 fb0 = *reinterpret_cast<const u32x4*>(pb + (((2 * s + h) ^ key_b) << 4));
-        const u32x4 fb1 = *reinterpret_cast<const u32x4*>(pb + 32 * 128 + (((2 * s + h) ^ key_b) << 4));
-        Tr::mma(fa, fb0, acc2[0]);
-        Tr::mma(fa, fb1, acc2[1]);
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 fa[2], fb[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int prow = (wave + tap / 3) * kS2PW + 16 * a + c16 + tap % 3;
+          fa[a] = *reinterpret_cast<const u32x4*>(s_p + prow * 128 + (((4 * ks + kg) ^ (((prow >> 1) & 3) << 1)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const u32x4*>(pb + j * 16 * 128 + (((4 * ks + kg) ^ key_b) << 4));
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Tr::mma16(fa[a], fb[j], acc2[a][j]);
       }
     }
-    // ---- D: bias, ReLU, horizontal pool in registers -> LDS; vertical pool + store
+    // ---- D: bias, ReLU, horizontal pool in registers -> LDS; vertical pool + store.  Accumulator register e of block a holds
+    // pixel 16 a + 4 kg + e of the row, channels 4 c16 + j: pooled column 8 a + 2 kg + hp from registers 2 hp, 2 hp + 1
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int e0 = 4 * qd + 2 * half;
-        const float m0 = fmaxf(fmaxf(acc2[0][e0], acc2[0][e0 + 1]) + b2_0, 0.f);
-        const float m1 = fmaxf(fmaxf(acc2[1][e0], acc2[1][e0 + 1]) + b2_1, 0.f);
-        const int m = 4 * qd + 2 * h + half;                          // pooled column 0..15
-        *reinterpret_cast<unsigned*>(s_pool + (wave * 16 + m) * 128 + r * 4) = Tr::cvt2(m0, m1);
+      for (int hp = 0; hp < 2; ++hp) {
+        float m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(acc2[a][j][2 * hp], acc2[a][j][2 * hp + 1]) + b2[j], 0.f);
+        const int mc = 8 * a + 2 * kg + hp;                             // pooled column 0..15
+        *reinterpret_cast<u32x2*>(s_pool + (wave * 16 + mc) * 128 + c16 * 8) = u32x2{Tr::cvt2(m[0], m[1]), Tr::cvt2(m[2], m[3])};
       }
     __syncthreads();
     {
@@ -390,16 +399,16 @@ void stem2_pack_w1(const float* hwio, int dtype, std::vector<uint16_t>* frags) {
       }
 }
 
-// LDS image of the conv1_2 weights for stem2_kernel from the HWIO [3,3,64,64] filter: tap-major, row (j*32 + r) of a tap
-// holds output channel 2r + j, 64 input channels = 8 chunks of 16 B, chunk c in slot c ^ ((row >> 1) & 7).
+// LDS image of the conv1_2 weights for stem2_kernel from the HWIO [3,3,64,64] filter: tap-major, row (j*16 + c) of a tap
+// holds output channel 4c + j, 64 input channels = 8 chunks of 16 B, chunk k in slot k ^ (((row >> 1) & 3) << 1).
 void stem2_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* img) {
   img->assign(9 * 64 * 64, 0);
   for (int tap = 0; tap < 9; ++tap)
     for (int row = 0; row < 64; ++row) {
-      const int j = row / 32, r = row % 32, ch = 2 * r + j;
+      const int j = row / 16, c = row % 16, ch = 4 * c + j;
       for (int cin = 0; cin < 64; ++cin) {
         const float v = hwio[((size_t)tap * 64 + cin) * 64 + ch];
-        const int chunk = cin / 8, slot = chunk ^ ((row >> 1) & 7);
+        const int chunk = cin / 8, slot = chunk ^ (((row >> 1) & 3) << 1);
         (*img)[((size_t)tap * 64 + row) * 64 + slot * 8 + cin % 8] = dtype == RON_DTYPE_BF16 ? f32_to_bf16_rne(v) : f32_to_f16_rne(v);
       }
     }
