@@ -44,7 +44,16 @@ typedef enum {
 
 /* REDUCEDFC / FULL: RON-320 bodies (nets/ron_vgg_320.py:510-580 / :434-508); SSD512: nets/ssd_vgg_512.py:364-460 */
 typedef enum { RON_VARIANT_REDUCEDFC = 0, RON_VARIANT_FULL = 1, RON_VARIANT_SSD512 = 2 } ron_variant;
-typedef enum { RON_DTYPE_F32 = 0, RON_DTYPE_BF16 = 1, RON_DTYPE_F16 = 2 } ron_dtype;
+/* Arithmetic of the conv stack (activations + weights in HBM, what the MFMAs consume); accumulation is fp32 in all of them.
+ *   F32   : v_mfma_f32_16x16x4_f32, exact fp32 products (parity mode, 157 TFLOP/s matrix peak)
+ *   BF16  : v_mfma_f32_16x16x32_bf16 (benchmark mode of BASELINE config 2)
+ *   F16   : v_mfma_f32_16x16x32_f16
+ *   F16X3 : split precision -- every value is stored as two f16 planes hi = rnd(v), lo = rnd(v - hi) (22 mantissa bits,
+ *           4 bytes per element: 32 hi followed by 32 lo per 128-byte channel chunk) and a product is three f16 MFMAs
+ *           hi*hi + lo*hi + hi*lo into the fp32 accumulator (the dropped lo*lo term is 2^-22 relative); weights carry a
+ *           per-layer power-of-two scale (undone in the epilogue) so that their lo plane stays a normal f16.  fp32-grade
+ *           head tensors (detections within 1e-4 of the fp32 CPU reference) at a third of the f16 matrix peak. */
+typedef enum { RON_DTYPE_F32 = 0, RON_DTYPE_BF16 = 1, RON_DTYPE_F16 = 2, RON_DTYPE_F16X3 = 3 } ron_dtype;
 
 const char* ron_last_error(void);
 /* ABI version of the library (bumped on any signature change). */

@@ -242,3 +242,11 @@ def round_bf16(a):
 
 def round_f16(a):
     return np.asarray(a, dtype=np.float16).astype(F32)
+
+
+def round_f16x3(a):
+    """hi + lo with hi = f16(a), lo = f16(a - hi): what a value keeps in the device's split-precision storage
+    (RON_DTYPE_F16X3, 22 mantissa bits), returned as float32."""
+    a = np.asarray(a, dtype=F32)
+    hi = a.astype(np.float16).astype(F32)
+    return hi + (a - hi).astype(np.float16).astype(F32)

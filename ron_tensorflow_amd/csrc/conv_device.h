@@ -42,6 +42,7 @@ struct ConvArgs {
   int out_Hp, out_Wp, out_cstride, out_pad, out_coff;
   int up, up_cout;
   int relu, out_f32;
+  float oscale;                             // accumulator * oscale + bias (2^-k of the weight scale in split-precision mode, else 1)
   int tiles_n;
   // split-K: workgroup z of `splitk` covers K steps [z*kt_split, (z+1)*kt_split) and stores raw fp32 sums to
   // partial[z][m][n] (n < Npad); splitk_finalize_kernel adds the slabs and applies the epilogue.
@@ -167,6 +168,73 @@ struct TraitsF32S : TraitsF32 {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
   }
 };
+// Split precision (RON_DTYPE_F16X3): an element is two f16 planes, hi = rnd(v) and lo = rnd(v - hi); a 128-byte row chunk holds
+// 32 elements as [32 x hi][32 x lo].  The K loop sees 4-byte elements like the fp32 mode (same addressing, 32 elements per
+// staging step); k-step 0 of a stage reads the hi fragments (16-byte slots 0..3), k-step 1 the lo fragments (slots 4..7), and
+// the products are hi*hi in k-step 0, lo*hi + hi*lo in k-step 1 (mma_step below) -- three v_mfma_f32_16x16x32_f16 per
+// 16 x 16 x 32 block into one fp32 accumulator.  hi*hi is exact in the matrix core (11 x 11 bits), the dropped lo*lo term is
+// 2^-22 of the product.  Element index i of a tensor -> f16 index (i / 32) * 64 + i % 32 (+ 32 for the lo plane): pixel
+// strides and channel slices are multiples of 32 elements everywhere.
+struct TraitsF16X3S {
+  typedef f32x4 acc_t;
+  static constexpr int kMT = 16;
+  static constexpr int kEsz = 4;
+  static constexpr int kMfmaPerMma = 1;
+  static constexpr bool kSplit = true;
+  static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int hidx(int i) { return ((i >> 5) << 6) + (i & 31); }
+  static __device__ __forceinline__ float load(const void* p, int i) {
+    const _Float16* h = reinterpret_cast<const _Float16*>(p) + hidx(i);
+    return (float)h[0] + (float)h[32];
+  }
+  static __device__ __forceinline__ void store(void* p, int i, float v) {
+    _Float16* h = reinterpret_cast<_Float16*>(p) + hidx(i);
+    const _Float16 hi = (_Float16)v;
+    h[0] = hi;
+    h[32] = (_Float16)(v - (float)hi);
+  }
+  template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
+    static_assert(32 % N == 0, "a vector must not straddle a 32-element chunk");
+    EVec<_Float16, N> hi, lo;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      hi.v[j] = (_Float16)v[j];
+      lo.v[j] = (_Float16)(v[j] - (float)hi.v[j]);
+    }
+    _Float16* h = reinterpret_cast<_Float16*>(p) + hidx(i);
+    *reinterpret_cast<EVec<_Float16, N>*>(h) = hi;
+    *reinterpret_cast<EVec<_Float16, N>*>(h + 32) = lo;
+  }
+  template <int N> static __device__ __forceinline__ void load_vec(const void* p, int i, float* v) {
+    const _Float16* h = reinterpret_cast<const _Float16*>(p) + hidx(i);
+    const EVec<_Float16, N> hi = *reinterpret_cast<const EVec<_Float16, N>*>(h);
+    const EVec<_Float16, N> lo = *reinterpret_cast<const EVec<_Float16, N>*>(h + 32);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = (float)hi.v[j] + (float)lo.v[j];
+  }
+};
+
+template <class Tr, class = void> struct IsSplit { static constexpr bool value = false; };
+template <class Tr> struct IsSplit<Tr, decltype((void)Tr::kSplit)> { static constexpr bool value = Tr::kSplit; };
+// MFMA instructions one (row tile, column tile) pair issues in k-step s of a stage
+template <class Tr> constexpr int mfma_in_step(int s) { return IsSplit<Tr>::value ? (s == 0 ? 1 : 2) : Tr::kMfmaPerMma; }
+// k-step s of a stage for the pair (i, j); fa / fb: the two fragment register sets (set s & 1 was read for k-step s)
+template <class Tr, int MR, int NR>
+__device__ __forceinline__ void mma_step(int s, const u32x4 (&fa)[2][MR], const u32x4 (&fb)[2][NR], int i, int j, typename Tr::acc_t& c) {
+  if constexpr (IsSplit<Tr>::value) {
+    if (s == 0) {
+      Tr::mma(fa[0][i], fb[0][j], c);      // hi * hi
+    } else {
+      Tr::mma(fa[1][i], fb[0][j], c);      // lo * hi
+      Tr::mma(fa[0][i], fb[1][j], c);      // hi * lo
+    }
+  } else {
+    Tr::mma(fa[s & 1][i], fb[s & 1][j], c);
+  }
+}
+
 template <class Tr> struct SmallShape;
 template <> struct SmallShape<TraitsBF16> { typedef TraitsBF16S type; };
 template <> struct SmallShape<TraitsF16> { typedef TraitsF16S type; };
@@ -203,7 +271,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, typename Tr::ac
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
           const float mx = fmaxf(fmaxf(acc[i][j][4 * t], acc[i][j][4 * t + 1]), fmaxf(acc[i][j][4 * t + 2], acc[i][j][4 * t + 3]));
-          v[j] = mx + bias_v[j];
+          v[j] = fmaf(mx, p.oscale, bias_v[j]);
           if (p.relu) v[j] = fmaxf(v[j], 0.f);
         }
         const int o = ooff + n_store;
@@ -227,7 +295,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, typename Tr::ac
       float v[NR];
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        v[j] = acc[i][j][e] + bias_v[j];
+        v[j] = fmaf(acc[i][j][e], p.oscale, bias_v[j]);
         if (p.relu) v[j] = fmaxf(v[j], 0.f);
       }
       if (n_valid >= NR) {
@@ -270,6 +338,7 @@ inline void fill_conv_args(const ConvLaunch& c, ConvArgs* out) {
   a.out_coff = c.out.coff;
   a.up = c.up; a.up_cout = c.up_cout;
   a.relu = c.relu; a.out_f32 = c.out_f32;
+  a.oscale = c.oscale;
   a.Npad = c.Npad;
   a.splitk = 1; a.kt_split = a.KT; a.partial = nullptr;
   a.pool = c.pool;

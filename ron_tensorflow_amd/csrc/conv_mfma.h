@@ -35,6 +35,7 @@ struct ConvLaunch {
   int64_t wgt_bytes = 0;
   const void* wgt_c64 = nullptr; // the same weights as LDS images for the resident-weight kernel (conv_c64.hip), or null
   const float* bias = nullptr;   // [Npad] fp32 (never null; zeros when the layer has none)
+  float oscale = 1.f;            // out = acc * oscale + bias: 2^-k of the packed weights' scale (RON_DTYPE_F16X3), else 1
   int Cout = 0;                  // GEMM N that is stored (<= Npad)
   int Npad = 0;                  // rows of wgt, multiple of the N tile
   int kh = 1, kw = 1, stride = 1, dil = 1, cpad = 0;
@@ -117,6 +118,7 @@ int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64
 int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg);
 constexpr int kMaxConvGroup = 8;
 size_t dtype_size(int dtype);
+inline bool dtype_is_half(int dtype) { return dtype == RON_DTYPE_BF16 || dtype == RON_DTYPE_F16; }   // 2-byte elements
 
 // conv1_1 (stem.hip): 3 -> 64 channels straight from the fp32 image, bf16 / f16 only
 void stem_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* frags);

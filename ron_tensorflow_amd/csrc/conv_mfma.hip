@@ -27,6 +27,30 @@ namespace detail {
 // its N youngest LDS-DMA transfers landed
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
+// Issue order of the k-steps s, s+1, ... of one stage (see the K loop): per k-step its MFMAs, the next k-step's RD fragment
+// reads one per MFMA gap, its share of the stage's LPT LDS-DMA pieces spaced evenly between them.  Everything is a
+// compile-time constant (the builtin wants immediates); the split-precision traits issue 1 MFMA per pair in k-step 0, 2 in 1.
+template <class Tr, int MR, int NR, int KS, int LPT, int SPREAD, int s>
+__device__ __forceinline__ void pin_ksteps() {
+  if constexpr (s < KS) {
+    constexpr int RD = MR + NR, MM = MR * NR * mfma_in_step<Tr>(s);
+    constexpr int first = SPREAD == 2 ? 0 : (s * LPT + KS - 1) / KS;                       // pieces [first, last) go out in k-step s
+    constexpr int last = SPREAD == 2 ? (s == 0 ? LPT : 0) : ((s + 1) * LPT + KS - 1) / KS;
+    constexpr int ps = last - first;
+#pragma unroll
+    for (int q2 = 0; q2 < MM; ++q2) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (s < KS - 1 && q2 < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (((q2 + 1) * ps) / MM > (q2 * ps) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    if constexpr (s < KS - 1 && RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+      if (x < ps - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    pin_ksteps<Tr, MR, NR, KS, LPT, SPREAD, s + 1>();
+  }
+}
+
 // Tile configuration: BM x BN block tile, WM x WN waves (each wave owns (BM/WM) x (BN/WN)), S LDS stages.
 // SPREAD 1: the LDS-DMA pieces of a tile are shared out over the k-steps of the stage; 2: all go out during k-step 0.
 // EXP (experimental builds only, make EXP=1): 1 = the A descriptor has no records (only the weights move), 2 = the B
@@ -256,31 +280,13 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
-        for (int j = 0; j < NR; ++j) Tr::mma(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
+        for (int j = 0; j < NR; ++j) mma_step<Tr, MR, NR>(s, fa, fb, i, j, acc[i][j]);
     }
     // Pin the issue order (hipcc otherwise sinks the next k-step's fragment reads below the MFMAs to save
     // registers): R0 | per k-step: MFMAs with the next k-step's reads one per MFMA gap and this k-step's LDS-DMA pieces
     // spaced evenly between them | MFMAs of the last k-step.
-    {
-      constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma;
-      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int first = SPREAD == 2 ? 0 : (s * LPT + KS - 1) / KS;                       // pieces [first, last) go out in k-step s
-        const int last = SPREAD == 2 ? (s == 0 ? LPT : 0) : ((s + 1) * LPT + KS - 1) / KS;
-        const int ps = last - first;
-#pragma unroll
-        for (int q2 = 0; q2 < MM; ++q2) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (s < KS - 1 && q2 < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (((q2 + 1) * ps) / MM > (q2 * ps) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        if (s < KS - 1 && RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
-#pragma unroll
-        for (int x = 0; x < 16; ++x)
-          if (x < ps - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-    }
+    __builtin_amdgcn_sched_group_barrier(0x100, MR + NR, 0);
+    pin_ksteps<Tr, MR, NR, KS, LPT, SPREAD, 0>();
     RON_STAGE_END();
   }
 #undef RON_STAGE_BEGIN
@@ -395,7 +401,7 @@ __device__ __forceinline__ void splitk_finalize_body(const ConvArgs& p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (n + j >= p.Cout) break;
-      float v = sum[j] + p.bias[n + j];
+      float v = fmaf(sum[j], p.oscale, p.bias[n + j]);
       if (p.relu) v = fmaxf(v, 0.f);
       if (p.res != nullptr) v = fmaxf(v + Tr::load(p.res, o + j), 0.f);
       if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = v;
@@ -478,7 +484,7 @@ int launch_finalize(const ConvArgs& a, hipStream_t s) {
 }  // namespace detail
 using namespace detail;
 
-size_t dtype_size(int dtype) { return dtype == RON_DTYPE_F32 ? 4 : 2; }
+size_t dtype_size(int dtype) { return dtype_is_half(dtype) ? 2 : 4; }     // F16X3: a hi and a lo f16 per element
 int conv_k_chunk(int dtype) { return kRowBytes / (int)dtype_size(dtype); }
 int conv_n_tile(int cout) { return cout <= 64 ? 64 : 128; }
 int conv_num_cfgs() { return kNumCfgsBuilt; }
@@ -583,10 +589,12 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   if (c.dtype == RON_DTYPE_BF16) rc = launch_cfg<TraitsBF16S>(cfg, a, stream);
   else if (c.dtype == RON_DTYPE_F16) rc = launch_cfg<TraitsF16S>(cfg, a, stream);
   else if (c.dtype == RON_DTYPE_F32) rc = launch_cfg<TraitsF32S>(cfg, a, stream);
+  else if (c.dtype == RON_DTYPE_F16X3) rc = launch_cfg<TraitsF16X3S>(cfg, a, stream);
   else { ron::set_error("conv: unknown dtype %d", c.dtype); return RON_ERR_INVALID; }
   if (rc != RON_OK || a.splitk == 1) return rc;
   if (c.dtype == RON_DTYPE_BF16) return launch_finalize<TraitsBF16S>(a, stream);
   if (c.dtype == RON_DTYPE_F16) return launch_finalize<TraitsF16S>(a, stream);
+  if (c.dtype == RON_DTYPE_F16X3) return launch_finalize<TraitsF16X3S>(a, stream);
   return launch_finalize<TraitsF32S>(a, stream);
 }
 
@@ -686,6 +694,7 @@ int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64
   if (ls[0].dtype == RON_DTYPE_BF16) return launch_group_cfg<TraitsBF16S>(cfg, g, any_split, stream);
   if (ls[0].dtype == RON_DTYPE_F16) return launch_group_cfg<TraitsF16S>(cfg, g, any_split, stream);
   if (ls[0].dtype == RON_DTYPE_F32) return launch_group_cfg<TraitsF32S>(cfg, g, any_split, stream);
+  if (ls[0].dtype == RON_DTYPE_F16X3) return launch_group_cfg<TraitsF16X3S>(cfg, g, any_split, stream);
   ron::set_error("conv group: unknown dtype %d", ls[0].dtype);
   return RON_ERR_INVALID;
 }

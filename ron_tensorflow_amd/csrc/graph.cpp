@@ -53,6 +53,7 @@ struct PackedConv {
   int64_t w_bytes = 0;
   void* d_w_c64 = nullptr;    // 3x3 on 64 input channels (conv2_1): the weights once more as LDS images for conv_c64.hip
   float* d_bias = nullptr;
+  float oscale = 1.f;         // accumulator scale of the epilogue (split-precision weights are stored times a power of two)
   int Npad = 0, Cout = 0;
 };
 
@@ -250,12 +251,12 @@ struct Rows {
 
 int upload(ron_ctx* c, const Rows& r, int cout) {
   PackedConv p;
-  std::vector<uint8_t> bytes = pack_conv_weights(r.w, r.npad, c->cfg.dtype);
+  std::vector<uint8_t> bytes = pack_conv_weights(r.w, r.npad, c->cfg.dtype, &p.oscale);
   p.w_bytes = (int64_t)bytes.size();
   p.Npad = r.npad; p.Cout = cout;
   RON_HIP_CHECK(hipMalloc(&p.d_w, bytes.size()));
   RON_HIP_CHECK(hipMemcpy(p.d_w, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
-  if (c->cfg.dtype != RON_DTYPE_F32 && r.kh == 3 && r.kw == 3 && r.cin == 64 && r.npad == cout && cout % 64 == 0) {
+  if (dtype_is_half(c->cfg.dtype) && r.kh == 3 && r.kw == 3 && r.cin == 64 && r.npad == cout && cout % 64 == 0) {
     const std::vector<uint8_t> img = pack_conv_c64_weights(r.w, r.npad, c->cfg.dtype);
     RON_HIP_CHECK(hipMalloc(&p.d_w_c64, img.size()));
     RON_HIP_CHECK(hipMemcpy(p.d_w_c64, img.data(), img.size(), hipMemcpyHostToDevice));
@@ -512,7 +513,7 @@ double conv_flops(const Var& w, int out_pixels) { return 2.0 * (double)w.numel()
 extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
   RON_REQUIRE(out && cfg, "NULL argument");
   RON_REQUIRE(cfg->variant >= RON_VARIANT_REDUCEDFC && cfg->variant <= RON_VARIANT_SSD512, "unknown variant %d", cfg->variant);
-  RON_REQUIRE(cfg->dtype >= 0 && cfg->dtype <= 2, "unknown dtype %d", cfg->dtype);
+  RON_REQUIRE(cfg->dtype >= 0 && cfg->dtype <= RON_DTYPE_F16X3, "unknown dtype %d", cfg->dtype);
   RON_REQUIRE(cfg->img_h > 0 && cfg->img_h % 64 == 0 && cfg->img_w > 0 && cfg->img_w % 64 == 0, "image size must be a multiple of 64");
   if (cfg->variant == RON_VARIANT_SSD512) RON_REQUIRE(cfg->img_h == 512 && cfg->img_w == 512, "SSD-512 runs on 512 x 512 inputs");
   RON_REQUIRE(cfg->num_classes >= 2 && cfg->num_classes <= 64, "num_classes out of range");
@@ -558,9 +559,9 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
   }
   }
   for (auto& t : c->tensors) {
-    if (t.name == "im2col" && cfg->dtype != RON_DTYPE_F32) continue;      // bf16 / f16 use the stem kernel
+    if (t.name == "im2col" && dtype_is_half(cfg->dtype)) continue;      // bf16 / f16 use the stem kernel
     if ((cfg->flags & RON_CFG_FUSE_POOLS) && (t.name == "conv1_2" || t.name == "conv2_2" || t.name == "conv3_3")) continue;
-    if ((cfg->flags & RON_CFG_FUSE_POOLS) && !(cfg->flags & RON_CFG_NO_STEM2) && cfg->dtype != RON_DTYPE_F32 && H % 8 == 0 &&
+    if ((cfg->flags & RON_CFG_FUSE_POOLS) && !(cfg->flags & RON_CFG_NO_STEM2) && dtype_is_half(cfg->dtype) && H % 8 == 0 &&
         W % 32 == 0 && t.name == "conv1_1") continue;         // conv1_1 + conv1_2 + pool1 run fused (stem2_kernel)
     t.bytes = TensorView::halo_pixels(cfg->max_batch, t.H, t.W, t.pad) * t.cstride * c->esz();     // shared halos, conv_mfma.h
     if (t.bytes >= ((int64_t)1 << 32)) {
@@ -668,7 +669,7 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
 #define ATTR() do { c->ops.back().flops += flops - mark; mark = flops; } while (0)
 #define PACK(expr) do { rc = (expr); if (rc < 0) return rc; } while (0)
   // ---- VGG-16 body ----
-  const bool use_stem = c->cfg.dtype != RON_DTYPE_F32;
+  const bool use_stem = dtype_is_half(c->cfg.dtype);      // fp32 / split precision: conv1_1 as im2col + GEMM
   if (!use_stem) {
     Op o; o.kind = OP_IM2COL; o.name = "im2col"; o.out = T("im2col");
     c->ops.push_back(o);
@@ -921,7 +922,7 @@ static int describe_conv(const ron_ctx* c, const Op& o, int n, const ron_heads* 
     L.out = c->view(o.out, n, o.out_coff, o.out_C > 0 ? o.out_C : -1);
   }
   L.res = o.res >= 0 ? c->tensors[o.res].d : nullptr;
-  L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.wgt_c64 = p.d_w_c64; L.bias = p.d_bias; L.Cout = p.Cout; L.Npad = p.Npad;
+  L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.wgt_c64 = p.d_w_c64; L.bias = p.d_bias; L.oscale = p.oscale; L.Cout = p.Cout; L.Npad = p.Npad;
   L.kh = o.kh; L.kw = o.kw; L.stride = o.stride; L.dil = o.dil; L.cpad = o.cpad; L.relu = o.relu;
   L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo; L.pool = o.pool;
   L.scratch = c->d_splitk[o.lane]; L.scratch_bytes = c->splitk_bytes[o.lane];

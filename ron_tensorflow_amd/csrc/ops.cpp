@@ -38,7 +38,7 @@ struct ConvSetup {
 // Packs weights like ron_finalize_weights does, uploads them and allocates the halo tensors.
 int setup_conv(const ron_conv_desc* d, const float* w, const float* bias, bool with_residual, ConvSetup* S) {
   using namespace ron;
-  RON_REQUIRE(d->dtype >= 0 && d->dtype <= 2, "bad dtype");
+  RON_REQUIRE(d->dtype >= 0 && d->dtype <= RON_DTYPE_F16X3, "bad dtype");
   const int esz = (int)dtype_size(d->dtype);
   const int chunk = conv_k_chunk(d->dtype);
   S->is_c3 = (!d->transpose && d->cin == 3 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dilation == 1);
@@ -86,14 +86,14 @@ int setup_conv(const ron_conv_desc* d, const float* w, const float* bias, bool w
   }
   c.Cout = cout_gemm;
   c.relu = d->relu;
-  std::vector<uint8_t> wbytes = pack_conv_weights(rows, c.Npad, d->dtype);
+  std::vector<uint8_t> wbytes = pack_conv_weights(rows, c.Npad, d->dtype, &c.oscale);
   int rc;
   if ((rc = S->d_w.alloc((int64_t)wbytes.size(), false))) return rc;
   if ((rc = S->d_b.alloc((int64_t)bias_pad.size() * 4, false))) return rc;
   RON_HIP_CHECK(hipMemcpy(S->d_w.p, wbytes.data(), wbytes.size(), hipMemcpyHostToDevice));
   RON_HIP_CHECK(hipMemcpy(S->d_b.p, bias_pad.data(), bias_pad.size() * 4, hipMemcpyHostToDevice));
   c.wgt = S->d_w.p; c.wgt_bytes = (int64_t)wbytes.size(); c.bias = (const float*)S->d_b.p;
-  if (!d->transpose && !S->is_c3 && d->dtype != RON_DTYPE_F32 && d->kh == 3 && d->kw == 3 && d->cin == 64 && c.Npad == d->cout && d->cout % 64 == 0) {
+  if (!d->transpose && !S->is_c3 && dtype_is_half(d->dtype) && d->kh == 3 && d->kw == 3 && d->cin == 64 && c.Npad == d->cout && d->cout % 64 == 0) {
     // what ron_finalize_weights adds for such a layer: the weights once more as LDS images for the resident-weight kernel
     const std::vector<uint8_t> img = pack_conv_c64_weights(rows, c.Npad, d->dtype);
     if ((rc = S->d_w_c64.alloc((int64_t)img.size(), false))) return rc;
@@ -112,7 +112,9 @@ int setup_conv(const ron_conv_desc* d, const float* w, const float* bias, bool w
   c.in.base = S->d_in.p;
   c.pool = d->pool;
   if (d->pool) { S->ho /= 2; S->wo /= 2; }
-  c.out = make_view(nullptr, d->n, S->ho, S->wo, d->cout, 1, esz);   // halo 1: exercises padded stores
+  // halo 1: exercises padded stores.  Split precision: pixels are whole 32-element (128-byte) chunks
+  c.out = make_view(nullptr, d->n, S->ho, S->wo, d->dtype == RON_DTYPE_F16X3 ? round_up(d->cout, 32) : d->cout, 1, esz);
+  c.out.C = d->cout;
   if ((rc = S->d_out.alloc(c.out.bytes, true))) return rc;
   c.out.base = S->d_out.p;
   if (with_residual) {
@@ -139,7 +141,7 @@ extern "C" int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const flo
   ConvSetup S;
   int rc;
   if ((rc = setup_conv(d, w, bias, residual != nullptr, &S))) return rc;
-  if (S.is_c3 && d->dtype != RON_DTYPE_F32 && d->cout == 64 && d->w % 32 == 0 && d->relu && !residual) {
+  if (S.is_c3 && dtype_is_half(d->dtype) && d->cout == 64 && d->w % 32 == 0 && d->relu && !residual) {
     // conv1_1 through the dedicated stem kernel (what the graph runs for bf16 / f16)
     std::vector<uint16_t> frags;
     stem_pack_weights(w, d->dtype, &frags);

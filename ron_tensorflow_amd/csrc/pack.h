@@ -1,6 +1,7 @@
 // Host-side weight packing: TF layouts (HWIO conv, [kh,kw,Cout,Cin] transposed conv) -> the
 // [Npad][K] K-contiguous rows the implicit-GEMM kernel streams, rounded to the ctx dtype.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -37,6 +38,33 @@ static inline std::vector<uint8_t> cast_rows(const std::vector<float>& rows, int
 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
+// RON_DTYPE_F16X3: power-of-two scale 2^k that brings the largest |w| of a layer into [2^14, 2^15): the hi plane stays below the
+// f16 maximum (65504) and the lo plane of every weight down to 2^-17 of the largest one is a normal f16 (full 22 bits).
+static inline int split_weight_exponent(const std::vector<float>& rows) {
+  float mx = 0.f;
+  for (float v : rows) mx = fmaxf(mx, fabsf(v));
+  if (!(mx > 0.f) || !isfinite(mx)) return 0;
+  int e;
+  frexpf(mx, &e);                     // mx = m * 2^e, m in [0.5, 1)
+  const int k = 15 - e;               // mx * 2^k in [2^14, 2^15)
+  return k < -40 ? -40 : (k > 60 ? 60 : k);
+}
+
+// rows: fp32 [npad][k], k % 32 == 0 -> split-precision bytes: per 32 elements [32 x f16 hi][32 x f16 lo] of w * 2^k
+static inline std::vector<uint8_t> split_rows(const std::vector<float>& rows, int k) {
+  std::vector<uint8_t> out(rows.size() * 4);
+  uint16_t* o = reinterpret_cast<uint16_t*>(out.data());
+  for (size_t i = 0; i < rows.size(); ++i) {
+    const float v = ldexpf(rows[i], k);
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const size_t at = (i / 32) * 64 + i % 32;
+    memcpy(&o[at], &hi, 2);
+    memcpy(&o[at + 32], &lo, 2);
+  }
+  return out;
+}
+
 // Row-major [npad][K] bytes -> 64-row x 128-byte blocks [npad / 64][K steps][64][128 B] (npad % 64 == 0, K * esz % 128 == 0):
 // the (64 rows, one K step) unit both conv kernels stage is 8 KB of consecutive memory, so a wave's LDS-DMA instruction
 // (8 rows x 128 B) reads one contiguous kilobyte instead of eight lines that are K * esz bytes apart.
@@ -49,13 +77,20 @@ static inline std::vector<uint8_t> block_rows(const std::vector<uint8_t>& rows, 
   return out;
 }
 
-// fp32 rows [npad][K] -> what the conv kernels read: rounded to the dtype, blocked
-static inline std::vector<uint8_t> pack_conv_weights(const std::vector<float>& rows, int npad, int dtype) {
+// fp32 rows [npad][K] -> what the conv kernels read: rounded to the dtype, blocked.  *oscale = what the epilogue multiplies the
+// accumulator by (1, or 2^-k in split-precision mode where the packed weights are w * 2^k).
+static inline std::vector<uint8_t> pack_conv_weights(const std::vector<float>& rows, int npad, int dtype, float* oscale) {
+  *oscale = 1.f;
 #ifdef RON_DIAG      // libron_hip_diag.so: the round-1 kernels of csrc/diag read row-major weights
   (void)npad;
   return cast_rows(rows, dtype);
 #else
   const int64_t K = (int64_t)(rows.size() / (size_t)npad);
+  if (dtype == RON_DTYPE_F16X3) {
+    const int k = split_weight_exponent(rows);
+    *oscale = ldexpf(1.f, -k);
+    return block_rows(split_rows(rows, k), npad, K * 4);
+  }
   return block_rows(cast_rows(rows, dtype), npad, K * (int64_t)dtype_size(dtype));
 #endif
 }

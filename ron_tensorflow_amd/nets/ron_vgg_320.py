@@ -5,7 +5,7 @@
 tensor op runs as HIP kernels through libron_hip.so; tensors are torch CUDA tensors (device containers).
 
 Additions: ``variant`` ('reducedfc' = what the reference's RONNet.net builds, :144; 'full' = ron_net,
-reachable in the reference through nets_factory.get_network_fn), ``dtype`` ('bf16' | 'fp16' | 'fp32'),
+reachable in the reference through nets_factory.get_network_fn), ``dtype`` ('bf16' | 'fp16' | 'fp32' | 'f16x3' = split precision: fp32-grade results on the f16 matrix cores),
 ``load_weights`` (dict keyed by TF variable names) and the fused ``detect``.
 """
 import contextlib

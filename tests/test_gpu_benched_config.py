@@ -17,17 +17,30 @@ import torch
 from oracle import anchors as oanchors
 from oracle import np_post
 from oracle import ron_forward as orf
+from parity_record import record
 
 pytestmark = pytest.mark.gpu
 
 BATCH = 32
-CHECK = (0, 17)            # images of the batch the oracle recomputes
-TOL = 0.04                 # bf16: fraction of the tensor's max magnitude (test_forward_reduced_precision)
+# images of the batch the oracle recomputes: the first, one in the middle and the LAST one -- the ragged last tiles of every
+# launch (block6 / block7: M = 3 200 = 12.5 tiles of 256; the 5 x 5 heads: M = 800) belong to the last image
+CHECK = (0, 17, 31)
+
+# Bounds = 2 x the error measured on MI355X (profiles/r03/parity_errors.json, same keys; fraction of the tensor's max
+# magnitude).  A key without an entry falls back to the blanket tolerance of its dtype.
+BLANKET = {'bf16': 0.04, 'fp16': 0.006, 'ssd_cls': 0.05, 'ssd_loc': 0.08}
+BOUNDS = {}
 
 
 def _rel(got, ref):
     assert got.shape == ref.shape, (got.shape, ref.shape)
     return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+
+
+def _check(key, got, ref, blanket):
+    """records the achieved error under `key` and asserts it against BOUNDS[key] (2 x the committed measurement)"""
+    err = record(key, _rel(got, ref))
+    assert err < BOUNDS.get(key, BLANKET[blanket]), (key, err, BOUNDS.get(key, BLANKET[blanket]))
 
 
 @pytest.fixture(scope='module')
@@ -77,7 +90,7 @@ def test_end_points_vs_oracle(run, oracle_bf16, slot):
                       ('block4_ref', 'block4_ref'), ('block7_ref', 'block7_ref')):
         got = s.end_point(name, BATCH).cpu().numpy()
         for i in CHECK:
-            assert _rel(got[i:i + 1], oracle_bf16[i][1][key]) < TOL, (name, i)
+            _check('cfg2/%s' % name, got[i:i + 1], oracle_bf16[i][1][key], 'bf16')
 
 
 def test_heads_vs_oracle(run, oracle_bf16):
@@ -86,9 +99,9 @@ def test_heads_vs_oracle(run, oracle_bf16):
     for i in CHECK:
         o = oracle_bf16[i][0]
         for l in range(4):
-            assert _rel(cls[l][i:i + 1].cpu().numpy(), o[1][l]) < TOL, ('cls', l, i)
-            assert _rel(obj[l][i:i + 1].cpu().numpy(), o[3][l]) < TOL, ('obj', l, i)
-            assert _rel(loc[l][i:i + 1].cpu().numpy(), o[4][l]) < TOL, ('loc', l, i)
+            _check('cfg2/cls%d' % l, cls[l][i:i + 1].cpu().numpy(), o[1][l], 'bf16')
+            _check('cfg2/obj%d' % l, obj[l][i:i + 1].cpu().numpy(), o[3][l], 'bf16')
+            _check('cfg2/loc%d' % l, loc[l][i:i + 1].cpu().numpy(), o[4][l], 'bf16')
 
 
 def test_pipeline_detections_equal_oracle_post_on_own_heads(run):
@@ -116,10 +129,55 @@ def test_bf16_vs_fp32_oracle_agreement(run):
         ref = np_post.detect_from_predictions(o[0], o[4], anchors, objness_pred=o[2])[0]
         a = detection_agreement(run['dets'][0][i], ref, tol=1e-4)
         rates.append(a)
+        record('cfg2/bf16_vs_fp32_oracle/not_reproduced', 1.0 - a['reproduced'])
+        record('cfg2/bf16_vs_fp32_oracle/max_score_diff', a['max_score_diff'])
+        record('cfg2/bf16_vs_fp32_oracle/max_box_diff', a['max_box_diff'])
         print('image %d: %s' % (i, a))
     # the bf16-rounded ORACLE reproduces 98 % of the fp32 oracle's detections on these images (max score diff 3e-3, box 9e-4)
     assert min(a['reproduced'] for a in rates) >= 0.90
     assert max(a['max_score_diff'] for a in rates) <= 0.02 and max(a['max_box_diff'] for a in rates) <= 0.01
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# north_star's tolerance clause at speed: the split-precision mode ('f16x3') at config 2's size
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config2_f16x3_detections_within_1e4_of_fp32_oracle():
+    """ron_net full, batch 32, dtype 'f16x3' (bench.py --dtype f16x3), two slots through DetectPipeline: for the first, a middle and
+    the last image of the batch >= 98 % of the fp32 oracle's detections (own conv stack + np_methods, /root/reference/nets/
+    ron_vgg_320.py:434-508 + nets/np_methods.py:23-242) are reproduced with the same class and anchor index, and ALL matched
+    scores and boxes are within 1e-4; head tensors within 2e-5 of their scale."""
+    from ron_tensorflow_amd import weights as W
+    from ron_tensorflow_amd.metrics import detection_agreement
+    from ron_tensorflow_amd.nets import nets_factory
+    from ron_tensorflow_amd.pipeline import DetectPipeline
+    weights = W.synthetic_weights('full', seed=1)
+    images = W.synthetic_images(BATCH, seed=3)
+    net = nets_factory.get_network('ron_320_vgg')(variant='full', dtype='f16x3', max_batch=BATCH, fuse_pools=True)
+    net.load_weights(weights)
+    x = torch.from_numpy(images).cuda()
+    pipe = DetectPipeline(net, slots=2, top_k=400)
+    args = dict(objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45)
+    dets = [t.wait().to_lists() for t in [pipe.submit(x, **args) for _ in range(2)]]
+    torch.cuda.synchronize()
+    for a, b in zip(dets[0], dets[1]):
+        assert np.array_equal(a['anchor_index'], b['anchor_index']) and np.array_equal(a['scores'], b['scores'])
+    cls, obj, loc = net.forward_heads(x)
+    anchors = oanchors.anchors_all_layers()
+    for i in CHECK:
+        o = orf.ron_forward(images[i:i + 1], weights, 'full', backend='torch')
+        for l in range(4):
+            for nm, g, r in (('cls', cls[l], o[1][l]), ('obj', obj[l], o[3][l]), ('loc', loc[l], o[4][l])):
+                assert record('cfg2_f16x3/%s%d' % (nm, l), _rel(g[i:i + 1].cpu().numpy(), r)) < 2e-5, (nm, l, i)
+        ref = np_post.detect_from_predictions(o[0], o[4], anchors, objness_pred=o[2])[0]
+        a = detection_agreement(dets[0][i], ref, tol=1e-4)
+        print('image %d: %s' % (i, a))
+        record('cfg2_f16x3/not_reproduced', 1.0 - a['reproduced'])
+        record('cfg2_f16x3/max_score_diff', a['max_score_diff'])
+        record('cfg2_f16x3/max_box_diff', a['max_box_diff'])
+        assert a['reproduced'] >= 0.98 and a['within_tol'] == 1.0, a
+        assert a['max_score_diff'] <= 1e-4 and a['max_box_diff'] <= 1e-4, a
+    pipe.close()
+    net.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -142,16 +200,16 @@ def test_config4_reducedfc_fp16_batch64_vs_oracle():
     for a, b in zip(dets[0], dets[1]):
         assert np.array_equal(a['anchor_index'], b['anchor_index']) and np.array_equal(a['scores'], b['scores'])
     cls, obj, loc = net.forward_heads(x)
-    for i in (5, 63):
+    for i in (5, 63):                       # 63 = the last image: the ragged last tiles
         col = {}
         o = orf.ron_forward(images[i:i + 1], weights, 'reducedfc', backend='torch', round_fn=orf.round_f16, collect=col)
         col.update(o[5])
         for l in range(4):
-            assert _rel(cls[l][i:i + 1].cpu().numpy(), o[1][l]) < 0.006, ('cls', l, i)
-            assert _rel(obj[l][i:i + 1].cpu().numpy(), o[3][l]) < 0.006, ('obj', l, i)
-            assert _rel(loc[l][i:i + 1].cpu().numpy(), o[4][l]) < 0.006, ('loc', l, i)
+            _check('cfg4/cls%d' % l, cls[l][i:i + 1].cpu().numpy(), o[1][l], 'fp16')
+            _check('cfg4/obj%d' % l, obj[l][i:i + 1].cpu().numpy(), o[3][l], 'fp16')
+            _check('cfg4/loc%d' % l, loc[l][i:i + 1].cpu().numpy(), o[4][l], 'fp16')
         for name in ('pool1', 'block4', 'block6', 'block7', 'block5_ref'):
-            assert _rel(net.end_point(name, 64).cpu().numpy()[i:i + 1], col[name]) < 0.006, (name, i)
+            _check('cfg4/%s' % name, net.end_point(name, 64).cpu().numpy()[i:i + 1], col[name], 'fp16')
     pipe.close()
     net.close()
 
@@ -170,11 +228,11 @@ def test_config5_ssd512_bf16_batch16_vs_oracle():
     logits, _, loc = net.forward_heads(x)
     det = net.detect(x, select_threshold=0.01, nms_threshold=0.45).to_lists()
     anchors = osf.anchors_all_layers()
-    for i in (0, 15):
+    for i in (0, 15):                       # 15 = the last image
         ref = osf.ssd_forward(images[i:i + 1], weights, round_fn=orf.round_bf16, backend='torch')
         for l in range(7):
-            assert _rel(logits[l][i:i + 1].cpu().numpy(), ref[2][l]) < 0.05, ('cls', l, i)
-            assert _rel(loc[l][i:i + 1].cpu().numpy(), ref[1][l]) < 0.08, ('loc', l, i)
+            _check('cfg5/cls%d' % l, logits[l][i:i + 1].cpu().numpy(), ref[2][l], 'ssd_cls')
+            _check('cfg5/loc%d' % l, loc[l][i:i + 1].cpu().numpy(), ref[1][l], 'ssd_loc')
         # probabilities from the device softmax kernel (bit-identical to the one fused into the select kernel: numpy's may
         # differ in the last bit, which reorders near-ties among thousands of candidates)
         from ron_tensorflow_amd import ops

@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 
 from oracle import ron_forward as orf  # noqa: E402
 
-ROUND = {'fp32': lambda a: np.asarray(a, np.float32), 'bf16': orf.round_bf16, 'fp16': orf.round_f16}
-OUT_EPS = {'fp32': 2e-5, 'bf16': 2 ** -7, 'fp16': 2 ** -10}
+# f16x3 = split precision (two f16 planes per value, three f16 MFMAs per product): graded like fp32
+ROUND = {'fp32': lambda a: np.asarray(a, np.float32), 'bf16': orf.round_bf16, 'fp16': orf.round_f16, 'f16x3': orf.round_f16x3}
+OUT_EPS = {'fp32': 2e-5, 'bf16': 2 ** -7, 'fp16': 2 ** -10, 'f16x3': 2e-5}
 
 
 @pytest.fixture(scope='module')
@@ -47,7 +48,7 @@ CONV_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16', 'f16x3'])
 @pytest.mark.parametrize('shape', CONV_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
 def test_conv2d(ops, dev, shape, dtype):
     n, h, w, cin, cout, k, stride, rate = shape
@@ -63,7 +64,7 @@ def test_conv2d(ops, dev, shape, dtype):
     _check(got, ref, dtype)
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'f16x3'])
 def test_conv2d_no_relu_no_bias_and_residual(ops, dev, dtype):
     rs = np.random.RandomState(5)
     x = rs.randn(2, 10, 10, 128).astype(np.float32)
@@ -82,7 +83,7 @@ def test_conv2d_no_relu_no_bias_and_residual(ops, dev, dtype):
     _check(got, ref, dtype)
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16', 'f16x3'])
 def test_conv2d_transpose_2x2(ops, dev, dtype):
     rs = np.random.RandomState(6)
     x = rs.randn(2, 5, 5, 128).astype(np.float32)
@@ -96,7 +97,7 @@ def test_conv2d_transpose_2x2(ops, dev, dtype):
     _check(got, ref, dtype)
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16', 'f16x3'])
 @pytest.mark.parametrize('hw', [(16, 20), (12, 64), (7, 96)])
 def test_conv_stem_3_channels(ops, dev, dtype, hw):
     """conv1_1: width % 32 == 0 goes through the dedicated stem kernel (bf16 / f16), otherwise im2col + 1x1 GEMM."""
@@ -110,7 +111,7 @@ def test_conv_stem_3_channels(ops, dev, dtype, hw):
     _check(got, ref, dtype)
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16', 'f16x3'])
 def test_maxpool(ops, dev, dtype):
     rs = np.random.RandomState(8)
     x = ROUND[dtype](rs.randn(2, 8, 12, 64).astype(np.float32))
@@ -122,7 +123,7 @@ IGEMM_CFGS = [0, 1, 2, 3, 7]        # conv_mfma.h: 256x256, 128x128, 128x128 ear
 PATCH_CFGS = {256: 4, 128: 5, 64: 6}  # halo-patch kernel by N tile
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32', 'f16x3'])
 @pytest.mark.parametrize('cfg', IGEMM_CFGS)
 def test_every_tile_configuration(ops, dev, cfg, dtype):
     """Each tile configuration of the row-gather kernel on a ragged multi-tile problem, K = 18 steps.  The shipped library
@@ -163,9 +164,12 @@ def test_no_entry_accepts_a_configuration_it_cannot_run(ops, dev):
         ops.conv2d_nhwc(x, w3, None, dtype='bf16', tile_cfg=8)
     with pytest.raises(RonError):                                        # ... and it has no fp32 form
         ops.conv2d_nhwc(torch.zeros((1, 8, 32, 64), device=dev), w3, None, dtype='fp32', tile_cfg=8)
+    for cfg in (4, 5, 6, 8):                                             # split precision: the row-gather kernel only
+        with pytest.raises(RonError):
+            ops.conv2d_nhwc(torch.zeros((1, 8, 32, 64), device=dev), w3, None, dtype='f16x3', tile_cfg=cfg)
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'f16x3'])
 @pytest.mark.parametrize('splitk', [1, 2, 3, 7, -1])
 def test_split_k(ops, dev, dtype, splitk):
     """Small grid, long K (the 5x5 / 10x10 head layers): K loop spread over workgroups, slabs summed by a second kernel."""
@@ -186,7 +190,7 @@ def test_split_k(ops, dev, dtype, splitk):
         _check(got, ref, dtype)
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'f16x3'])
 @pytest.mark.parametrize('cfg', [-1, 0, 1, 3])
 def test_conv_with_fused_maxpool(ops, dev, dtype, cfg):
     """conv3x3 + bias + ReLU + 2x2/2 max-pool in one kernel == pool(conv) (nets/ron_vgg_320.py:454-466)."""
@@ -299,7 +303,7 @@ def test_resident_weight_kernel_conv3x3_c64(ops, dev, shape, dtype):
     _check(ops.conv2d_nhwc(xd, wt, None, relu=False, dtype=dtype, tile_cfg=8).cpu().numpy(), ref2, dtype)
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32', 'f16x3'])
 @pytest.mark.parametrize('cfg', [-1, 0, 1])
 def test_weight_heavy_layer_runs_its_tiles_row_fastest(ops, dev, cfg, dtype):
     """fc6-like: few row tiles, several column tiles, K = 6272: without split-K conv_mfma.hip walks the tiles M fastest (the row tiles
@@ -314,3 +318,39 @@ def test_weight_heavy_layer_runs_its_tiles_row_fastest(ops, dev, cfg, dtype):
     got = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=cfg, splitk=1).cpu().numpy()
     _check(got, ref, dtype)
     _check(ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=cfg, splitk=4).cpu().numpy(), ref, dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# split precision (RON_DTYPE_F16X3): what the three-MFMA product keeps
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('scale', [1.0, 2.0 ** -10, 300.0])
+def test_split_precision_is_fp32_grade(ops, dev, scale):
+    """A K = 4608 conv (conv4_x / the 3x3 heads) in f16x3 vs float64: error <= 4e-6 of the output scale (bf16: ~4e-3, f16: ~5e-4,
+    the exact-fp32 MFMA mode: ~1e-6) -- at activation scales 1, 2^-10 (the lo plane of such values is an f16 subnormal: the
+    matrix core must not flush it) and 300 (the conv1 layers see +-130)."""
+    rs = np.random.RandomState(11)
+    x = (rs.randn(2, 12, 12, 512) * scale).astype(np.float32)
+    wt = (rs.randn(3, 3, 512, 128) * np.sqrt(2.0 / 4608)).astype(np.float32)
+    b = (rs.randn(128) * 0.1 * scale).astype(np.float32)
+    xt = torch.from_numpy(x.astype(np.float64)).permute(0, 3, 1, 2)
+    wt64 = torch.from_numpy(wt.astype(np.float64)).permute(3, 2, 0, 1)
+    ref = (torch.nn.functional.conv2d(xt, wt64, padding=1).permute(0, 2, 3, 1).numpy() + b.astype(np.float64))
+    errs = {}
+    for dtype in ('f16x3', 'fp32', 'fp16'):
+        got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=False, dtype=dtype).cpu().numpy()
+        errs[dtype] = float(np.abs(got - ref).max() / np.abs(ref).max())
+    print('scale %g: max err / output scale %s' % (scale, errs))
+    assert errs['f16x3'] <= 4e-6, errs
+    assert errs['f16x3'] <= 0.02 * errs['fp16'], errs
+
+
+def test_split_precision_weight_scale_is_exact(ops, dev):
+    """Weights far below / above 1 (the per-layer power-of-two scale brings them to [2^14, 2^15) and the epilogue undoes it):
+    same relative error as at unit scale."""
+    rs = np.random.RandomState(12)
+    x = rs.randn(1, 10, 10, 64).astype(np.float32)
+    for wscale in (2.0 ** -20, 1.0, 2.0 ** 12):
+        wt = (rs.randn(3, 3, 64, 64) * wscale).astype(np.float32)
+        ref = orf.conv2d_np(x.astype(np.float64), wt.astype(np.float64))
+        got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, None, relu=False, dtype='f16x3').cpu().numpy()
+        assert np.abs(got - ref).max() / np.abs(ref).max() <= 4e-6, wscale

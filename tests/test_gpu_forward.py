@@ -128,6 +128,57 @@ def test_forward_fp32_full(pkg, dev, weights_full, images):
     net.close()
 
 
+@pytest.mark.parametrize('fuse_pools', [False, True])
+def test_forward_split_precision_reducedfc(pkg, dev, weights_reduced, images, oracle_reduced, fuse_pools):
+    """dtype 'f16x3' (two f16 planes per value, three f16 MFMAs per product, fp32 accumulate) against the all-fp32 oracle, with
+    the bounds of the exact-fp32 mode: every head tensor and end point within 1e-4 of its scale (measured ~2e-6), detections of
+    the fused path >= 98 % those of the independent oracle with scores / boxes within 1e-4."""
+    (pred, logits, objp, objl, loc, eps), col = oracle_reduced
+    net = pkg['ron'].RONNet(variant='reducedfc', dtype='f16x3', max_batch=2, fuse_pools=fuse_pools).load_weights(weights_reduced)
+    x = torch.from_numpy(images).to(dev)
+    g_pred, g_logits, g_objp, g_objl, g_loc, g_eps = net.net(x, is_training=False)
+    worst = 0.0
+    for i in range(4):
+        for g, r in ((g_logits[i], logits[i]), (g_objl[i], objl[i]), (g_loc[i], loc[i])):
+            worst = max(worst, _rel_err(g.cpu().numpy(), r))
+        np.testing.assert_allclose(g_pred[i].cpu().numpy(), pred[i], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(g_objp[i].cpu().numpy(), objp[i], rtol=0, atol=1e-4)
+    for name in ('block4', 'block5', 'block6', 'block7'):
+        worst = max(worst, _rel_err(g_eps[name].cpu().numpy(), eps[name]))
+    for name in ('block7_ref', 'block4_ref', 'pool5'):
+        worst = max(worst, _rel_err(net.end_point(name, 2).cpu().numpy(), col[name]))
+    print('f16x3 reducedfc (fuse_pools=%s): worst head / end-point error relative to the tensor scale: %.3g' % (fuse_pools, worst))
+    assert worst < 2e-5
+    anchors = oanchors.anchors_all_layers()
+    det = net.detect(x).to_lists()
+    ind = np_post.detect_from_predictions(pred, loc, anchors, objness_pred=objp)
+    for b in range(2):
+        ref_keys = {(int(c), int(a)): k for k, (c, a) in enumerate(zip(ind[b]['classes'], ind[b]['anchor_index']))}
+        hit = [(k, ref_keys[(int(c), int(a))]) for k, (c, a) in enumerate(zip(det[b]['classes'], det[b]['anchor_index']))
+               if (int(c), int(a)) in ref_keys]
+        assert len(hit) >= 0.98 * len(ref_keys) and len(hit) >= 0.98 * len(det[b]['classes'])
+        gi, ri = np.array([h[0] for h in hit]), np.array([h[1] for h in hit])
+        np.testing.assert_allclose(det[b]['scores'][gi], ind[b]['scores'][ri], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(det[b]['bboxes'][gi], ind[b]['bboxes'][ri], rtol=0, atol=1e-4)
+    # deterministic
+    again = net.forward_heads(x)
+    for i in range(4):
+        assert torch.equal(again[0][i], g_logits[i].reshape(again[0][i].shape))
+    net.close()
+
+
+def test_forward_split_precision_full(pkg, dev, weights_full, images):
+    """ron_net full (fc6: K = 25 088) in f16x3 vs the fp32 oracle."""
+    ref = orf.ron_forward(images[:1], weights_full, 'full', backend='numpy')
+    net = pkg['ron'].RONNet(variant='full', dtype='f16x3', max_batch=1).load_weights(weights_full)
+    cls, obj, loc = net.forward_heads(torch.from_numpy(images[:1]).to(dev))
+    for i in range(4):
+        assert _rel_err(cls[i].cpu().numpy(), ref[1][i]) < 2e-5, i
+        assert _rel_err(obj[i].cpu().numpy(), ref[3][i]) < 2e-5, i
+        assert _rel_err(loc[i].cpu().numpy(), ref[4][i]) < 2e-5, i
+    net.close()
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 def test_forward_reduced_precision(pkg, dev, weights_reduced, images, oracle_reduced, dtype):
     rnd = {'bf16': orf.round_bf16, 'fp16': orf.round_f16}[dtype]
@@ -246,12 +297,12 @@ def test_fused_stem_matches_separate_launches(pkg, dev, weights_reduced, dtype):
         assert _rel_err(a, b) < (3e-2 if dtype == 'bf16' else 5e-3)
 
 
-@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-5), ('bf16', 3e-2)])
+@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-5), ('bf16', 3e-2), ('f16x3', 2e-5)])
 def test_ragged_batch_sizes(pkg, dev, weights_reduced, dtype, tol):
     """Every batch size up to max_batch goes through the same launch plan (tile counts, split-K factors and the fused stem's tile
     loop change with n): the first n images of a batch of 7 give the heads of a batch of n."""
     cls = pkg['factory'].get_network('ron_320_vgg')
-    net = cls(variant='reducedfc', dtype=dtype, max_batch=7, device=dev, fuse_pools=dtype != 'fp32')
+    net = cls(variant='reducedfc', dtype=dtype, max_batch=7, device=dev, fuse_pools=dtype == 'bf16')
     net.load_weights(weights_reduced)
     x = torch.from_numpy(pkg['W'].synthetic_images(7, seed=21)).to(dev)
     full = [t.clone() for t in net.forward_heads(x)[0]]
@@ -266,7 +317,7 @@ def test_ragged_batch_sizes(pkg, dev, weights_reduced, dtype, tol):
     net.close()
 
 
-@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-5), ('bf16', 2e-2), ('f16x3', 2e-5)])
 def test_grouped_head_launches_match_one_launch_per_conv(pkg, dev, weights_reduced, images, dtype, tol):
     """RON_CFG_NO_GROUPS: the same graph with every head convolution as its own launch.  Grouping changes tiles and the split
     of K, i.e. only the order of fp32 partial sums (and, in bf16, where a value sits relative to a rounding boundary of the
