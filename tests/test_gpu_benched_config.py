@@ -29,7 +29,21 @@ CHECK = (0, 17, 31)
 # Bounds = 2 x the error measured on MI355X (profiles/r03/parity_errors.json, same keys; fraction of the tensor's max
 # magnitude).  A key without an entry falls back to the blanket tolerance of its dtype.
 BLANKET = {'bf16': 0.04, 'fp16': 0.006, 'ssd_cls': 0.05, 'ssd_loc': 0.08}
-BOUNDS = {}
+BOUNDS = {
+    'cfg2/block4': 0.012, 'cfg2/block4_ref': 0.016, 'cfg2/block6': 0.014, 'cfg2/block7': 0.016,
+    'cfg2/block7_ref': 0.018, 'cfg2/cls0': 0.0083, 'cfg2/cls1': 0.0089, 'cfg2/cls2': 0.0077,
+    'cfg2/cls3': 0.0092, 'cfg2/loc0': 0.019, 'cfg2/loc1': 0.017, 'cfg2/loc2': 0.015,
+    'cfg2/loc3': 0.02, 'cfg2/obj0': 0.0086, 'cfg2/obj1': 0.01, 'cfg2/obj2': 0.0097,
+    'cfg2/obj3': 0.011, 'cfg2/pool1': 0.0067, 'cfg4/block4': 0.0018, 'cfg4/block5_ref': 0.0023,
+    'cfg4/block6': 0.002, 'cfg4/block7': 0.0018, 'cfg4/cls0': 0.00082, 'cfg4/cls1': 0.00097,
+    'cfg4/cls2': 0.0012, 'cfg4/cls3': 0.0011, 'cfg4/loc0': 0.0022, 'cfg4/loc1': 0.0022,
+    'cfg4/loc2': 0.0023, 'cfg4/loc3': 0.002, 'cfg4/obj0': 0.0011, 'cfg4/obj1': 0.0013,
+    'cfg4/obj2': 0.0014, 'cfg4/obj3': 0.0012, 'cfg4/pool1': 0.00089, 'cfg5/cls0': 0.0017,
+    'cfg5/cls1': 0.0081, 'cfg5/cls2': 0.009, 'cfg5/cls3': 0.012, 'cfg5/cls4': 0.011,
+    'cfg5/cls5': 0.0061, 'cfg5/cls6': 0.0017, 'cfg5/loc0': 0.015, 'cfg5/loc1': 0.016,
+    'cfg5/loc2': 0.027, 'cfg5/loc3': 0.014, 'cfg5/loc4': 0.014, 'cfg5/loc5': 0.019,
+    'cfg5/loc6': 0.027,
+}
 
 
 def _rel(got, ref):
@@ -145,7 +159,7 @@ def test_config2_f16x3_detections_within_1e4_of_fp32_oracle():
     """ron_net full, batch 32, dtype 'f16x3' (bench.py --dtype f16x3), two slots through DetectPipeline: for the first, a middle and
     the last image of the batch >= 98 % of the fp32 oracle's detections (own conv stack + np_methods, /root/reference/nets/
     ron_vgg_320.py:434-508 + nets/np_methods.py:23-242) are reproduced with the same class and anchor index, and ALL matched
-    scores and boxes are within 1e-4; head tensors within 2e-5 of their scale."""
+    scores and boxes are within 1e-4; head tensors within 1.5e-5 of their scale."""
     from ron_tensorflow_amd import weights as W
     from ron_tensorflow_amd.metrics import detection_agreement
     from ron_tensorflow_amd.nets import nets_factory
@@ -167,7 +181,7 @@ def test_config2_f16x3_detections_within_1e4_of_fp32_oracle():
         o = orf.ron_forward(images[i:i + 1], weights, 'full', backend='torch')
         for l in range(4):
             for nm, g, r in (('cls', cls[l], o[1][l]), ('obj', obj[l], o[3][l]), ('loc', loc[l], o[4][l])):
-                assert record('cfg2_f16x3/%s%d' % (nm, l), _rel(g[i:i + 1].cpu().numpy(), r)) < 2e-5, (nm, l, i)
+                assert record('cfg2_f16x3/%s%d' % (nm, l), _rel(g[i:i + 1].cpu().numpy(), r)) < 1.5e-5, (nm, l, i)      # measured <= 6.8e-6
         ref = np_post.detect_from_predictions(o[0], o[4], anchors, objness_pred=o[2])[0]
         a = detection_agreement(dets[0][i], ref, tol=1e-4)
         print('image %d: %s' % (i, a))
