@@ -203,84 +203,35 @@ def main():
     images = torch.from_numpy(synthetic_images(args.batch, seed=3 + rank, img_shape=ron_params.img_shape)).to(dev)   # resident in HBM
     top_k = 400
 
-    from ron_tensorflow_amd import parallel
-    gathered = None
-    if use_dist:
-        gathered = torch.empty((world, args.batch, top_k + 1, parallel.RECORD_WIDTH), dtype=torch.float32, device=dev)
-
     # One step = one batch through ron_detect.  `--in-flight F` batches are kept in flight on F execution slots (shared
-    # weights, one stream each): a step is submitted as soon as its slot's previous batch has been consumed.
+    # weights, one stream each): a step is submitted as soon as its slot's previous batch has been consumed.  The loop itself
+    # (step / consume / gather / check, barriers, MAX over ranks) is parallel.bench_loop, which the world-size-2 gloo test
+    # drives with a stub pipeline.
+    from ron_tensorflow_amd import parallel
     from ron_tensorflow_amd.pipeline import DetectPipeline
     in_flight = max(1, args.in_flight)
     pipe = DetectPipeline(net, slots=in_flight, top_k=top_k)
     detect_args = dict(select_threshold=0.01, nms_threshold=0.45) if ssd else \
         dict(objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45)
-    pending = []
-
-    last = [None]
-
     io_stream = torch.cuda.Stream(device=dev)      # the consumer (record packing + RCCL gather) has its own stream
-
-    def consume(ticket):
-        if not use_dist:
-            last[0] = ticket.wait()                # the current stream waits for that slot; the host does not
-            return last[0]
-        with torch.cuda.stream(io_stream):
-            det = last[0] = ticket.wait()
-            rec = parallel.pack_detections(det)
-            ticket.release()                       # the slot may overwrite this output set from here on
-            parallel.gather_detections(rec, out=gathered)
-        return det
-
-    def step():
-        pending.append(pipe.submit(images, **detect_args))
-        return consume(pending.pop(0)) if len(pending) >= in_flight else None
-
-    def drain():
-        while pending:
-            consume(pending.pop(0))
-        return last[0]
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
     lib = _lib.lib()
     contexts = [slot._context() for slot in pipe.slots]
-    # HIP events around every launch for PROFILED_STEPS of each slot's timed steps (each event costs ~3 us of host +
-    # queue time, so not on all of them)
-    for ctx in contexts:
-        _lib.check(lib.ron_profile_reset(ctx))
-        _lib.check(lib.ron_profile_enable(ctx, min(PROFILED_STEPS, args.steps)))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    det = drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    for ctx in contexts:
-        _lib.check(lib.ron_profile_enable(ctx, 0))
-    gather_check = None
-    if use_dist and args.check_gather:
-        # the last step's records as this rank packed them vs the slice of the gathered tensor that belongs to this rank
-        local = parallel.pack_detections(det)
-        torch.cuda.synchronize()
-        same = bool(torch.equal(gathered[rank], local))
-        cl, sc, bb, ai, cnt = parallel.unpack_records(gathered)
-        sane = bool((cnt >= 0).all() and (cnt <= top_k).all() and torch.equal(cnt[rank], det.count))
-        flag = torch.tensor([1 if (same and sane) else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        gather_check = 'ok' if int(flag.item()) == 1 else 'MISMATCH'
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+
+    def before_timed():
+        # HIP events around every launch for PROFILED_STEPS of each slot's timed steps (each event costs ~3 us of host +
+        # queue time, so not on all of them)
+        for ctx in contexts:
+            _lib.check(lib.ron_profile_reset(ctx))
+            _lib.check(lib.ron_profile_enable(ctx, min(PROFILED_STEPS, args.steps)))
+
+    def after_timed(_det):
+        for ctx in contexts:
+            _lib.check(lib.ron_profile_enable(ctx, 0))
+
+    res = parallel.bench_loop(pipe, images, args.steps, args.warmup, in_flight, detect_args, top_k, rank=rank, world=world,
+                              use_dist=use_dist, device=dev, check_gather=args.check_gather, consumer_stream=io_stream,
+                              before_timed=before_timed, after_timed=after_timed)
+    dt, det, gather_check = res['dt'], res['det'], res['gather_check']
 
     # ---- per-launch timing of the timed region (HIP events on the launch stream, inside libron_hip)
     def collect_rows(ctxs):

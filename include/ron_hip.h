@@ -329,9 +329,13 @@ double ron_flops_per_image(const ron_ctx* ctx);
  * ron_forward / ron_detect calls record one event per launch on the launch's stream (n = 0: off); ron_profile_get synchronises on the recorded events and
  * returns, for launch i (the last index is the post-processing stage of ron_detect), its name, whether it is
  * the implicit-GEMM conv kernel, its algorithmic FLOPs per image, the accumulated time and launch count, and its
- * algorithmic HBM bytes (activations in + out per image; packed weights once per launch). */
+ * algorithmic HBM bytes (activations in + out per image; packed weights once per launch).  A grouped launch (several small
+ * head convolutions in one launch) is reported on its first member as "group[first+N]", the other members as "(name)" with
+ * no work of their own.  *name points into the context and stays valid until ron_destroy. */
 int ron_profile_enable(ron_ctx* ctx, int enable);
 int ron_profile_num_ops(const ron_ctx* ctx);
+/* Grouped launches in the plan of this context: 7 (RON-320), 5 (SSD-512); 0 with RON_CFG_NO_GROUPS / RON_CFG_MULTI_STREAM. */
+int ron_num_grouped_launches(const ron_ctx* ctx);
 int ron_profile_get(ron_ctx* ctx, int i, const char** name, int* is_conv, double* flops_per_image,
                     double* total_ms, int* launches, double* act_bytes_per_image, double* weight_bytes);
 int ron_profile_reset(ron_ctx* ctx);

@@ -117,6 +117,7 @@ SIGNATURES = {
     'ron_detect': (C.c_int, [_P, _P, C.c_int, C.POINTER(PostCfg), C.POINTER(Detections), _P]),
     'ron_flops_per_image': (C.c_double, [_P]),
     'ron_profile_enable': (C.c_int, [_P, C.c_int]),
+    'ron_num_grouped_launches': (C.c_int, [_P]),
     'ron_profile_num_ops': (C.c_int, [_P]),
     'ron_profile_get': (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -123,6 +123,8 @@ struct ron_ctx {
   // optional per-launch timing (ron_profile_*): event pairs recorded on the caller's stream
   int profiling = 0;                    // calls still to be recorded (ron_profile_enable)
   std::vector<OpTiming> timing;                       // ops.size() + 1 (last = post-processing)
+  std::vector<std::string> labels;                    // ron_profile_get names, one per op, built once (stable until ron_destroy)
+  int grouped_launches = 0;                           // grouped launches in the plan (0: one launch per convolution)
   std::vector<std::vector<hipEvent_t>> pending;       // per recorded call: one event per stamp ...
   std::vector<std::vector<int>> pending_ops;          // ... and what it marks: op index (its start), -1 = end of a lane,
                                                       //     -2 / -3 = start / end of the post-processing stage
@@ -480,11 +482,18 @@ void plan_groups(ron_ctx* c) {
   for (const Slot& s : order)
     for (const char* nm : s.names) {
       auto it = at.find(nm);
-      if (it == at.end()) return;                         // not the graph this plan was written for: keep the plain order
+      if (it == at.end()) {                               // not the graph this plan was written for: keep the plain order, loudly
+        fprintf(stderr, "libron_hip: grouped launch plan names op '%s' which the graph does not have: one launch per convolution\n", nm);
+        return;
+      }
       first_head = std::min(first_head, (size_t)it->second);
       ++n_named;
     }
-  if (first_head + n_named != c->ops.size()) return;      // the heads must be exactly the tail of the op list
+  if (first_head + n_named != c->ops.size()) {            // the heads must be exactly the tail of the op list
+    fprintf(stderr, "libron_hip: grouped launch plan covers %zu ops, the graph has %zu after '%s': one launch per convolution\n",
+            n_named, c->ops.size() - first_head, c->ops[first_head].name.c_str());
+    return;
+  }
   std::vector<Op> planned(c->ops.begin(), c->ops.begin() + first_head);
   int gid = 0;
   for (const Slot& s : order) {
@@ -495,6 +504,7 @@ void plan_groups(ron_ctx* c) {
     }
     if (s.cfg >= 0) ++gid;
   }
+  c->grouped_launches = gid;
   c->ops.swap(planned);
 }
 
@@ -957,6 +967,18 @@ static int slot_resources(ron_ctx* c) {
   for (int l = 0; l < 4; ++l)
     if (c->splitk_bytes[l] > 0) RON_HIP_CHECK(hipMalloc(&c->d_splitk[l], (size_t)c->splitk_bytes[l]));
   c->timing.assign(c->ops.size() + 1, OpTiming());
+  // names ron_profile_get hands out: a grouped launch is reported on its first member as "group[first+N]", the other members as
+  // "(name)"; built once so that the pointers stay valid until ron_destroy
+  c->labels.assign(c->ops.size() + 1, std::string());
+  for (size_t i = 0; i < c->ops.size(); ++i) {
+    const Op& o = c->ops[i];
+    const bool member = o.group >= 0 && i > 0 && c->ops[i - 1].group == o.group;
+    if (member) { c->labels[i] = "(" + o.name + ")"; continue; }
+    int extra = 0;
+    for (size_t j = i + 1; o.group >= 0 && j < c->ops.size() && c->ops[j].group == o.group; ++j) ++extra;
+    c->labels[i] = extra > 0 ? "group[" + o.name + "+" + std::to_string(extra) + "]" : o.name;
+  }
+  c->labels[c->ops.size()] = "post_np";
   return RON_OK;
 }
 
@@ -974,6 +996,7 @@ extern "C" int ron_clone(ron_ctx* src, ron_ctx** out) {
   c->d_l2_gamma = owner->d_l2_gamma; c->d_stem_w = owner->d_stem_w; c->d_stem_b = owner->d_stem_b;
   c->d_stem2_w = owner->d_stem2_w; c->d_stem2_b = owner->d_stem2_b; c->d_stem2_w1 = owner->d_stem2_w1;
   c->flops_per_image = owner->flops_per_image;
+  c->grouped_launches = owner->grouped_launches;
   c->weights_owner = owner;
   ++owner->clones;
   for (auto& v : c->vars) v.loaded = true;
@@ -1132,6 +1155,7 @@ static int profile_collect(ron_ctx* c) {
 }
 
 extern "C" int ron_profile_num_ops(const ron_ctx* c) { return c ? (int)c->ops.size() + 1 : RON_ERR_INVALID; }
+extern "C" int ron_num_grouped_launches(const ron_ctx* c) { return c ? c->grouped_launches : RON_ERR_INVALID; }
 
 extern "C" int ron_profile_get(ron_ctx* c, int i, const char** name, int* is_conv, double* flops_per_image,
                                double* total_ms, int* launches, double* act_bytes_per_image, double* weight_bytes) {
@@ -1142,23 +1166,15 @@ extern "C" int ron_profile_get(ron_ctx* c, int i, const char** name, int* is_con
   // a grouped launch is reported on its first member (FLOPs / bytes of the whole group, name "first+N"); the other members
   // report nothing, so sums over the rows stay right
   double fl = 0, ab = 0, wb = 0;
-  static thread_local std::string label;
   if (!post) {
     const Op& o = c->ops[i];
-    label = o.name;
     const bool member = o.group >= 0 && i > 0 && c->ops[i - 1].group == o.group;
-    if (!member) {
-      int extra = 0;
+    if (!member)
       for (size_t j = i; j < c->ops.size() && (j == (size_t)i || (o.group >= 0 && c->ops[j].group == o.group)); ++j) {
         fl += c->ops[j].flops; ab += c->ops[j].act_bytes; wb += c->ops[j].wgt_bytes;
-        if (j > (size_t)i) ++extra;
       }
-      if (extra > 0) label = "group[" + o.name + "+" + std::to_string(extra) + "]";
-    } else {
-      label = "(" + o.name + ")";
-    }
   }
-  if (name) *name = post ? "post_np" : label.c_str();
+  if (name) *name = c->labels[i].c_str();
   if (is_conv) *is_conv = !post && c->ops[i].kind == OP_CONV;
   if (flops_per_image) *flops_per_image = fl;
   if (total_ms) *total_ms = c->timing[i].ms;

@@ -116,6 +116,20 @@ class RONNet(object):
             found = dict(extra, **found)
         return self.load_weights(found)
 
+    def launch_plan(self):
+        """Names of the launches of one forward pass in order (ron_profile_get): a grouped launch reads 'group[first+N]', its other
+        members '(name)'; the last entry is the post-processing stage."""
+        import ctypes as C
+        ctx, names = self._context(), []
+        for i in range(lib().ron_profile_num_ops(ctx)):
+            name = C.c_char_p()
+            check(lib().ron_profile_get(ctx, i, C.byref(name), None, None, None, None, None, None))
+            names.append(name.value.decode())
+        return names
+
+    def grouped_launches(self):
+        return int(lib().ron_num_grouped_launches(self._context()))
+
     def flops_per_image(self):
         return lib().ron_flops_per_image(self._context())
 

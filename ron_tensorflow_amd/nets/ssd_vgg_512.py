@@ -74,11 +74,14 @@ class SSDNet(RONNet):
         fn = prediction_fn if prediction_fn is not None else ops.softmax_last
         predictions = [fn(l) for l in logits]
         eps = {name: self.end_point(name, inputs.shape[0]) for name in (end_points or ())}
+        if update_feat_shapes:                       # nets/ssd_vgg_512.py:134-136: the feature shapes follow the predictions
+            self.update_feature_shapes(predictions)
         return predictions, localisations, logits, eps
 
     def update_feature_shapes(self, predictions):
-        """nets/ssd_vgg_512.py:141-146: feat_shapes from the prediction tensors."""
-        self.params = self.params._replace(feat_shapes=[tuple(p.shape[1:3]) for p in predictions])
+        """nets/ssd_vgg_512.py:141-146 -> ssd_feat_shapes_from_net (nets/ssd_vgg_300.py:282-303): feat_shapes become the
+        [H, W, A] of every prediction tensor ([N, H, W, A, C]); anchors() reads the first two entries like the reference's."""
+        self.params = self.params._replace(feat_shapes=[[int(d) for d in p.shape[1:4]] for p in predictions])
 
     def anchors(self, img_shape, dtype=np.float32):
         """nets/ssd_vgg_512.py:148-157: list of (y, x, h, w) per layer."""

@@ -4,6 +4,7 @@ Each function takes/returns torch tensors on the GPU (device containers only) an
 C-ABI entry point of libron_hip.so.  Names follow the reference's numpy module
 (``nets/np_methods.py``) where a function replaces one of its steps.
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -104,18 +105,26 @@ def _fill_heads(cls, obj, loc, anchors_dev, num_classes):
     return h, keep
 
 
-_WORKSPACES = {}
+_WORKSPACES = collections.OrderedDict()
+_MAX_WORKSPACES = 8
 
 
 def _workspace(device, nbytes):
     """Scratch of the post-processing entry points, one per (device, stream): calls on different streams never share
-    candidate lists, and a regrown buffer is dropped on the stream that was its only user."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _WORKSPACES.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)
-        _WORKSPACES[key] = ws
-    return ws
+    candidate lists, and a regrown buffer is dropped on the stream that was its only user.  At most _MAX_WORKSPACES
+    entries, least recently used first out, so short-lived streams do not pin scratch for the life of the process; an
+    entry is (buffer, stream object): holding the stream keeps its handle from being recycled for another stream while
+    the allocator still attributes the buffer to it."""
+    stream = torch.cuda.current_stream(device)
+    key = (device.type, device.index, stream.cuda_stream)
+    ent = _WORKSPACES.get(key)
+    if ent is None or ent[0].numel() < nbytes:
+        ent = (torch.empty((int(nbytes),), dtype=torch.uint8, device=device), stream)
+        _WORKSPACES[key] = ent
+    _WORKSPACES.move_to_end(key)
+    while len(_WORKSPACES) > _MAX_WORKSPACES:
+        _WORKSPACES.popitem(last=False)
+    return ent[0]
 
 
 def post_np(cls, obj, loc, anchors_dev, num_classes=21, objectness_thres=0.03, select_threshold=0.01,

@@ -59,3 +59,89 @@ def gather_detections(rec, group=None, out=None):
     # the flat "concatenate along dim 0" form is the one every backend accepts (gloo rejects the stacked one)
     dist.all_gather_into_tensor(out.view((world * rec.shape[0],) + tuple(rec.shape[1:])), rec.contiguous(), group=group)
     return out
+
+
+def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=0, world=1, use_dist=False, device=None,
+               check_gather=True, pack=pack_detections, synchronize=None, consumer_stream=None, before_timed=None,
+               after_timed=None):
+    """The step / consume / gather / check sequence bench.py times, with the pipeline as an argument (bench.py passes a
+    DetectPipeline on the GPU; tests/test_parallel_gloo.py a CPU stub at world size 2).
+
+    One step = `pipe.submit(images, **detect_args)`; at most `in_flight` tickets are pending, the oldest is consumed when a
+    new one is submitted.  With a process group (`use_dist`) consuming = pack the detections into records on the consumer
+    stream, release the slot, all-gather the records into `gathered[world, n, top_k + 1, 7]`.  `warmup` untimed steps,
+    then exactly `steps` timed ones bracketed by synchronize + barrier on both sides; the time is the MAX over ranks.
+    After the timed region every rank compares the slice of `gathered` that is its own with its local records and checks
+    every rank's counts; the verdict is the MIN over ranks, so one bad rank makes it 'MISMATCH' everywhere.
+
+    Returns dict(dt, det (this rank's last detections), gathered, gather_check ('ok' | 'MISMATCH' | None))."""
+    import contextlib
+    import time
+    if synchronize is None:
+        synchronize = torch.cuda.synchronize
+    in_flight = max(1, int(in_flight))
+    n = images.shape[0]
+    gathered = None
+    if use_dist:
+        gathered = torch.empty((world, n, top_k + 1, RECORD_WIDTH), dtype=torch.float32, device=device)
+    pending, last = [], [None]
+
+    def consumer():
+        return torch.cuda.stream(consumer_stream) if consumer_stream is not None else contextlib.nullcontext()
+
+    def consume(ticket):
+        if not use_dist:
+            last[0] = ticket.wait()                # the current stream waits for that slot; the host does not
+            return last[0]
+        with consumer():                           # record packing + gather on the consumer's own stream
+            det = last[0] = ticket.wait()
+            rec = pack(det)
+            ticket.release()                       # the slot may overwrite this output set from here on
+            gather_detections(rec, out=gathered)
+        return det
+
+    def step():
+        pending.append(pipe.submit(images, **detect_args))
+        return consume(pending.pop(0)) if len(pending) >= in_flight else None
+
+    def drain():
+        while pending:
+            consume(pending.pop(0))
+        return last[0]
+
+    for _ in range(warmup):
+        step()
+    drain()
+    synchronize()
+    if use_dist:
+        dist.barrier()
+    if before_timed is not None:
+        before_timed()
+    synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    det = drain()
+    synchronize()
+    if use_dist:
+        dist.barrier()
+    synchronize()
+    dt = time.perf_counter() - t0
+    if after_timed is not None:
+        after_timed(det)
+    gather_check = None
+    if use_dist and check_gather:
+        # the last step's records as this rank packs them vs the slice of the gathered tensor that belongs to this rank
+        local = pack(det)
+        synchronize()
+        same = bool(torch.equal(gathered[rank], local))
+        cnt = unpack_records(gathered)[4]
+        sane = bool((cnt >= 0).all() and (cnt <= top_k).all() and torch.equal(cnt[rank], det.count.to(cnt.device)))
+        flag = torch.tensor([1 if (same and sane) else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_check = 'ok' if int(flag.item()) == 1 else 'MISMATCH'
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dict(dt=dt, det=det, gathered=gathered, gather_check=gather_check)

@@ -6,14 +6,26 @@ hides both by keeping a second batch in flight: while one slot's launch drains, 
 free CUs.  The slots are ``ron_clone`` contexts (shared packed weights, own activations / scratch / head buffers),
 each fed on its own HIP stream; results are handed back through events, nothing blocks the host."""
 import os
+import warnings
 
-# one hardware queue per stream (slots + consumer + RCCL + default > the runtime's default of 4; streams that share a queue
-# serialise behind each other).  Read by the HIP runtime when it initialises, i.e. no effect if a kernel has already run.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+import torch
 
-import torch  # noqa: E402
+from . import ops
 
-from . import ops  # noqa: E402
+
+def _check_hw_queues(streams_needed):
+    """One hardware queue per stream: slots + a consumer + RCCL's stream + the default stream are more than the HIP runtime's
+    default of 4, and streams that share a queue serialise behind each other (measured: -1.8 % images/s).  The runtime reads
+    GPU_MAX_HW_QUEUES when it initialises, so a library cannot set it reliably: the APPLICATION exports it before its first
+    HIP call (bench.py does).  Here it is only checked."""
+    try:
+        have = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+    except ValueError:
+        have = 4
+    if have < streams_needed:
+        warnings.warn('DetectPipeline: %d streams in use but GPU_MAX_HW_QUEUES=%s: streams will share hardware queues and serialise; '
+                      'export GPU_MAX_HW_QUEUES=8 before the first HIP call' % (streams_needed, os.environ.get('GPU_MAX_HW_QUEUES', 'unset (4)')),
+                      RuntimeWarning, stacklevel=3)
 
 
 class Ticket(object):
@@ -56,6 +68,8 @@ class DetectPipeline(object):
 
     def __init__(self, net, slots=2, top_k=400, buffers_per_slot=2):
         assert slots >= 1 and buffers_per_slot >= 1
+        if slots > 1:
+            _check_hw_queues(slots + 3)               # + consumer + RCCL + the default stream
         self.net, self.top_k, self.buffers_per_slot = net, top_k, buffers_per_slot
         self.slots = [net] + [net.clone() for _ in range(slots - 1)]
         with torch.cuda.device(net.device):

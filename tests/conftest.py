@@ -22,28 +22,43 @@ def pytest_sessionstart(session):
         import subprocess
         subprocess.run(['make', '-C', os.path.join(ROOT, 'ron_tensorflow_amd', 'csrc'), '-j', str(min(8, os.cpu_count() or 1))],
                        check=False)
-    _start_torchrun_child(session.config)
 
 
 TORCHRUN_CHILD = {}
 
 
-def _gpu_run_selected(config):
+def pytest_collection_modifyitems(session, config, items):
+    """The single-rank torchrun child runs only when tests/test_gpu_torchrun.py is among the SELECTED items (after -m / -k),
+    not for every session that mentions gpu."""
     expr = config.getoption('-m') or ''
-    return 'gpu' in expr and 'not gpu' not in expr
-
-
-def _start_torchrun_child(config):
-    """`bench.py` under `python -m torch.distributed.run --nproc-per-node 1` as a FRESH child process, started and finished
-    before this process touches the GPU (a process that has initialised HIP must not fork + exec on the GPU pool; counting
-    devices does not initialise it).  tests/test_gpu_torchrun.py reads the result."""
-    if not _gpu_run_selected(config) or TORCHRUN_CHILD:
+    if 'gpu' not in expr or 'not gpu' in expr:
         return
-    try:
-        import torch
-        if torch.cuda.device_count() < 1:
-            return
-    except Exception:
+    selected = items
+    kexpr = config.getoption('-k') or ''
+    if kexpr:                                    # -k deselection happens in a later hook: apply the same expression here
+        try:
+            from _pytest.mark import KeywordMatcher
+            from _pytest.mark.expression import Expression
+            e = Expression.compile(kexpr)
+            selected = [it for it in items if e.evaluate(KeywordMatcher.from_item(it))]
+        except Exception:      # noqa: BLE001  (private API moved: fall back to "selected")
+            selected = items
+    if any(it.nodeid.startswith('tests/test_gpu_torchrun.py') or 'test_gpu_torchrun' in it.nodeid for it in selected):
+        _start_torchrun_child()
+
+
+def _gpu_present():
+    """Without torch and without a HIP call (torch.cuda.device_count() may fall back to hipGetDeviceCount, which initialises
+    the runtime in THIS process): the kernel driver's device node + a render node."""
+    import glob
+    return os.path.exists('/dev/kfd') and bool(glob.glob('/dev/dri/renderD*'))
+
+
+def _start_torchrun_child():
+    """`bench.py` under `python -m torch.distributed.run --nproc-per-node 1` as a FRESH child process, started and finished
+    before this process touches the GPU (a process that has initialised HIP must not fork + exec on the GPU pool; test modules
+    are only imported here, none of them makes a HIP call at import).  tests/test_gpu_torchrun.py reads the result."""
+    if TORCHRUN_CHILD or not _gpu_present():
         return
     import socket
     import subprocess

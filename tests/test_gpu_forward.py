@@ -265,6 +265,30 @@ def test_multi_stream_heads_are_identical(pkg, dev, weights_reduced, images):
     b.close()
 
 
+@pytest.mark.parametrize('variant', ['reducedfc', 'full'])
+def test_grouped_launch_plan_is_active(pkg, dev, weights_reduced, weights_full, variant):
+    """The grouped head launches are keyed on op names inside libron_hip (plan_groups): a rename in the graph builder would
+    silently fall back to one launch per convolution (-7 % of the step) while every equivalence test still passed.  Read the plan."""
+    w = weights_reduced if variant == 'reducedfc' else weights_full
+    net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=1, fuse_pools=True).load_weights(w)
+    plan = net.launch_plan()
+    groups = [n for n in plan if n.startswith('group[')]
+    assert net.grouped_launches() == 7 and len(groups) == 7, plan
+    assert groups == ['group[block7_trio3+2]', 'group[block7_objectness_score+5]', 'group[block6_trio3+1]',
+                      'group[block6_inception2_3x3+2]', 'group[block7_cls_pred+3]', 'group[block6_cls_pred+2]',
+                      'group[block5_inception2_3x3+1]'], groups
+    assert plan[0] == 'conv1_1+conv1_2+pool1' and plan[-1] == 'post_np'
+    launches = [n for n in plan[:-1] if not n.startswith('(')]
+    assert len(launches) == 35, (len(launches), launches)       # fused stem + 13 backbone convs / pools + fc6 + fc7 + 19 head launches
+    clone = net.clone()
+    assert clone.launch_plan() == plan and clone.grouped_launches() == 7
+    clone.close()
+    net.close()
+    net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=1, fuse_pools=True, group_heads=False).load_weights(w)
+    assert net.grouped_launches() == 0 and not any(n.startswith('group[') for n in net.launch_plan())
+    net.close()
+
+
 def test_network_fn_uses_full_variant(pkg, dev, weights_full, images):
     fn = pkg['factory'].get_network_fn('ron_320_vgg', 21, is_training=False, weights=weights_full, dtype='bf16', max_batch=1)
     assert fn.default_image_size == 320

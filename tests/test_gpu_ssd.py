@@ -37,7 +37,11 @@ def test_ssd_fp32_forward_and_detect(setup, dev):
     assert net.variables() == [(n, tuple(s)) for n, s in setup['W'].ssd_variable_shapes()]
     assert abs(net.flops_per_image() / 1e9 - 180.4) < 0.6
     x = torch.from_numpy(setup['images']).to(dev)
-    pred, loc, logits, eps = net.net(x, is_training=False)
+    net.params = net.params._replace(feat_shapes=[(1, 1)] * 7)          # stale shapes ...
+    pred, loc, logits, eps = net.net(x, is_training=False, update_feat_shapes=False)
+    assert net.params.feat_shapes == [(1, 1)] * 7                       # ... stay when the caller says so,
+    pred, loc, logits, eps = net.net(x, is_training=False)              # and follow the predictions by default
+    assert net.params.feat_shapes == [[64, 64, 4], [32, 32, 6], [16, 16, 6], [8, 8, 6], [4, 4, 6], [2, 2, 4], [1, 1, 4]]   # nets/ssd_vgg_300.py:297
     r_pred, r_loc, r_logits, r_eps = setup['ref']
     assert len(pred) == 7 and sorted(eps) == sorted(['block4', 'block7', 'block8', 'block9', 'block10', 'block11', 'block12'])
     for i in range(7):
@@ -71,6 +75,7 @@ def test_ssd_fp32_forward_and_detect(setup, dev):
     for c in range(1, 21):
         assert np.array_equal(ds[c].cpu().numpy(), rs[c]), c
         assert np.array_equal(db[c].cpu().numpy(), rb[c]), c
+    assert net.grouped_launches() == 5 and sum(n.startswith('group[') for n in net.launch_plan()) == 5
     net.close()
 
 

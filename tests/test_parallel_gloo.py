@@ -59,6 +59,85 @@ def test_gather_detections_world2():
     assert dict(ret) == {0: True, 1: True}
 
 
+# ---- bench.py's timed loop (parallel.bench_loop) at world size 2, with a stub pipeline ------------------------------
+class _StubTicket(object):
+    def __init__(self, det, log):
+        self.det, self.log = det, log
+
+    def wait(self):
+        return self.det
+
+    def release(self):
+        self.log.append('release')
+
+
+class _StubPipeline(object):
+    """submit() -> a ticket whose detections depend on (rank, step); rank r sleeps r * 20 ms per step (ranks finish apart)."""
+
+    def __init__(self, rank, n, k):
+        self.rank, self.n, self.k, self.step, self.log = rank, n, k, 0, []
+
+    def submit(self, images, **detect_args):
+        import time
+        from ron_tensorflow_amd.ops import DetectionBuffers
+        assert detect_args == dict(select_threshold=0.01, nms_threshold=0.45)
+        time.sleep(0.02 * self.rank)
+        det = DetectionBuffers(self.n, self.k, 'cpu')
+        cl, sc, bb, ai, cnt = _fake_detections(1000 * self.rank + self.step, self.n, self.k)
+        det.classes, det.scores, det.bboxes, det.anchor_index, det.count = cl.to(torch.int32), sc, bb, ai.to(torch.int32), cnt
+        self.step += 1
+        return _StubTicket(det, self.log)
+
+
+def _pack_cpu(det):
+    return parallel.pack_records(det.classes, det.scores, det.bboxes, det.anchor_index, det.count)
+
+
+def _bench_worker(rank, world, port, corrupt_rank, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n, k, steps, warmup, in_flight = 3, 400, 4, 2, 2
+        pipe = _StubPipeline(rank, n, k)
+        images = torch.zeros((n, 8, 8, 3))
+
+        def after_timed(det):
+            if rank == corrupt_rank:                  # this rank's local records no longer equal what it sent
+                det.scores[0, 0] += 1.0
+
+        res = parallel.bench_loop(pipe, images, steps, warmup, in_flight, dict(select_threshold=0.01, nms_threshold=0.45), k,
+                                  rank=rank, world=world, use_dist=True, device='cpu', pack=_pack_cpu, synchronize=lambda: None,
+                                  after_timed=after_timed)
+        assert pipe.step == warmup + steps and pipe.log.count('release') == warmup + steps
+        # every rank holds every rank's records of the LAST step
+        found = []
+        for r in range(world):
+            want = parallel.pack_records(*_fake_detections(1000 * r + warmup + steps - 1, n, k))
+            found.append(bool(torch.equal(res['gathered'][r], want)))
+        ret[rank] = dict(dt=res['dt'], gather_check=res['gather_check'], found=found,
+                         det_is_last=bool(torch.equal(res['det'].count, _fake_detections(1000 * rank + warmup + steps - 1, n, k)[4])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('corrupt_rank', [-1, 1])
+def test_bench_loop_world2(corrupt_rank):
+    """The N > 1 control flow of bench.py without a node: rank-indexed `gathered[rank]`, the MAX all-reduce of the time, the
+    barriers inside the timed region, the MIN all-reduce of the gather check."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bench_worker, args=(world, _free_port(), corrupt_rank, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0['found'] == [True, True] and r1['found'] == [True, True]        # own and the other rank's records
+    assert r0['det_is_last'] and r1['det_is_last']
+    assert r0['dt'] == r1['dt']                                               # MAX over ranks, the same on both
+    assert r0['dt'] >= 4 * 0.02                                               # ... and it is the slow rank's (4 steps x 20 ms)
+    want = 'ok' if corrupt_rank < 0 else 'MISMATCH'
+    assert r0['gather_check'] == want and r1['gather_check'] == want          # one bad rank fails the check on every rank
+
+
 def test_shard_range_partitions_every_image_once():
     for n in (1, 7, 32, 255, 256):
         for world in (1, 2, 3, 8):
