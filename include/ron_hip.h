@@ -111,7 +111,8 @@ typedef struct {
 
 typedef struct {
   float objectness_thres;   /* eval_ron_network.py:66-67,227-229 (0.03); ignored if obj NULL */
-  float select_threshold;   /* np_methods.py:59 / eval_ron_network.py:64-65                  */
+  float select_threshold;   /* np_methods.py:59 / eval_ron_network.py:64-65; 0 = the arg-max
+                             * branch (np_methods.py:82-89): one candidate per anchor       */
   float nms_threshold;      /* np_methods.py:229                                             */
   int32_t top_k;            /* np_methods.py:137 (400); <= RON_MAX_TOPK                      */
   float bbox_img[4];        /* clip reference + resize box (notebook cell 8): [0,0,1,1]      */

@@ -106,19 +106,26 @@ def bboxes_select_image(predictions_img, bboxes_img, select_threshold):
     anchor_index int64) in the reference's order: layers in list order, then
     anchor-major / class-minor (the row-major order of ``np.where``).
     """
-    if select_threshold is None or select_threshold == 0:
-        raise NotImplementedError("argmax branch (np_methods.py:82-89) is outside the graded path")
-    thr = F32(select_threshold)
+    argmax = select_threshold is None or select_threshold == 0       # np_methods.py:82-89: "score > no-label" criterion
+    thr = None if argmax else F32(select_threshold)
     cls_l, sc_l, bb_l, ai_l = [], [], [], []
     base = 0
     for pred, box in zip(predictions_img, bboxes_img):
         n_cls = pred.shape[-1]
         flat = np.asarray(pred, F32).reshape(-1, n_cls)
         boxes = np.asarray(box, F32).reshape(-1, 4)
-        fg = flat[:, 1:]
-        anchor, c = np.nonzero(fg > thr)
-        cls_l.append(c.astype(np.int64) + 1)
-        sc_l.append(fg[anchor, c])
+        if argmax:
+            # ONE candidate per anchor: the arg-max class over ALL classes (first maximum, like np.argmax), kept when it
+            # is not the background class; anchors the objectness gate zeroed have class 0 and drop out
+            c = np.argmax(flat, axis=1)
+            anchor = np.nonzero(c > 0)[0]
+            cls_l.append(c[anchor].astype(np.int64))
+            sc_l.append(flat[anchor, c[anchor]])
+        else:
+            fg = flat[:, 1:]
+            anchor, c = np.nonzero(fg > thr)
+            cls_l.append(c.astype(np.int64) + 1)
+            sc_l.append(fg[anchor, c])
         bb_l.append(boxes[anchor])
         ai_l.append(anchor.astype(np.int64) + base)
         base += flat.shape[0]

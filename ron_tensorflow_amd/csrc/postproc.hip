@@ -119,7 +119,20 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(HeadsDev hd, Pos
     inv_sum = s;
   }
   int n_sel = 0;
-  if (gate) {
+  // select_threshold 0 / None: the "score > no-label" branch of ssd_bboxes_select_layer (np_methods.py:82-89): ONE candidate per
+  // anchor, the arg-max over ALL classes (first maximum, like np.argmax), kept when it is not the background class.  A gated-out
+  // anchor is an all-zero row there: arg-max 0, dropped.
+  const bool argmax_mode = pc.sel_thr == 0.f;
+  int best_c = 0;
+  float best_sc = 0.f;
+  if (gate && argmax_mode) {
+    best_sc = is_prob ? row[0] : expf(row[0] - mx) / inv_sum;
+    for (int c = 1; c < C; ++c) {
+      const float sc = is_prob ? row[c] : expf(row[c] - mx) / inv_sum;
+      if (sc > best_sc) { best_sc = sc; best_c = c; }
+    }
+    n_sel = best_c > 0 ? 1 : 0;
+  } else if (gate) {
     for (int c = 1; c < C; ++c) {
       const float sc = is_prob ? row[c] : expf(row[c] - mx) / inv_sum;
       n_sel += (sc > pc.sel_thr) ? 1 : 0;
@@ -141,6 +154,10 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(HeadsDev hd, Pos
     int pos = base + incl - n_sel;
     const unsigned p0 = (unsigned)(hd.anchor_base[layer] + local) * (unsigned)(C - 1);
     u64* out = keys + (size_t)img * cap;
+    if (argmax_mode) {
+      if (pos < cap) out[pos] = make_key(best_sc, p0 + (unsigned)(best_c - 1));
+      return;
+    }
     for (int c = 1; c < C; ++c) {
       const float sc = is_prob ? row[c] : expf(row[c] - mx) / inv_sum;
       if (sc > pc.sel_thr) {
@@ -693,8 +710,7 @@ extern "C" int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cf
                            int32_t* n_candidates, void* stream) {
   RON_REQUIRE(cfg != nullptr && n > 0, "bad cfg / n");
   RON_REQUIRE(cfg->top_k >= 1 && cfg->top_k <= kMaxTopK, "top_k %d not in [1, %d]", cfg->top_k, kMaxTopK);
-  RON_REQUIRE(cfg->select_threshold > 0.f,
-              "select_threshold must be > 0 (the argmax branch of np_methods.py:82-89 is not on this path)");
+  RON_REQUIRE(cfg->select_threshold >= 0.f, "select_threshold must be >= 0 (0 = the arg-max branch of np_methods.py:82-89)");
   HeadsDev hd;
   int rc = build_heads_dev(heads, &hd, (cfg->input_flags & RON_IN_LOC_DECODED) == 0);
   if (rc != RON_OK) return rc;

@@ -248,7 +248,7 @@ class RONNet(object):
         n = inputs.shape[0]
         cfg = _lib.PostCfg()
         cfg.objectness_thres, cfg.select_threshold, cfg.nms_threshold, cfg.top_k = \
-            objectness_thres, select_threshold, nms_threshold, top_k
+            objectness_thres, (select_threshold or 0.0), nms_threshold, top_k
         for i in range(4):
             cfg.bbox_img[i] = bbox_img[i]
             cfg.prior_scaling[i] = self.params.prior_scaling[i]

@@ -140,7 +140,8 @@ def post_np(cls, obj, loc, anchors_dev, num_classes=21, objectness_thres=0.03, s
     dev = cls[0].device
     heads, keep = _fill_heads(cls, obj, loc, None if loc_decoded else anchors_dev, num_classes)
     cfg = PostCfg()
-    cfg.objectness_thres, cfg.select_threshold, cfg.nms_threshold = objectness_thres, select_threshold, nms_threshold
+    # select_threshold None / 0: the arg-max branch of ssd_bboxes_select_layer (np_methods.py:82-89)
+    cfg.objectness_thres, cfg.select_threshold, cfg.nms_threshold = objectness_thres, (select_threshold or 0.0), nms_threshold
     cfg.top_k = top_k
     for i in range(4):
         cfg.bbox_img[i] = bbox_img[i]

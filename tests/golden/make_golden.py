@@ -248,6 +248,11 @@ G3_CASES = [
     ('thr50_s6', 6, 8.0, -2.0, 3.0, 0.5, 0.45),
     ('thr50_s7', 7, 6.0, -1.0, 3.0, 0.5, 0.40),
     ('empty_s8', 8, 30.0, -30.0, 1.0, 0.01, 0.45),
+    # select_threshold 0: the "score > no-label" branch of ssd_bboxes_select_layer (np_methods.py:82-89): one candidate per
+    # anchor, arg-max over all classes, kept when the class is not background
+    ('argmax_dense_s9', 9, 2.0, 1.0, 1.0, 0.0, 0.45),
+    ('argmax_sparse_s10', 10, 4.5, -2.0, 1.0, 0.0, 0.45),
+    ('argmax_empty_s11', 11, 30.0, -30.0, 1.0, 0.0, 0.45),
 ]
 
 

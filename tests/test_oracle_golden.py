@@ -87,6 +87,19 @@ def test_g3_pipeline_matches_reference(golden_dir):
             assert res['anchor_index'].min() >= 0 and res['anchor_index'].max() < 21250
 
 
+def test_select_threshold_none_is_the_argmax_branch():
+    """np_methods.py:82: `select_threshold is None or select_threshold == 0` -- both spellings, one candidate per anchor."""
+    layers = oanchors.anchors_all_layers()
+    cls, obj, loc = synth.head_tensors(10, batch=1, bg=4.5, ob=-2.0)
+    a = np_post.detect_from_logits(cls, obj, loc, layers, select_threshold=None)[0]
+    b = np_post.detect_from_logits(cls, obj, loc, layers, select_threshold=0)[0]
+    assert a['n_candidates'] == b['n_candidates'] == 170
+    for k in ('classes', 'scores', 'bboxes', 'anchor_index'):
+        assert np.array_equal(a[k], b[k])
+    assert len(set(a['anchor_index'].tolist())) == len(a['anchor_index'])       # at most one class per anchor
+    assert a['classes'].min() >= 1
+
+
 def test_g3_batch_equals_per_image(golden_dir):
     layers = oanchors.anchors_all_layers()
     cls, obj, loc = synth.head_tensors(40, batch=3)

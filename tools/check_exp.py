@@ -4,7 +4,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ['RON_HIP_LIB'] = os.path.join(ROOT, 'ron_tensorflow_amd', 'libron_hip_exp.so')
+os.environ['RON_HIP_LIB'] = os.path.join(ROOT, 'tools', 'experiments', 'libron_hip_exp.so')
 import numpy as np
 import torch
 from oracle import ron_forward as orf

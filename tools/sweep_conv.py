@@ -16,7 +16,7 @@ if '--zeros' in sys.argv:       # all-zero operands: the clock-limited share of 
 for flag, so in (('--exp', 'libron_hip_exp.so'), ('--diag', 'libron_hip_diag.so')):
     if flag in sys.argv:
         sys.argv.remove(flag)
-        os.environ['RON_HIP_LIB'] = os.path.join(ROOT, 'ron_tensorflow_amd', so)
+        os.environ['RON_HIP_LIB'] = os.path.join(ROOT, 'tools', 'experiments', so)
 from ron_tensorflow_amd import _lib
 
 # name, h, w, cin, cout, k, stride, rate, transpose
