@@ -335,7 +335,7 @@ double ron_flops_per_image(const ron_ctx* ctx);
  * no work of their own.  *name points into the context and stays valid until ron_destroy. */
 int ron_profile_enable(ron_ctx* ctx, int enable);
 int ron_profile_num_ops(const ron_ctx* ctx);
-/* Grouped launches in the plan of this context: 7 (RON-320), 5 (SSD-512); 0 with RON_CFG_NO_GROUPS / RON_CFG_MULTI_STREAM. */
+/* Grouped launches in the plan of this context: 8 (RON-320), 5 (SSD-512); 0 with RON_CFG_NO_GROUPS / RON_CFG_MULTI_STREAM. */
 int ron_num_grouped_launches(const ron_ctx* ctx);
 int ron_profile_get(ron_ctx* ctx, int i, const char** name, int* is_conv, double* flops_per_image,
                     double* total_ms, int* launches, double* act_bytes_per_image, double* weight_bytes);

@@ -106,6 +106,9 @@ std::vector<uint8_t> pack_conv_c64_weights(const std::vector<float>& rows, int n
 bool conv_patch_applicable(const ConvLaunch& c);
 int conv_patch_pick(const ConvLaunch& c);          // kCfgPatch* when the patch kernel is the better choice for this launch, else -1
 int launch_conv_patch(const ConvLaunch& c, int cfg, hipStream_t stream);
+// two convolutions over channel slices of the same map as ONE launch of the patch kernel (the skinny heads of a scale)
+bool conv_patch_pair_applicable(const ConvLaunch& a, const ConvLaunch& b);
+int launch_conv_patch_pair(const ConvLaunch& a, const ConvLaunch& b, hipStream_t stream);
 // Elements along K one staging step covers for this dtype (Cin must be a multiple of it).
 int conv_k_chunk(int dtype);
 int conv_n_tile(int cout);       // granularity Cout is padded to (64 or 128)

@@ -650,6 +650,10 @@ static int64_t group_slab_bytes(const ConvLaunch& c, int cfg) {
 
 int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg) {
   int64_t total = 0;
+  if (cfg == kCfgPatch64) {                      // a pair of the patch kernel, or each launch on its own
+    for (int k = 0; k < n; ++k) total = std::max(total, conv_scratch_bytes(ls[k]));
+    return total;
+  }
   for (int k = 0; k < n; ++k) total += group_slab_bytes(ls[k], cfg);
   return total;
 }
@@ -658,6 +662,17 @@ int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg) {
 // `scratch`: conv_group_scratch_bytes() for the split-K slabs (each conv gets its own part).
 int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
   RON_REQUIRE(n >= 1 && n <= kMaxGroup, "conv group: %d launches (1..%d)", n, kMaxGroup);
+  if (cfg == kCfgPatch64) {
+    // the two skinny heads of a scale: one launch of the patch kernel where it is the choice for both (dtype, map, batch),
+    // otherwise each as the launch it would be on its own
+    RON_REQUIRE(n == 2, "conv group: the patch-kernel form takes a pair");
+    if (conv_patch_pair_applicable(ls[0], ls[1])) return launch_conv_patch_pair(ls[0], ls[1], stream);
+    for (int k = 0; k < n; ++k) {
+      const int rc = launch_conv(ls[k], stream);
+      if (rc) return rc;
+    }
+    return RON_OK;
+  }
   RON_REQUIRE(cfg == kCfgIgemm128x64 || cfg == kCfgIgemm128, "conv group: tile config %d has no grouped form", cfg);
   const int BM = igemm_bm(cfg), BN = igemm_bn(cfg);
   ConvGroupArgs g = ConvGroupArgs();

@@ -44,9 +44,10 @@ struct PatchArgs {
 // SB weight stages: SB-1 steps of lead for the per-tap weight tiles.
 // EXP (experimental builds only, make EXP=1; 0 in everything the shipped library holds): bit 0 = no patch traffic, bit 1 =
 // no weight traffic (zero-record descriptors: timing only, results wrong).
+// One tile of convolution `p` (geometry `pa`): workgroup `bid` of the `nwg` that convolution's launch -- or its share of a pair
+// launch -- consists of.
 template <class Tr, int BN, int WN, int SB, int EXP = 0>
-__global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
-  const ConvArgs& p = pa.c;
+__device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const ConvArgs& p, const unsigned bid, const unsigned nwg) {
   constexpr int BM = 256, WM = 8 / WN, kThreads = 512;
   constexpr int MT = Tr::kMT, kGroups = 64 / MT, KS = 8 / kGroups, EPA = MT * MT / 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -67,7 +68,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
 
-  const unsigned nwg = gridDim.x, bid = blockIdx.x;
   const unsigned xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
   const unsigned wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tile_n = (int)(wgid % (unsigned)p.tiles_n);
@@ -282,6 +282,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
 }
 
 template <class Tr, int BN, int WN, int SB, int EXP = 0>
+__global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
+  conv3x3_patch_tile<Tr, BN, WN, SB, EXP>(pa, pa.c, blockIdx.x, gridDim.x);
+}
+
+// Two convolutions over the SAME input tensor geometry (channel slices of one map: the Cout = 20 / 40 heads of a scale read
+// slices of the per-scale concatenated tensor, nets/ron_vgg_320.py:406-415,427-428) in ONE launch: workgroups [0, first) run
+// `pa.c`, the rest `second`, each exactly as its own launch would.  Alone each fills 200 of the 512 workgroup slots.
+template <class Tr, int BN, int WN, int SB>
+__global__ __launch_bounds__(512, 2) void conv3x3_patch_pair_kernel(PatchArgs pa, ConvArgs second, int first) {
+  const int b = (int)blockIdx.x;
+  if (b < first) conv3x3_patch_tile<Tr, BN, WN, SB, 0>(pa, pa.c, (unsigned)b, (unsigned)first);
+  else conv3x3_patch_tile<Tr, BN, WN, SB, 0>(pa, second, (unsigned)(b - first), gridDim.x - (unsigned)first);
+}
+
+template <class Tr, int BN, int WN, int SB>
+int launch_patch_pair_t(const PatchArgs& a, const ConvArgs& second, int first, int grid, hipStream_t s) {
+  const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
+  static PerDeviceOnce once;
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_patch_pair_kernel<Tr, BN, WN, SB>), (int)lds));
+  hipLaunchKernelGGL((conv3x3_patch_pair_kernel<Tr, BN, WN, SB>), dim3(grid), dim3(512), lds, s, a, second, first);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+template <class Tr, int BN, int WN, int SB, int EXP = 0>
 int launch_patch_t(const PatchArgs& a, int grid, hipStream_t s) {
   const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
   static PerDeviceOnce once;
@@ -336,7 +361,8 @@ int conv_patch_pick(const ConvLaunch& c) {
   return g.tiles_sp >= 192 ? kCfgPatch64 : -1;
 }
 
-int launch_conv_patch(const ConvLaunch& c, int cfg, hipStream_t stream) {
+// Kernel arguments of launch `c` with N tile BN; *grid = its workgroups.
+static int patch_args(const ConvLaunch& c, int cfg, PatchArgs* out, int* grid) {
   RON_REQUIRE(conv_patch_applicable(c), "patch kernel: not a 3x3 / stride 1 / pad 1 conv on a map it can tile");
   RON_REQUIRE(conv_cfg_is_patch(cfg) && cfg < kNumCfgsBuilt, "patch kernel: bad tile config %d", cfg);
   const int BN = patch_bn(cfg);
@@ -358,7 +384,48 @@ int launch_conv_patch(const ConvLaunch& c, int cfg, hipStream_t stream) {
   a.P0 = c.in.pad * c.in.Wp();
   a.max_pixel = (unsigned)(c.in.bytes / ((int64_t)c.in.cstride * esz) - 1);
   a.c.tiles_n = c.Npad / BN;
-  const int grid = g.tiles_sp * a.c.tiles_n;
+  *grid = g.tiles_sp * a.c.tiles_n;
+  *out = a;
+  return RON_OK;
+}
+
+// Can `a` and `b` share a launch of the patch kernel (conv3x3_patch_pair_kernel)?  Same input tensor and geometry (channel
+// slices may differ), same dtype and N tile, no fused pool, and each big enough for the patch kernel to be the choice at all.
+bool conv_patch_pair_applicable(const ConvLaunch& a, const ConvLaunch& b) {
+  if (!conv_patch_applicable(a) || !conv_patch_applicable(b) || a.pool || b.pool) return false;
+  if (a.dtype != b.dtype || a.in.base != b.in.base || a.in.bytes != b.in.bytes || a.in.N != b.in.N || a.in.H != b.in.H || a.in.W != b.in.W ||
+      a.in.pad != b.in.pad || a.in.cstride != b.in.cstride || a.in.C != b.in.C)
+    return false;
+  const int ca = conv_patch_pick(a), cb = conv_patch_pick(b);
+  return ca >= 0 && ca == cb;
+}
+
+int launch_conv_patch_pair(const ConvLaunch& ca, const ConvLaunch& cb, hipStream_t stream) {
+  RON_REQUIRE(conv_patch_pair_applicable(ca, cb), "patch kernel pair: the two convolutions cannot share a launch");
+  const int cfg = conv_patch_pick(ca);
+  PatchArgs a, b;
+  int grid_a = 0, grid_b = 0, rc;
+  if ((rc = patch_args(ca, cfg, &a, &grid_a)) || (rc = patch_args(cb, cfg, &b, &grid_b))) return rc;
+  const int grid = grid_a + grid_b;
+  const int BN = patch_bn(cfg);
+#define RON_PATCH_PAIR(Tr)                                                                          \
+  do {                                                                                              \
+    if (BN == 256) return launch_patch_pair_t<Tr, 256, 2, 2>(a, b.c, grid_a, grid, stream);         \
+    if (BN == 128) return launch_patch_pair_t<Tr, 128, 2, 3>(a, b.c, grid_a, grid, stream);         \
+    return launch_patch_pair_t<Tr, 64, 2, 3>(a, b.c, grid_a, grid, stream);                         \
+  } while (0)
+  if (ca.dtype == RON_DTYPE_BF16) RON_PATCH_PAIR(TraitsBF16S);
+  if (ca.dtype == RON_DTYPE_F16) RON_PATCH_PAIR(TraitsF16S);
+  RON_PATCH_PAIR(TraitsF32S);
+#undef RON_PATCH_PAIR
+}
+
+int launch_conv_patch(const ConvLaunch& c, int cfg, hipStream_t stream) {
+  PatchArgs a;
+  int grid = 0;
+  const int rc0 = patch_args(c, cfg, &a, &grid);
+  if (rc0) return rc0;
+  const int BN = patch_bn(cfg);
 #ifdef RON_EXP
 #define RON_PATCH_EXP(Tr)                                                                            \
     if (cfg == kExpPatch128S4) return launch_patch_t<Tr, 128, 2, 4>(a, grid, stream);                \

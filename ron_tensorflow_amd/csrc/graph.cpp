@@ -469,10 +469,10 @@ void plan_groups(ron_ctx* c) {
       {-1, {"block4_trio3"}},
       {-1, {"block5_cls_pred"}},             // grouped with block4_inception1_1x1 it ran 8 % slower than the two alone
       {-1, {"block4_inception1_1x1"}},
-      {-1, {"block4_objectness_score"}},
+      // Cout = 20 / 40 over channel slices of the same tensor: one launch of the halo-patch kernel (400 workgroups; 200 each alone)
+      {kCfgPatch64, {"block4_objectness_score", "block4_loc_pred"}},
       {-1, {"block4_inception2_3x3"}},
       {-1, {"block4_inception2_1x1"}},
-      {-1, {"block4_loc_pred"}},
       {-1, {"block4_cls_pred"}},
   };
   const std::vector<Slot>& order = c->is_ssd() ? ssd_order : ron_order;
