@@ -51,6 +51,10 @@ struct ConvArgs {
   // fused 2x2 / stride-2 max-pool: tile rows are ordered window-major (rows 4q..4q+3 = the four conv outputs of
   // pooled pixel q), which puts a window into four consecutive accumulator registers of one lane.
   int pool;
+  // fused pool + the full-resolution map too (conv4_3 / conv5_3 feed both their pool and a reverse-connection conv): `out2` is the
+  // un-pooled output view, written from the same accumulators; nullptr = pooled map only
+  void* out2;
+  int out2_Hp, out2_Wp, out2_cstride, out2_pad, out2_coff;
   // tile order inside an XCD's run of workgroups: 0 = N fastest (the column tiles that re-read one activation tile share an L2),
   // 1 = M fastest (the row tiles that re-read one weight slice do: fc6's 205 MB of weights are then fetched once, not once per XCD)
   int m_fastest;
@@ -253,13 +257,37 @@ typedef __attribute__((address_space(3))) void lds_void;
 // per row (dtype or fp32).  s_out_off[row] = element offset of the row's output pixel, -1 for rows that store nothing.
 template <class Tr, int MR, int NR, int MT, int EPA>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, typename Tr::acc_t (&acc)[MR][NR], const int* s_out_off, int row0,
-                                              int fh, int n_glob, int n_store, int tap_off) {
+                                              int fh, int n_glob, int n_store, int tap_off, const int* s_out2_off = nullptr) {
   float bias_v[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) bias_v[j] = p.bias[n_glob + j];
   const int n_valid = p.Cout - n_glob;                 // channels of this lane's group that exist (may be <= 0)
   if (n_valid <= 0) return;
   if (p.pool) {
+    if (p.out2 != nullptr && s_out2_off != nullptr) {
+      // the un-pooled map as well (s_out2_off[row] = element offset of the row's pixel in out2, channel slice included)
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int e = 0; e < EPA; ++e) {
+          const int ooff = s_out2_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
+          if (ooff < 0) continue;
+          float v[NR];
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            v[j] = fmaf(acc[i][j][e], p.oscale, bias_v[j]);
+            if (p.relu) v[j] = fmaxf(v[j], 0.f);
+          }
+          const int o = ooff + n_store;
+          if (n_valid >= NR) {
+            Tr::template store_vec<NR>(p.out2, o, v);
+          } else {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) if (j < n_valid) Tr::store(p.out2, o + j, v[j]);
+          }
+        }
+      }
+    }
     // max over the 2x2 window = max over registers 4t..4t+3; relu(max(x) + b) == max(relu(x + b))
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
@@ -342,6 +370,8 @@ inline void fill_conv_args(const ConvLaunch& c, ConvArgs* out) {
   a.Npad = c.Npad;
   a.splitk = 1; a.kt_split = a.KT; a.partial = nullptr;
   a.pool = c.pool;
+  a.out2 = c.out2.base;
+  a.out2_Hp = c.out2.Hp(); a.out2_Wp = c.out2.Wp(); a.out2_cstride = c.out2.cstride; a.out2_pad = c.out2.pad; a.out2_coff = c.out2.coff;
   a.m_fastest = 0;
   a.dbg = c.dbg;
   *out = a;

@@ -80,7 +80,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   constexpr bool kTablesAlias = SA > S;               // the deeper ring takes the LDS the tables would need: see SA above
   constexpr int kChunkElems = kRowBytes / Tr::kEsz;
   static_assert(SA == S || SA == S + 1, "activation ring: as deep as the weight ring, or one deeper");
-  static_assert(!kTablesAlias || 2 * BM * (int)sizeof(int) <= kBBytes, "tables must fit a weight stage");
+  static_assert(!kTablesAlias || 3 * BM * (int)sizeof(int) <= kBBytes, "tables must fit a weight stage");
   static_assert(BM % kRowsPerIt == 0 && BN % kRowsPerIt == 0 && kRowsPerIt % 16 == 0, "tile / thread-count mismatch");
   static_assert(TM % 32 == 0 && TN % 32 == 0 && S >= 2 && S <= 5, "bad wave tile / stage count");
   static_assert(NR <= 8, "vector epilogue: at most 8 channels per lane");
@@ -91,6 +91,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   char* s_b = smem + SA * kABytes;
   int* s_in_off = reinterpret_cast<int*>(kTablesAlias ? s_b + (S - 1) * kBBytes : smem + kRingBytes);
   int* s_out_off = s_in_off + BM;
+  int* s_out2_off = s_out_off + BM;                   // fused pool with the un-pooled map as a second output (ConvArgs::out2)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -126,6 +127,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
       oy = 2 * py + ((r >> 1) & 1);
       ox = 2 * px + (r & 1);
       off = ((img * p.out_Hp + py + p.out_pad) * p.out_Wp + px + p.out_pad) * p.out_cstride + p.out_coff;
+      if (p.out2 != nullptr && in_off != nullptr)
+        s_out2_off[r] = valid ? ((img * p.out2_Hp + oy + p.out2_pad) * p.out2_Wp + ox + p.out2_pad) * p.out2_cstride + p.out2_coff : -1;
     } else {
       int m = m0 + r;
       valid = m < p.M;
@@ -327,7 +330,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
     }
     return;
   }
-  conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n_base + nloc, tap_off);
+  conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n_base + nloc, tap_off, kTablesAlias ? nullptr : s_out2_off);
 }
 
 #ifdef RON_EXP
@@ -335,7 +338,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
 #endif
 
 constexpr int igemm_lds_bytes(int BM, int BN, int S, int SA) {
-  return (SA * BM + S * BN) * kRowBytes + (SA > S ? 0 : 2 * BM * (int)sizeof(int));
+  return (SA * BM + S * BN) * kRowBytes + (SA > S ? 0 : 3 * BM * (int)sizeof(int));
 }
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S, bool TI = false>
@@ -541,7 +544,7 @@ static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int 
 int conv_pick_cfg(const ConvLaunch& c) {
   const int M = c.in.N * c.Ho * c.Wo;
   if (conv_c64_applicable(c)) return kCfgC64Resident;
-  if (conv_patch_applicable(c)) {
+  if (c.out2.base == nullptr && conv_patch_applicable(c)) {
     const int cfg = conv_patch_pick(c);
     if (cfg >= 0) return cfg;
   }
@@ -575,6 +578,11 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
     RON_REQUIRE(c.up == 0 && c.res == nullptr && !c.out_f32 && c.Ho % 2 == 0 && c.Wo % 2 == 0 && c.stride == 1,
                 "conv + fused pool: plain stride-1 conv on an even map only");
     RON_REQUIRE(c.out.H == c.Ho / 2 && c.out.W == c.Wo / 2, "conv + fused pool: output view must be the pooled map");
+  }
+  if (c.out2.base != nullptr) {
+    RON_REQUIRE(c.pool && c.out2.H == c.Ho && c.out2.W == c.Wo && c.out2.C >= c.Cout && c.out2.N == c.in.N,
+                "conv: a second output is the un-pooled map of a fused-pool launch");
+    RON_REQUIRE(c.out2.pixels() * c.out2.cstride < (int64_t)1 << 31, "conv: second output too large for 32-bit offsets");
   }
   const int sk = c.splitk >= 0 ? c.splitk : conv_pick_splitk(a.tiles_total, a.KT, igemm_slots(cfg));
   if (sk > 1 && c.up == 0 && !c.pool && c.scratch != nullptr && (int64_t)sk * M * c.Npad * 4 <= c.scratch_bytes) {

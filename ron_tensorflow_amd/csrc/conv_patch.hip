@@ -365,6 +365,7 @@ int conv_patch_pick(const ConvLaunch& c) {
 static int patch_args(const ConvLaunch& c, int cfg, PatchArgs* out, int* grid) {
   RON_REQUIRE(conv_patch_applicable(c), "patch kernel: not a 3x3 / stride 1 / pad 1 conv on a map it can tile");
   RON_REQUIRE(conv_cfg_is_patch(cfg) && cfg < kNumCfgsBuilt, "patch kernel: bad tile config %d", cfg);
+  RON_REQUIRE(c.out2.base == nullptr, "patch kernel: no second (un-pooled) output");
   const int BN = patch_bn(cfg);
   RON_REQUIRE(c.Npad % BN == 0, "patch kernel: Npad %d not a multiple of the N tile %d", c.Npad, BN);
   const int esz = (int)dtype_size(c.dtype);

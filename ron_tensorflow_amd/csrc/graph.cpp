@@ -68,6 +68,8 @@ struct Op {
   int packed = -1;
   int kh = 1, kw = 1, stride = 1, dil = 1, cpad = 0, relu = 0;
   int up = 0, up_cout = 0, pool = 0;
+  int fuse_next_pool = 0;               // the next op is this conv's 2x2 pool and both maps are needed (conv4_3, conv5_3): one launch
+                                        // with two outputs whenever the conv would not split K (decided per batch in ron_forward)
   int head_kind = -1, head_layer = -1;  // 0 cls, 1 obj, 2 loc
   int Ho = 0, Wo = 0;
   int lane = 0;                         // 0 = the caller's stream; 1..3 = side streams (independent head branches)
@@ -738,6 +740,7 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
         c->ops.push_back(f);
       }
     } else {
+      if ((c->cfg.flags & RON_CFG_FUSE_POOLS) && c->ops.back().kind == OP_CONV) c->ops.back().fuse_next_pool = 1;
       Op p; p.kind = OP_POOL; p.name = pname; p.in = prev; p.out = T(p.name);
       c->ops.push_back(p);
     }
@@ -1097,6 +1100,14 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
     } else {
       ConvLaunch L;
       if ((rc = describe_conv(c, o, n, out, &L))) return rc;
+      if (o.fuse_next_pool && oi + 1 < c->ops.size() && c->ops[oi + 1].kind == OP_POOL && conv_scratch_bytes(L) == 0) {
+        // conv4_3 / conv5_3: both the map and its pool are read later.  When this launch does not split K (it does at small
+        // batches: the pool epilogue needs whole sums) the pool comes out of the same accumulators and the pool launch is skipped.
+        L.out2 = L.out;
+        L.out = c->view(c->ops[oi + 1].out, n);
+        L.pool = 1;
+        ++oi;
+      }
       if ((rc = launch_conv(L, s))) {
         std::string msg = ron_last_error();
         ron::set_error("%s: %s", o.name.c_str(), msg.c_str());

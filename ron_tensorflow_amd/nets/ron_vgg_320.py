@@ -162,10 +162,20 @@ class RONNet(object):
             pass
 
     # ------------------------------------------------------------------ reference interface
+    def _head_geometry(self):
+        """[(feat_h, feat_w, anchors per cell)] per scale and the class count, as the context computes them from the image size
+        (ron_heads_describe) -- NOT from params.feat_shapes, which callers may replace (SSDNet.update_feature_shapes does)."""
+        if getattr(self, '_geom', None) is None:
+            hd = _lib.Heads()
+            check(lib().ron_heads_describe(self._context(), C.byref(hd)))
+            self._geom = ([(int(hd.feat_h[i]), int(hd.feat_w[i]), int(hd.num_anchors[i])) for i in range(hd.num_layers)],
+                          int(hd.num_classes))
+        return self._geom
+
     def _head_buffers(self, n):
-        A, nc = len(self.params.anchor_sizes[0]) * len(self.params.anchor_ratios[0]), self.params.num_classes
+        geom, nc = self._head_geometry()
         cls, obj, loc = [], [], []
-        for (fh, fw) in self.params.feat_shapes:
+        for (fh, fw, A) in geom:
             cls.append(torch.empty((n, fh, fw, A, nc), dtype=torch.float32, device=self.device))
             obj.append(torch.empty((n, fh, fw, A, 2), dtype=torch.float32, device=self.device))
             loc.append(torch.empty((n, fh, fw, A, 4), dtype=torch.float32, device=self.device))

@@ -47,10 +47,9 @@ class SSDNet(RONNet):
         self._anchors_dev = None
 
     def _head_buffers(self, n):
-        nc = self.params.num_classes
+        geom, nc = self._head_geometry()             # from the context, not from params.feat_shapes (update_feature_shapes)
         cls, loc = [], []
-        for i, (fh, fw) in enumerate(self.params.feat_shapes):
-            a = len(self.params.anchor_sizes[i]) + len(self.params.anchor_ratios[i])
+        for (fh, fw, a) in geom:
             cls.append(torch.empty((n, fh, fw, a, nc), dtype=torch.float32, device=self.device))
             loc.append(torch.empty((n, fh, fw, a, 4), dtype=torch.float32, device=self.device))
         return cls, None, loc

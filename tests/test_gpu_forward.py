@@ -241,6 +241,31 @@ def test_fused_pools_give_identical_heads(pkg, dev, weights_reduced, images):
     b.close()
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_conv4_3_writes_its_map_and_its_pool_in_one_launch(pkg, dev, weights_reduced, dtype):
+    """With fused pools conv4_3 / conv5_3 store BOTH the full-resolution map (read by the reverse-connection conv,
+    nets/ron_vgg_320.py:495-506) and the pooled one from the same accumulators whenever the launch does not split K (batch 8:
+    conv4_3 does not, conv5_3 still does and keeps its pool launch).  Same tiles, same K order as the separate launches: the maps
+    are bit-identical, and so is everything downstream."""
+    x = torch.from_numpy(pkg['W'].synthetic_images(8, seed=31)).to(dev)
+    a = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=8, fuse_pools=True).load_weights(weights_reduced)
+    b = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=8, fuse_pools=False).load_weights(weights_reduced)
+    ha, hb = a.forward_heads(x), b.forward_heads(x)
+    for name in ('block4', 'pool4', 'block5', 'pool5'):
+        ea, eb = a.end_point(name, 8), b.end_point(name, 8)
+        assert float(eb.abs().max()) > 0
+        if dtype == 'fp32':
+            assert torch.equal(ea, eb), name
+        else:       # bf16: the fused stem / block1-3 pools reorder fp32 partial sums upstream
+            assert float((ea - eb).abs().max()) <= 0.04 * float(eb.abs().max()), name
+    if dtype == 'fp32':
+        for la, lb in zip(ha, hb):
+            for ta, tb in zip(la, lb):
+                assert float((ta - tb).abs().max()) <= 2e-5 * float(tb.abs().max())
+    a.close()
+    b.close()
+
+
 def test_multi_stream_heads_are_identical(pkg, dev, weights_reduced, images):
     """RON_CFG_MULTI_STREAM only changes which stream a head branch is enqueued on: bitwise the same tensors,
     also when calls follow each other without a host sync (fork/join ordering)."""
