@@ -20,6 +20,13 @@ constexpr int kTopkThreads = 1024;
 constexpr int kMaskWords = kMaxTopK / 64;
 constexpr int kCountStride = 32;   // ints: every per-image candidate counter on its own 128-B line (they are atomic targets)
 constexpr int kSelectCap = 1024;   // the radix select narrows to at most this many keys before the LDS sort
+// Dense images (most of the 425 k (anchor, class) pairs pass): the radix select of one workgroup reads every key once per pass,
+// ~70 us per pass over 3.4 MB.  Images with more than kPartMin candidates are first cut into kPartChunks ranges, one workgroup
+// each, which keep their own top_k; the image's workgroup then selects among the kPartChunks * top_k survivors (the global top_k
+// is a subset of the union of the ranges' top_k: same result, bit for bit).
+constexpr int kPartChunks = 8;
+constexpr int kPartMin = 16384;
+static_assert(kPartChunks * kMaxTopK <= kSortCap, "the survivors of the partial pass must fit the LDS sort");
 
 typedef unsigned long long u64;
 
@@ -539,18 +546,42 @@ __device__ __forceinline__ void decode_box(const float* l, float ya, float xa, f
 }
 
 // ------------------------------------------------------------------------------------------
+// K-topk-partial: blockIdx.x = range of the image's key list, blockIdx.y = image.  Only for images with > kPartMin keys.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTopkThreads) void topk_partial_kernel(const u64* keys, const int* counts, int cap, int top_k,
+                                                                    u64* part_keys, int* part_total) {
+  __shared__ ImageLds lds;
+  const int img = blockIdx.y, c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int m = min(counts[img * kCountStride], cap);
+  if (m <= kPartMin) return;
+  const int beg = (int)((long long)m * c / kPartChunks), end = (int)((long long)m * (c + 1) / kPartChunks);
+  const int n = topk_keys(keys + (size_t)img * cap + beg, end - beg, top_k, lds);
+  if (tid == 0) lds.scalars[5] = atomicAdd(&part_total[img * kCountStride], n);
+  __syncthreads();
+  u64* dst = part_keys + (size_t)img * (kPartChunks * kMaxTopK) + lds.scalars[5];
+  for (int r = tid; r < n; r += blockDim.x) dst[r] = lds.sort[r];
+}
+
+// ------------------------------------------------------------------------------------------
 // K-topk-nms: one workgroup per image.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kTopkThreads) void topk_nms_kernel(HeadsDev hd, PostDev pc, const u64* keys,
-                                                                const int* counts, int cap, DetDev out,
+                                                                const int* counts, int cap, const u64* part_keys,
+                                                                const int* part_total, DetDev out,
                                                                 DetDev sorted_out, int* n_candidates) {
   __shared__ ImageLds lds;
   const int img = blockIdx.x;
   const int tid = threadIdx.x;
   const int m_raw = counts[img * kCountStride];
   if (tid == 0 && n_candidates != nullptr) n_candidates[img] = m_raw;
-  const int m = min(m_raw, cap);
-  const int n = topk_keys(keys + (size_t)img * cap, m, pc.top_k, lds);
+  int m = min(m_raw, cap);
+  const u64* my_keys = keys + (size_t)img * cap;
+  if (m > kPartMin) {                 // the partial pass ran for this image: select among its survivors
+    my_keys = part_keys + (size_t)img * (kPartChunks * kMaxTopK);
+    m = part_total[img * kCountStride];
+  }
+  const int n = topk_keys(my_keys, m, pc.top_k, lds);
   // keys -> records.  Each thread keeps its key in a register before the LDS region is reused.
   const int C1 = hd.num_classes - 1;
   for (int r = tid; r < n; r += blockDim.x) {
@@ -702,7 +733,8 @@ extern "C" int64_t ron_post_np_workspace_bytes(const ron_heads* heads, int n) {
   HeadsDev hd;
   if (build_heads_dev(heads, &hd, false) != RON_OK || n <= 0) return -1;
   const int64_t cap = (int64_t)hd.anchor_base[RON_MAX_LAYERS] * (heads->num_classes - 1);
-  return ron::align_up((int64_t)n * kCountStride * 4, 256) + (int64_t)n * cap * 8;
+  // [candidate counts][survivor counts of the partial pass][keys][survivors]
+  return 2 * ron::align_up((int64_t)n * kCountStride * 4, 256) + (int64_t)n * cap * 8 + (int64_t)n * kPartChunks * kMaxTopK * 8;
 }
 
 extern "C" int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cfg, void* workspace,
@@ -725,14 +757,20 @@ extern "C" int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cf
   pc.top_k = cfg->top_k; pc.flags = cfg->input_flags;
   for (int i = 0; i < 4; ++i) { pc.ref[i] = cfg->bbox_img[i]; pc.ps[i] = cfg->prior_scaling[i]; }
   hipStream_t s = (hipStream_t)stream;
-  int* counts = (int*)workspace;
-  u64* keys = (u64*)((char*)workspace + ron::align_up((int64_t)n * kCountStride * 4, 256));
+  const int64_t cnt_bytes = ron::align_up((int64_t)n * kCountStride * 4, 256);
   const int cap = hd.anchor_base[RON_MAX_LAYERS] * (hd.num_classes - 1);
-  RON_HIP_CHECK(hipMemsetAsync(counts, 0, ron::align_up((int64_t)n * kCountStride * 4, 256), s));
+  int* counts = (int*)workspace;
+  int* part_total = (int*)((char*)workspace + cnt_bytes);
+  u64* keys = (u64*)((char*)workspace + 2 * cnt_bytes);
+  u64* part_keys = keys + (size_t)n * cap;
+  RON_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * cnt_bytes, s));
   dim3 grid(hd.block_base[RON_MAX_LAYERS], n);
   const size_t lds = (size_t)kSelectThreads * hd.num_classes * sizeof(float);
   hipLaunchKernelGGL(select_kernel, grid, dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
-  hipLaunchKernelGGL(topk_nms_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, d_out,
+  // only lists that can exceed kPartMin need the partial pass at all (its workgroups return at once for shorter ones)
+  if (cap > kPartMin)
+    hipLaunchKernelGGL(topk_partial_kernel, dim3(kPartChunks, n), dim3(kTopkThreads), 0, s, keys, counts, cap, pc.top_k, part_keys, part_total);
+  hipLaunchKernelGGL(topk_nms_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, part_keys, part_total, d_out,
                      d_sorted, n_candidates);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;

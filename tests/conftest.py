@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the application's job: one hardware queue per stream for the two-slot pipeline tests; read when HIP initialises
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
