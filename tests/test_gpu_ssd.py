@@ -90,6 +90,28 @@ def test_ssd_bf16_forward(setup, dev):
     net.close()
 
 
+def test_ssd_split_precision_forward_and_detect(setup, dev):
+    """SSD-512 in dtype 'f16x3' (split precision: fp32-grade results on the f16 matrix cores) against the all-fp32 oracle: head
+    tensors within 2e-5 of their scale (rate-6 conv6, the stride-2 / 4x4 VALID extra blocks and the L2 normalisation included),
+    detections of the fused path == the oracle's np_methods pipeline on the oracle's own heads up to threshold ties."""
+    from ron_tensorflow_amd.metrics import detection_agreement
+    cls = setup['factory'].get_network('ssd_512_vgg')
+    net = cls(cls.default_params._replace(num_classes=21), dtype='f16x3', max_batch=1, fuse_pools=True).load_weights(setup['weights'])
+    x = torch.from_numpy(setup['images']).to(dev)
+    logits, _, loc = net.forward_heads(x)
+    r_pred, r_loc, r_logits, _ = setup['ref']
+    for i in range(7):
+        assert _rel(logits[i].cpu().numpy(), r_logits[i]) < 2e-5, i
+        assert _rel(loc[i].cpu().numpy(), r_loc[i]) < 2e-5, i
+    assert _rel(net.end_point('block4_norm', 1).cpu().numpy(), setup['col']['block4_norm']) < 2e-5
+    det = net.detect(x).to_lists()[0]
+    want = np_post.detect_from_predictions(r_pred, r_loc, osf.anchors_all_layers(), objness_pred=None,
+                                           prior_scaling=net.params.prior_scaling)[0]
+    a = detection_agreement(det, want, tol=1e-4)
+    assert a['reproduced'] >= 0.98 and a['within_tol'] == 1.0, a
+    net.close()
+
+
 def test_network_fn_ssd(setup, dev):
     fn = setup['factory'].get_network_fn('ssd_512_vgg', 21, is_training=False, weights=setup['weights'], dtype='bf16', max_batch=1)
     assert fn.default_image_size == 512
