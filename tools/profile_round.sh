@@ -7,6 +7,11 @@ O=gpurun_out/final
 mkdir -p $O
 python3 bench.py --layers $O/layers_cfg2_inflight2.txt > $O/bench_cfg2_default.json 2> $O/bench_cfg2_default.err
 python3 bench.py --no-cpu-baseline --in-flight 1 --layers $O/layers_cfg2_inflight1.txt > $O/bench_cfg2_inflight1.json 2>> $O/err.txt
+# the modes that meet north_star's 1e-4 clause: split precision (three f16 MFMAs per product) and exact-fp32 MFMA; both lines carry
+# <dtype>_vs_fp32_oracle_agreement (cpu_baseline leg on)
+python3 bench.py --dtype f16x3 --layers $O/layers_cfg2_f16x3.txt > $O/bench_cfg2_f16x3.json 2>> $O/err.txt
+python3 bench.py --dtype f16x3 --no-cpu-baseline --in-flight 1 > $O/bench_cfg2_f16x3_inflight1.json 2>> $O/err.txt
+python3 bench.py --dtype fp32 --steps 10 --warmup 3 --layers $O/layers_cfg2_fp32.txt > $O/bench_cfg2_fp32.json 2>> $O/err.txt
 python3 bench.py --no-cpu-baseline --variant reducedfc --dtype fp16 --batch 64 --layers $O/layers_cfg4.txt > $O/bench_cfg4.json 2>> $O/err.txt
 python3 bench.py --no-cpu-baseline --variant ssd512 --batch 16 --layers $O/layers_cfg5.txt > $O/bench_cfg5.json 2>> $O/err.txt
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --no-cpu-baseline --check-gather > $O/bench_cfg2_torchrun_1rank.json 2>> $O/err.txt
@@ -16,11 +21,16 @@ for d in if1 if2; do f=$(ls $O/prof_$d/*/*kernel_stats.csv 2>/dev/null | head -1
 bash tools/pmc_bench.sh $O/pmc --in-flight 1 > $O/pmc.log 2>&1
 cp $O/pmc/traffic_*.json $O/ 2>/dev/null
 bash tools/pmc_mfma.sh $O/pmc > $O/pmc_mfma.log 2>&1
+bash tools/pmc_bench.sh $O/pmc --in-flight 1 --dtype f16x3 > $O/pmc_f16x3.log 2>&1
+bash tools/pmc_mfma.sh $O/pmc --dtype f16x3 > $O/pmc_mfma_f16x3.log 2>&1
+cp $O/pmc/traffic_*.json $O/ 2>/dev/null
 cp $O/pmc/mfma_busy_*.json $O/ 2>/dev/null
+python3 tools/post_regimes.py > $O/post_regimes.txt 2>> $O/err.txt
+BATCHES="1 2 4 8 16 32" bash tools/batch_sweep.sh > $O/batch_sweep.txt 2>> $O/err.txt
 rm -rf $O/prof_if1 $O/prof_if2 $O/pmc/pmc_fetch $O/pmc/pmc_write $O/pmc/pmc_mfma
 ls -la $O
 tail -3 $O/pmc.log; tail -30 $O/pmc_mfma.log
-for f in bench_cfg2_default bench_cfg2_inflight1 bench_cfg4 bench_cfg5 bench_cfg2_torchrun_1rank; do python3 - "$O/$f.json" <<'PY'
+for f in bench_cfg2_default bench_cfg2_inflight1 bench_cfg2_f16x3 bench_cfg2_f16x3_inflight1 bench_cfg2_fp32 bench_cfg4 bench_cfg5 bench_cfg2_torchrun_1rank; do python3 - "$O/$f.json" <<'PY'
 import json,sys
 try:
     l=[x for x in open(sys.argv[1]) if x.startswith('{')][-1]; d=json.loads(l)
