@@ -1100,13 +1100,17 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
     } else {
       ConvLaunch L;
       if ((rc = describe_conv(c, o, n, out, &L))) return rc;
-      if (o.fuse_next_pool && oi + 1 < c->ops.size() && c->ops[oi + 1].kind == OP_POOL && conv_scratch_bytes(L) == 0) {
+      if (o.fuse_next_pool && oi + 1 < c->ops.size() && c->ops[oi + 1].kind == OP_POOL) {
         // conv4_3 / conv5_3: both the map and its pool are read later.  When this launch does not split K (it does at small
         // batches: the pool epilogue needs whole sums) the pool comes out of the same accumulators and the pool launch is skipped.
-        L.out2 = L.out;
-        L.out = c->view(c->ops[oi + 1].out, n);
-        L.pool = 1;
-        ++oi;
+        ConvLaunch F = L;
+        F.out2 = L.out;                           // the kernel choice of a two-output launch (row-gather kernel only) ...
+        if (conv_scratch_bytes(F) == 0) {         // ... would not split K at this batch
+          F.out = c->view(c->ops[oi + 1].out, n);
+          F.pool = 1;
+          L = F;
+          ++oi;
+        }
       }
       if ((rc = launch_conv(L, s))) {
         std::string msg = ron_last_error();
