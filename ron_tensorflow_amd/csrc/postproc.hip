@@ -189,6 +189,7 @@ struct ImageLds {
   int order[kMaxTopK];             // class-grouped position -> sorted row (class-wise NMS)
   int keep[kMaxTopK];              // sorted row -> kept?
   int cstart[66];                  // first class-grouped position of every class
+  float gbox[kMaxTopK][4];         // boxes in class-grouped order (class-wise NMS: no double indirection in the pair loop)
 };
 
 __device__ void bitonic_sort_desc(u64* s, int n2, int tid, int nthreads) {
@@ -417,31 +418,41 @@ __device__ void nms_scan_classwise(ImageLds& lds, int n, float nms_thr, int num_
     lds.keep[i] = 0;
   }
   __syncthreads();
-  for (int a = wave; a < n; a += nwaves) {   // suppression bits of grouped row a
+  for (int a = tid; a < n; a += nth) {       // boxes in grouped order
     const int ia = lds.order[a];
-    const int s1 = lds.cstart[(lds.cls[ia] & 63) + 1];
-    for (int w = 0; w < words; ++w) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lds.gbox[a][q] = lds.box[ia][q];
+  }
+  __syncthreads();
+  for (int a = wave; a < n; a += nwaves) {   // suppression bits of grouped row a: only the words that overlap (a, end of its class)
+    const int s1 = lds.cstart[(lds.cls[lds.order[a]] & 63) + 1];
+    const int w0 = a >> 6, w1 = (s1 - 1) >> 6;
+    float ba[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ba[q] = lds.gbox[a][q];
+    for (int w = w0; w <= w1; ++w) {
       const int b = (w << 6) + lane;
-      u64 bits = 0;
-      if ((w << 6) + 63 > a && (w << 6) < s1) {           // wave-uniform: the word overlaps (a, s1)
-        bool sup = false;
-        if (b > a && b < s1) sup = nms_suppresses(lds.box[ia], lds.box[lds.order[b]], nms_thr);
-        bits = __ballot(sup);
-      }
+      bool sup = false;
+      if (b > a && b < s1) sup = nms_suppresses(ba, lds.gbox[b], nms_thr);
+      const u64 bits = __ballot(sup);
       if (lane == 0) mask[a * kMaskWords + w] = bits;
     }
   }
   __syncthreads();
   for (int c = wave; c < 64 && c < num_classes; c += nwaves) {   // one wave per class
     const int s0 = lds.cstart[c], s1 = lds.cstart[c + 1];
-    u64 removed = 0;
+    if (s0 >= s1) continue;
+    const int w1 = (s1 - 1) >> 6;
+    u64 removed = 0;                           // lane w: word w of the class's "removed" set
     for (int a = s0; a < s1; ++a) {
       const int wi = a >> 6;
       const unsigned lo = __builtin_amdgcn_readlane((unsigned)(removed & 0xFFFFFFFFull), wi);
       const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), wi);
       const u64 rw = ((u64)hi << 32) | lo;
       if (((rw >> (a & 63)) & 1ull) == 0) {
-        if (lane < words) removed |= mask[a * kMaskWords + lane];
+        // only a kept row pays the LDS round trip for its mask (measured: fetching every row one ahead, or holding 64 rows in
+        // registers and chaining readlanes, both take longer on a 218-row class); words [a >> 6, w1] of row a were written
+        if (lane >= wi && lane <= w1) removed |= mask[a * kMaskWords + lane];
         if (lane == 0) lds.keep[lds.order[a]] = 1;
       }
     }
