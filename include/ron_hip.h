@@ -290,6 +290,11 @@ typedef struct {
  * block5) run as grouped launches, several convolutions per launch (33 head launches -> 18); this flag keeps one launch
  * per convolution (same results up to the order of the fp32 partial sums: the split of K differs; tests compare the two). */
 #define RON_CFG_NO_GROUPS 8u
+/* Small maps with large filters spend a good part of their MACs on the zero halo (fc6: 7x7 on 10 x 10, 31 %; conv6 of SSD-512;
+ * the 3x3 heads of the 5 x 5 / 10 x 10 scales).  By default such launches order their GEMM rows position-major and every tile
+ * skips the filter rows that fall outside the image for all of its rows (bit-identical results: only products with zeros go).
+ * This flag keeps the image-major order and the full K loop (tests compare the two). */
+#define RON_CFG_NO_HALO_SKIP 16u
 
 int ron_create(ron_ctx** out, const ron_config* cfg);
 int ron_destroy(ron_ctx* ctx);

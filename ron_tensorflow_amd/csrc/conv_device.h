@@ -58,6 +58,10 @@ struct ConvArgs {
   // tile order inside an XCD's run of workgroups: 0 = N fastest (the column tiles that re-read one activation tile share an L2),
   // 1 = M fastest (the row tiles that re-read one weight slice do: fc6's 205 MB of weights are then fetched once, not once per XCD)
   int m_fastest;
+  // Rows ordered position-major (m = (oy * Wo + ox) * n_img + img) instead of image-major: a tile then covers few output rows oy,
+  // and the filter rows ky whose taps fall into the zero halo for ALL of them are skipped (K range [kt0, kt1) of the tile).
+  // fc6 (7x7 on a 10 x 10 map): 31 % of the MACs multiply halo zeros; skipping whole filter rows per tile recovers half of that.
+  int pos_major, n_img, in_H, cpad, kh;
   // diagnostic builds only (ABL 5): per-wave cycle sums {wait, barrier, compute, K steps}, 4 x u64 per wave
   unsigned long long* dbg;
 };
@@ -373,6 +377,7 @@ inline void fill_conv_args(const ConvLaunch& c, ConvArgs* out) {
   a.out2 = c.out2.base;
   a.out2_Hp = c.out2.Hp(); a.out2_Wp = c.out2.Wp(); a.out2_cstride = c.out2.cstride; a.out2_pad = c.out2.pad; a.out2_coff = c.out2.coff;
   a.m_fastest = 0;
+  a.pos_major = 0; a.n_img = c.in.N; a.in_H = c.in.H; a.cpad = c.cpad; a.kh = c.kh;
   a.dbg = c.dbg;
   *out = a;
 }

@@ -47,6 +47,7 @@ struct ConvLaunch {
   int Ho = 0, Wo = 0;            // GEMM rows = N*Ho*Wo (input grid for a transposed conv)
   int pool = 0;                  // fuse slim.max_pool2d [2,2] into the epilogue: `out` is the pooled map
   TensorView out2;               // with pool: the un-pooled map too (base == nullptr: none), same dtype, geometry Ho x Wo x Cout
+  int halo_skip = 1;             // position-major rows + per-tile skipping of filter rows that only see the halo, where it pays (0: never)
   int cfg = -1;                  // tile configuration (kCfg* below); -1 = pick by shape
   int splitk = -1;               // split-K factor; -1 = pick by grid size, 1 = off
   void* scratch = nullptr;       // fp32 slabs for split-K (conv_scratch_bytes); null disables split-K

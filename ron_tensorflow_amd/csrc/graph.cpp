@@ -939,6 +939,7 @@ static int describe_conv(const ron_ctx* c, const Op& o, int n, const ron_heads* 
   L.kh = o.kh; L.kw = o.kw; L.stride = o.stride; L.dil = o.dil; L.cpad = o.cpad; L.relu = o.relu;
   L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo; L.pool = o.pool;
   L.scratch = c->d_splitk[o.lane]; L.scratch_bytes = c->splitk_bytes[o.lane];
+  L.halo_skip = (c->cfg.flags & RON_CFG_NO_HALO_SKIP) ? 0 : 1;
   *out_l = L;
   return RON_OK;
 }

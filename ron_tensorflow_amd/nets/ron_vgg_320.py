@@ -67,7 +67,8 @@ class RONNet(object):
                               (_lib.RON_CFG_FUSE_POOLS if self.fuse_pools else 0) |
                               (_lib.RON_CFG_MULTI_STREAM if getattr(self, 'multi_stream', False) else 0) |
                               (_lib.RON_CFG_NO_STEM2 if getattr(self, 'no_stem2', False) else 0) |
-                              (_lib.RON_CFG_NO_GROUPS if getattr(self, 'no_groups', False) else 0))
+                              (_lib.RON_CFG_NO_GROUPS if getattr(self, 'no_groups', False) else 0) |
+                              (_lib.RON_CFG_NO_HALO_SKIP if getattr(self, 'no_halo_skip', False) else 0))
             h = C.c_void_p()
             check(lib().ron_create(C.byref(h), C.byref(cfg)))
             self._ctx = h

@@ -359,3 +359,43 @@ def test_split_precision_weight_scale_is_exact(ops, dev):
         got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, None, relu=False, dtype='f16x3').cpu().numpy()
         err = np.abs(got - ref).max() / np.abs(ref).max()
         assert err <= 4e-6, (wscale, err)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# position-major rows + skipping of filter rows that only see the zero halo (ConvArgs::pos_major)
+# ---------------------------------------------------------------------------------------------------------------------
+HALO_SHAPES = [  # n, h, w, cin, cout, k, rate: small maps, many images -> a tile covers few output rows
+    (32, 10, 10, 64, 256, 7, 1),     # fc6-like: 13 row tiles of 256, 4..7 of the 7 filter rows each
+    (32, 5, 5, 128, 256, 3, 1),      # 3x3 on 5 x 5: the first and last output row skip a filter row
+    (32, 10, 10, 64, 128, 3, 3),     # fc6 reduced: rate 3, rows 0-2 / 7-9 skip a filter row
+    (24, 10, 10, 128, 210, 3, 1),    # masked N tail, ragged last tile
+    (16, 16, 16, 64, 256, 3, 6),     # rate 6 on a 16 x 16 map (conv6 of SSD-512 in small)
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32', 'f16x3'])
+@pytest.mark.parametrize('shape', HALO_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_halo_filter_rows_are_skipped_not_missed(ops, dev, shape, dtype):
+    """Launches whose rows the library orders position-major (a tile = the same few output positions of many images) and whose
+    tiles skip the filter rows that fall into the zero halo for all of their rows -- alone, with every split-K factor (slices share
+    what is left of the tile's K range; some are empty), with a residual, in every row-gather tile -- against the oracle conv."""
+    n, h, w, cin, cout, k, rate = shape
+    rs = np.random.RandomState(sum(shape))
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    b = (rs.randn(cout) * 0.1).astype(np.float32)
+    res = np.maximum(rs.randn(n, h, w, cout), 0).astype(np.float32)
+    rnd = ROUND[dtype]
+    conv = orf.conv2d_np(rnd(x), rnd(wt), 1, rate) + b
+    ref = np.maximum(conv, 0)
+    ref_res = np.maximum(ref + rnd(res), 0)
+    xd = torch.from_numpy(x).to(dev)
+    cfgs = (-1, 0, 1) if cout % 256 == 0 else (-1, 1)        # tile 0 = 256 x 256
+    for cfg in cfgs:
+        for splitk in (1, 2, 5, -1):
+            got = ops.conv2d_nhwc(xd, wt, b, dilation=rate, relu=True, dtype=dtype, tile_cfg=cfg, splitk=splitk).cpu().numpy()
+            _check(got, ref, dtype)
+    got = ops.conv2d_nhwc(xd, wt, b, residual=torch.from_numpy(res).to(dev), dilation=rate, relu=True, dtype=dtype, splitk=1).cpu().numpy()
+    _check(got, ref_res, dtype)
+    got = ops.conv2d_nhwc(xd, wt, b, residual=torch.from_numpy(res).to(dev), dilation=rate, relu=True, dtype=dtype, splitk=3).cpu().numpy()
+    _check(got, ref_res, dtype)

@@ -266,6 +266,27 @@ def test_conv4_3_writes_its_map_and_its_pool_in_one_launch(pkg, dev, weights_red
     b.close()
 
 
+@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-5), ('bf16', 2e-2)])
+def test_halo_filter_row_skipping_changes_nothing(pkg, dev, weights_reduced, dtype, tol):
+    """RON_CFG_NO_HALO_SKIP: image-major rows and the full K loop everywhere.  The default (position-major rows on the small maps,
+    tiles skip the filter rows that fall outside the image for all of their rows) only drops products with halo zeros; where K is
+    split the slices cut what is left of the range, so fp32 partial sums are grouped differently -- equal to rounding."""
+    x = torch.from_numpy(pkg['W'].synthetic_images(8, seed=41)).to(dev)
+    a = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=8).load_weights(weights_reduced)
+    b = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=8)
+    b.no_halo_skip = True
+    b.load_weights(weights_reduced)
+    ha, hb = a.forward_heads(x), b.forward_heads(x)
+    for la, lb in zip(ha, hb):
+        for ta, tb in zip(la, lb):
+            assert float((ta - tb).abs().max()) <= tol * float(tb.abs().max())
+    for name in ('block6', 'block7', 'block7_ref', 'block6_ref'):
+        ea, eb = a.end_point(name, 8), b.end_point(name, 8)
+        assert float((ea - eb).abs().max()) <= tol * float(eb.abs().max()), name
+    a.close()
+    b.close()
+
+
 def test_multi_stream_heads_are_identical(pkg, dev, weights_reduced, images):
     """RON_CFG_MULTI_STREAM only changes which stream a head branch is enqueued on: bitwise the same tensors,
     also when calls follow each other without a host sync (fork/join ordering)."""
