@@ -561,6 +561,9 @@ static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int 
 // share what is left of a tile's K range.
 static int pick_pos_major(const ConvLaunch& c, int cfg, int BM) {
   if (!c.halo_skip || c.pool || c.up > 0 || c.kh < 2 || cfg == kCfgIgemm256TapsInner) return 0;
+  // at most (kh - 1) * dil of a map's H output rows can skip anything: below 5 % there is nothing to decide (and no per-tile walk
+  // over the thousands of tiles of a large map on the launch path)
+  if ((c.kh - 1) * c.dil * 20 < c.in.H) return 0;
   const int M = c.in.N * c.Ho * c.Wo, tiles_m = (M + BM - 1) / BM;
   long long rows_all = 0, rows_kept = 0;
   for (int t = 0; t < tiles_m; ++t) {
