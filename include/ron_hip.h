@@ -287,7 +287,7 @@ typedef struct {
  * (neither 64-channel full-resolution map touches HBM).  This flag keeps them as separate launches (A/B tests). */
 #define RON_CFG_NO_STEM2 4u
 /* The small, mutually independent head convolutions of the coarse scales (block7 / block6 and the 1x1 / skinny ones of
- * block5) run as grouped launches, several convolutions per launch (33 head launches -> 18); this flag keeps one launch
+ * block5) run as grouped launches, several convolutions per launch (33 head launches -> 16); this flag keeps one launch
  * per convolution (same results up to the order of the fp32 partial sums: the split of K differs; tests compare the two). */
 #define RON_CFG_NO_GROUPS 8u
 /* Small maps with large filters spend a good part of their MACs on the zero halo (fc6: 7x7 on 10 x 10, 31 %; conv6 of SSD-512;
@@ -340,7 +340,7 @@ double ron_flops_per_image(const ron_ctx* ctx);
  * no work of their own.  *name points into the context and stays valid until ron_destroy. */
 int ron_profile_enable(ron_ctx* ctx, int enable);
 int ron_profile_num_ops(const ron_ctx* ctx);
-/* Grouped launches in the plan of this context: 8 (RON-320), 5 (SSD-512); 0 with RON_CFG_NO_GROUPS / RON_CFG_MULTI_STREAM. */
+/* Grouped launches in the plan of this context: 7 (RON-320), 5 (SSD-512); 0 with RON_CFG_NO_GROUPS / RON_CFG_MULTI_STREAM. */
 int ron_num_grouped_launches(const ron_ctx* ctx);
 int ron_profile_get(ron_ctx* ctx, int i, const char** name, int* is_conv, double* flops_per_image,
                     double* total_ms, int* launches, double* act_bytes_per_image, double* weight_bytes);
@@ -369,6 +369,8 @@ typedef struct {
   int32_t in_coff;          /* ... and first channel of the slice                                              */
   int32_t pool;             /* fuse a 2x2 stride-2 max-pool into the epilogue: y is [n, h/2, w/2, cout]        */
   int32_t splitk;           /* split-K factor: -1 = by grid size, 1 = off                                      */
+  int32_t center_from;      /* > 0: output channels >= center_from have weights in the centre tap only (the caller's w is
+                             * zero elsewhere): their column tiles run that tap's K steps alone.  0 = none              */
 } ron_conv_desc;
 int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const float* w, const float* bias,
                     const float* residual, float* y, void* stream);

@@ -74,7 +74,8 @@ class ConvDesc(C.Structure):
     _fields_ = [('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('cin', C.c_int32), ('cout', C.c_int32),
                 ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('dilation', C.c_int32),
                 ('relu', C.c_int32), ('transpose', C.c_int32), ('dtype', C.c_int32), ('tile_cfg', C.c_int32),
-                ('in_cstride', C.c_int32), ('in_coff', C.c_int32), ('pool', C.c_int32), ('splitk', C.c_int32)]
+                ('in_cstride', C.c_int32), ('in_coff', C.c_int32), ('pool', C.c_int32), ('splitk', C.c_int32),
+                ('center_from', C.c_int32)]
 
 
 # every symbol include/ron_hip.h declares: (restype, argtypes)

@@ -13,7 +13,7 @@ const char* get_error() { return g_err; }
 }  // namespace ron
 
 extern "C" const char* ron_last_error(void) { return ron::get_error(); }
-extern "C" int ron_abi_version(void) { return 1; }
+extern "C" int ron_abi_version(void) { return 2; }   // 2: ron_conv_desc.center_from, RON_DTYPE_F16X3, ron_num_grouped_launches
 
 // CRC32C (Castagnoli, reflected 0x82F63B78), slicing-by-8 on the host: the checksum of TensorFlow's tensor-bundle files
 // (ron_tensorflow_amd/checkpoint.py); `crc` chains calls (0 for the first).

@@ -456,7 +456,7 @@ std::vector<uint8_t> pack_conv_c64_weights(const std::vector<float>& rows, int n
 }
 
 bool conv_c64_applicable(const ConvLaunch& c) {
-  return c.wgt_c64 != nullptr && c.out2.base == nullptr && (c.dtype == RON_DTYPE_BF16 || c.dtype == RON_DTYPE_F16) && c.kh == 3 && c.kw == 3 && c.stride == 1 &&
+  return c.wgt_c64 != nullptr && c.out2.base == nullptr && c.center_from == 0 && (c.dtype == RON_DTYPE_BF16 || c.dtype == RON_DTYPE_F16) && c.kh == 3 && c.kw == 3 && c.stride == 1 &&
          c.dil == 1 && c.cpad == 1 && c.up == 0 && !c.pool && c.res == nullptr && !c.out_f32 && c.in.C == 64 && c.in.cstride == 64 &&
          c.in.coff == 0 && c.in.pad >= 1 && c.Npad == c.Cout && c.Cout % 64 == 0 && (c.Cout / 64 == 1 || c.Cout / 64 == 2 || c.Cout / 64 == 4) &&
          c.Ho % kC6TH == 0 && c.Wo % kC6TW == 0 && c.Ho == c.in.H && c.Wo == c.in.W && c.out.cstride % 4 == 0 && c.out.coff % 4 == 0 &&

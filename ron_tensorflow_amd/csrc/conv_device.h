@@ -62,6 +62,9 @@ struct ConvArgs {
   // and the filter rows ky whose taps fall into the zero halo for ALL of them are skipped (K range [kt0, kt1) of the tile).
   // fc6 (7x7 on a 10 x 10 map): 31 % of the MACs multiply halo zeros; skipping whole filter rows per tile recovers half of that.
   int pos_major, n_img, in_H, cpad, kh;
+  // Column tiles at or beyond output channel center_from_n (0: none) hold a 1x1 branch whose weights sit in the centre tap of the
+  // kh x kw filter, zeros elsewhere: they run the K steps of that tap only.
+  int center_from_n;
   // diagnostic builds only (ABL 5): per-wave cycle sums {wait, barrier, compute, K steps}, 4 x u64 per wave
   unsigned long long* dbg;
 };
@@ -378,6 +381,7 @@ inline void fill_conv_args(const ConvLaunch& c, ConvArgs* out) {
   a.out2_Hp = c.out2.Hp(); a.out2_Wp = c.out2.Wp(); a.out2_cstride = c.out2.cstride; a.out2_pad = c.out2.pad; a.out2_coff = c.out2.coff;
   a.m_fastest = 0;
   a.pos_major = 0; a.n_img = c.in.N; a.in_H = c.in.H; a.cpad = c.cpad; a.kh = c.kh;
+  a.center_from_n = c.center_from;
   a.dbg = c.dbg;
   *out = a;
 }

@@ -47,6 +47,8 @@ struct ConvLaunch {
   int Ho = 0, Wo = 0;            // GEMM rows = N*Ho*Wo (input grid for a transposed conv)
   int pool = 0;                  // fuse slim.max_pool2d [2,2] into the epilogue: `out` is the pooled map
   TensorView out2;               // with pool: the un-pooled map too (base == nullptr: none), same dtype, geometry Ho x Wo x Cout
+  int center_from = 0;           // > 0: output channels >= center_from have weights in the CENTRE tap only (a 1x1 branch packed beside
+                                 // 3x3 ones: nets/ron_vgg_320.py:378-397); their column tiles run that tap's K steps alone
   int halo_skip = 1;             // position-major rows + per-tile skipping of filter rows that only see the halo, where it pays (0: never)
   int cfg = -1;                  // tile configuration (kCfg* below); -1 = pick by shape
   int splitk = -1;               // split-K factor; -1 = pick by grid size, 1 = off

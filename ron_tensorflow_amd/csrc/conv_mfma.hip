@@ -102,23 +102,53 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   // so the N-tiles that re-read one A tile hit the same L2.
   const unsigned xcd = bid & 7u, q = nwg >> 3, r8 = nwg & 7u;
   const unsigned wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-  const int zsplit = (int)(wgid / (unsigned)p.tiles_total);
+  int zsplit = (int)(wgid / (unsigned)p.tiles_total);
   const unsigned tile = wgid - (unsigned)zsplit * (unsigned)p.tiles_total;
   const unsigned tiles_m = (unsigned)p.tiles_total / (unsigned)p.tiles_n;
-  const int tile_n = (int)(p.m_fastest ? tile / tiles_m : tile % (unsigned)p.tiles_n);
-  const int tile_m = (int)(p.m_fastest ? tile % tiles_m : tile / (unsigned)p.tiles_n);
+  int tile_n = (int)(p.m_fastest ? tile / tiles_m : tile % (unsigned)p.tiles_n);
+  int tile_m = (int)(p.m_fastest ? tile % tiles_m : tile / (unsigned)p.tiles_n);
+  if (p.center_from_n > 0 && p.splitk == 1) {
+    // Column tiles that run the centre tap only (a 1x1 branch beside 3x3 ones) are short: a ninth of the K steps plus a whole
+    // tile's set-up and stores.  Interleaved with the long ones they cost more than they save (measured: 857 -> 736 us where
+    // 440 + 63 us as two launches); dispatched AFTER every long tile they run on the CUs the last round of long tiles leaves idle.
+    // Workgroups are dispatched in blockIdx order: the first n_long ids take the long tiles (XCD-major among themselves), the rest
+    // the short ones.
+    const unsigned cols_long = (unsigned)(p.center_from_n / BN), cols_short = (unsigned)p.tiles_n - cols_long;
+    const unsigned n_long = tiles_m * cols_long;
+    if (bid < n_long) {
+      const unsigned xq = n_long >> 3, xr = n_long & 7u;
+      const unsigned t = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+      tile_m = (int)(t / cols_long); tile_n = (int)(t % cols_long);
+    } else {
+      const unsigned b2 = bid - n_long, n_short = nwg - n_long;
+      const unsigned x2 = b2 & 7u, xq = n_short >> 3, xr = n_short & 7u;
+      const unsigned t = (x2 < xr ? x2 * (xq + 1) : xr * (xq + 1) + (x2 - xr) * xq) + (b2 >> 3);
+      tile_m = (int)(t / cols_short); tile_n = (int)(cols_long + t % cols_short);
+    }
+    zsplit = 0;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   int kt0 = zsplit * p.kt_split;
   int kt1 = min(p.KT, kt0 + p.kt_split);
-  if (p.pos_major) {
-    // filter rows that touch the image for at least one output row of this tile (tap-major K order: a filter row is a
-    // contiguous K range); split-K slices share that range evenly (a slice may be empty: it stores zeros)
-    const int oy_lo = (m0 / p.n_img) / p.Wo, oy_hi = (min(p.M, m0 + BM) - 1) / p.n_img / p.Wo;
-    int ky_lo = 0, ky_hi = p.kh - 1;
-    while (ky_lo < ky_hi && oy_hi * p.stride - p.cpad + ky_lo * p.dil < 0) ++ky_lo;
-    while (ky_hi > ky_lo && oy_lo * p.stride - p.cpad + ky_hi * p.dil > p.in_H - 1) --ky_hi;
-    const int steps_per_row = p.kw * (p.Cin / (kRowBytes / Tr::kEsz));
-    const int lo = ky_lo * steps_per_row, hi = (ky_hi + 1) * steps_per_row;
+  const bool center_only = p.center_from_n > 0 && n0 >= p.center_from_n;
+  if (p.pos_major || center_only) {
+    // K range of this tile (tap-major K order: a filter row / a tap is a contiguous K range); split-K slices share it evenly (a
+    // slice may be empty: it stores zeros)
+    const int steps_per_tap = p.Cin / (kRowBytes / Tr::kEsz);
+    int lo, hi;
+    if (center_only) {
+      // a 1x1 branch in the centre tap of the filter: that tap alone
+      lo = ((p.kh >> 1) * p.kw + (p.kw >> 1)) * steps_per_tap;
+      hi = lo + steps_per_tap;
+    } else {
+      // filter rows that touch the image for at least one output row of this tile
+      const int oy_lo = (m0 / p.n_img) / p.Wo, oy_hi = (min(p.M, m0 + BM) - 1) / p.n_img / p.Wo;
+      int ky_lo = 0, ky_hi = p.kh - 1;
+      while (ky_lo < ky_hi && oy_hi * p.stride - p.cpad + ky_lo * p.dil < 0) ++ky_lo;
+      while (ky_hi > ky_lo && oy_lo * p.stride - p.cpad + ky_hi * p.dil > p.in_H - 1) --ky_hi;
+      lo = ky_lo * p.kw * steps_per_tap;
+      hi = (ky_hi + 1) * p.kw * steps_per_tap;
+    }
     const int per = (hi - lo + p.splitk - 1) / p.splitk;
     kt0 = min(hi, lo + zsplit * per);
     kt1 = min(hi, kt0 + per);
@@ -585,7 +615,9 @@ int conv_pick_cfg(const ConvLaunch& c) {
     const int cfg = conv_patch_pick(c);
     if (cfg >= 0) return cfg;
   }
-  return conv_pick_igemm_cfg(M, c.Npad, c.kh * c.kw);
+  // centre-tap-only columns are a ninth of a column's work: the grid that has to fill the chip is the long columns'
+  const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw);
+  return (cfg == kCfgIgemm256TapsInner && c.center_from > 0) ? kCfgIgemm256 : cfg;      // a tap must be a contiguous K range
 }
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
@@ -630,6 +662,9 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   }
   a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
   a.pos_major = pick_pos_major(c, cfg, BM);
+  if (c.center_from > 0)
+    RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1) && cfg != kCfgIgemm256TapsInner && c.up == 0,
+                "conv: centre-tap-only columns need an odd filter, the tap-major K order and a boundary on the N tile (%d)", BN);
   RON_REQUIRE((int64_t)c.Npad * K * esz == c.wgt_bytes, "conv: packed weight size mismatch");
   int rc;
   if (c.dtype == RON_DTYPE_BF16) rc = launch_cfg<TraitsBF16S>(cfg, a, stream);
@@ -751,6 +786,7 @@ int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64
     }
     a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
     a.pos_major = pick_pos_major(c, cfg, BM);
+    if (c.center_from > 0) RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1), "conv group: bad centre-tap-only columns");
     g.first[k + 1] = g.first[k] + a.tiles_total * a.splitk;
   }
   if (ls[0].dtype == RON_DTYPE_BF16) return launch_group_cfg<TraitsBF16S>(cfg, g, any_split, stream);

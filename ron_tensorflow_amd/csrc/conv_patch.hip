@@ -340,7 +340,7 @@ using namespace detail;
 
 bool conv_patch_applicable(const ConvLaunch& c) {
   PatchGeom g;
-  return c.dtype != RON_DTYPE_F16X3 &&     // the split-precision mode runs on the row-gather kernel only
+  return c.dtype != RON_DTYPE_F16X3 && c.center_from == 0 &&     // split precision / centre-tap-only columns: the row-gather kernel only
          c.kh == 3 && c.kw == 3 && c.stride == 1 && c.dil == 1 && c.cpad == 1 && c.up == 0 && c.in.H == c.Ho && c.in.W == c.Wo &&
          c.in.pad >= 1 && c.Npad % 64 == 0 && c.in.C % conv_k_chunk(c.dtype) == 0 &&
          patch_geom(c.in.N, c.in.H, c.in.W, c.in.pad, c.pool != 0, &g);

@@ -68,6 +68,7 @@ struct Op {
   int packed = -1;
   int kh = 1, kw = 1, stride = 1, dil = 1, cpad = 0, relu = 0;
   int up = 0, up_cout = 0, pool = 0;
+  int center_from = 0;                  // output channels >= this hold a 1x1 branch in the centre tap of the 3x3 filter (0: none)
   int fuse_next_pool = 0;               // the next op is this conv's 2x2 pool and both maps are needed (conv4_3, conv5_3): one launch
                                         // with two outputs whenever the conv would not split K (decided per batch in ron_forward)
   int head_kind = -1, head_layer = -1;  // 0 cls, 1 obj, 2 loc
@@ -303,12 +304,14 @@ int pack_deconv(ron_ctx* c, const std::string& scope) {
   return upload(c, r, taps * co);
 }
 
-// The three 3x3 convs that read the reference map, as one GEMM with 1536 outputs:
-// rows 0..511 objectness hidden (conv+BN), 512..1023 box hidden (conv+BN), 1024..1535 inception-1 branch 0
-// (3x3 + bias, BN channels 0..511 of the concat).  Output channels [0, 1536) of the per-scale "hcat" tensor.
+// Everything that reads the reference map of a scale, as ONE convolution with 2048 outputs = the per-scale "hcat" tensor:
+// rows 0..511 objectness hidden (3x3 conv + BN), 512..1023 box hidden (3x3 conv + BN), 1024..1535 inception-1 branch 0 (3x3 + bias,
+// BN channels 0..511 of the concat), 1536..2047 inception-1 branch 1 (1x1 + bias, BN channels 512..1023) -- the 1x1 filter sits in
+// the CENTRE tap of its rows and those column tiles run that tap's K steps only (ConvLaunch::center_from = 1536), so it costs
+// its own MACs, not nine times them.
 int pack_trio3(ron_ctx* c, const std::string& L) {
   Rows r;
-  r.init(3, 3, 512, 1536, 256);
+  r.init(3, 3, 512, 2048, 256);
   r.place(c->var(L + "_objectness/weights"), 0);
   r.fold_bn(c, L + "_objectness", 0, 512);
   r.place(c->var(L + "/Conv2d_0_3x3/weights"), 512);
@@ -316,20 +319,26 @@ int pack_trio3(ron_ctx* c, const std::string& L) {
   r.place(c->var(L + "_inception1/Branch_0/Conv2d_3x3/weights"), 1024);
   r.add_bias(c->var(L + "_inception1/Branch_0/Conv2d_3x3/biases"), 1024);
   r.fold_bn(c, L + "_inception1", 1024, 512, 0);
-  return upload(c, r, 1536);
+  r.place(c->var(L + "_inception1/Branch_1/Conv2d_1x1/weights"), 1536);
+  r.add_bias(c->var(L + "_inception1/Branch_1/Conv2d_1x1/biases"), 1536);
+  r.fold_bn(c, L + "_inception1", 1536, 512, 512);
+  return upload(c, r, 2048);
 }
 
-// One branch of an "inception" block (nets/ron_vgg_320.py:378-397): conv + bias, then its half of the BatchNorm
-// that follows the concat (branch 0 = channels 0..511, branch 1 = 512..1023), ReLU in the kernel epilogue.
-int pack_branch(ron_ctx* c, const std::string& I, int branch) {
-  const std::string scope = I + (branch == 0 ? "/Branch_0/Conv2d_3x3" : "/Branch_1/Conv2d_1x1");
-  const Var& w = c->var(scope + "/weights");
+// Both branches of an "inception" block (nets/ron_vgg_320.py:378-397) as one convolution over the block's input: rows 0..511 the 3x3
+// branch, 512..1023 the 1x1 branch in the centre tap (center_from = 512); each conv + bias, then its half of the BatchNorm that
+// follows the concat, ReLU in the kernel epilogue.
+int pack_inception(ron_ctx* c, const std::string& I) {
+  const Var& w3 = c->var(I + "/Branch_0/Conv2d_3x3/weights");
   Rows r;
-  r.init((int)w.shape[0], (int)w.shape[1], (int)w.shape[2], 512, 256);
-  r.place(w, 0);
-  r.add_bias(c->var(scope + "/biases"), 0);
-  r.fold_bn(c, I, 0, 512, branch * 512);
-  return upload(c, r, 512);
+  r.init(3, 3, (int)w3.shape[2], 1024, 256);
+  r.place(w3, 0);
+  r.add_bias(c->var(I + "/Branch_0/Conv2d_3x3/biases"), 0);
+  r.fold_bn(c, I, 0, 512, 0);
+  r.place(c->var(I + "/Branch_1/Conv2d_1x1/weights"), 512);
+  r.add_bias(c->var(I + "/Branch_1/Conv2d_1x1/biases"), 512);
+  r.fold_bn(c, I, 512, 512, 512);
+  return upload(c, r, 1024);
 }
 
 
@@ -426,7 +435,7 @@ int make_anchors_ssd(ron_ctx* c) {
 }
 
 // Launch order of the RON heads with the small convolutions grouped (launch_conv_group).  The reference builds the scales one
-// after the other (nets/ron_vgg_320.py:495-506); the only true dependencies are  ref(i) -> {trio3, inception1_1x1}(i) ->
+// after the other (nets/ron_vgg_320.py:495-506); the only true dependencies are  ref(i) -> trio3(i) (the 1x1 inception branch rides in its centre tap) ->
 // {objectness_score, inception2_*, loc_pred}(i) -> cls_pred(i)  inside a scale and  ref(i) -> deconv_right(i+1) -> conv_left(i+1)
 // -> ref(i+1)  across scales.  At batch 32 the 5x5 and 10x10 scales (M = 800 / 3 200 rows) and the 1x1 / Cout <= 40 layers of
 // the 20x20 scale each fill a fraction of the chip and run 20-35 us apiece, mostly launch + pipeline fill; interleaving the
@@ -457,24 +466,21 @@ void plan_groups(ron_ctx* c) {
   };
   const std::vector<Slot> ron_order = {
       {-1, {"block7_conv_left"}},
-      {T64, {"block7_trio3", "block7_inception1_1x1", "block6_deconv_right"}},
+      {T64, {"block7_trio3", "block6_deconv_right"}},
       {-1, {"block6_conv_left"}},
-      {T64, {"block7_objectness_score", "block7_inception2_3x3", "block7_inception2_1x1", "block7_loc_pred",
-             "block6_inception1_1x1", "block5_deconv_right"}},
+      {T64, {"block7_objectness_score", "block7_inception2", "block7_loc_pred", "block5_deconv_right"}},
       {T128, {"block6_trio3", "block5_conv_left"}},
-      {T128, {"block6_inception2_3x3", "block5_inception1_1x1", "block4_deconv_right"}},
-      {T64, {"block7_cls_pred", "block6_objectness_score", "block6_inception2_1x1", "block6_loc_pred"}},
+      {T128, {"block6_inception2", "block4_deconv_right"}},
+      {T64, {"block7_cls_pred", "block6_objectness_score", "block6_loc_pred"}},
       {-1, {"block5_trio3"}},
       {-1, {"block4_conv_left"}},
       {T64, {"block6_cls_pred", "block5_objectness_score", "block5_loc_pred"}},
-      {T128, {"block5_inception2_3x3", "block5_inception2_1x1"}},
+      {-1, {"block5_inception2"}},
       {-1, {"block4_trio3"}},
-      {-1, {"block5_cls_pred"}},             // grouped with block4_inception1_1x1 it ran 8 % slower than the two alone
-      {-1, {"block4_inception1_1x1"}},
+      {-1, {"block5_cls_pred"}},
       // Cout = 20 / 40 over channel slices of the same tensor: one launch of the halo-patch kernel (400 workgroups; 200 each alone)
       {kCfgPatch64, {"block4_objectness_score", "block4_loc_pred"}},
-      {-1, {"block4_inception2_3x3"}},
-      {-1, {"block4_inception2_1x1"}},
+      {-1, {"block4_inception2"}},
       {-1, {"block4_cls_pred"}},
   };
   const std::vector<Slot>& order = c->is_ssd() ? ssd_order : ron_order;
@@ -829,17 +835,11 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
     PACK(pack_trio3(c, L));
     {
       Op o = conv_op(Ln + "_trio3", T(Ln + "_ref"), T(Ln + "_hcat"), rc, 3, 1, 1, sh, sw);
-      o.out_coff = 0;
+      o.center_from = 1536;
       c->ops.push_back(o);
       flops += conv_flops(c->var(L + "_objectness/weights"), sh * sw) + conv_flops(c->var(L + "/Conv2d_0_3x3/weights"), sh * sw) +
-               conv_flops(c->var(L + "_inception1/Branch_0/Conv2d_3x3/weights"), sh * sw); ATTR();
-    }
-    PACK(pack_branch(c, L + "_inception1", 1));
-    {
-      Op o = conv_op(Ln + "_inception1_1x1", T(Ln + "_ref"), T(Ln + "_hcat"), rc, 1, 0, 1, sh, sw);
-      o.out_coff = 1536;
-      c->ops.push_back(o);
-      flops += conv_flops(c->var(L + "_inception1/Branch_1/Conv2d_1x1/weights"), sh * sw); ATTR();
+               conv_flops(c->var(L + "_inception1/Branch_0/Conv2d_3x3/weights"), sh * sw) +
+               conv_flops(c->var(L + "_inception1/Branch_1/Conv2d_1x1/weights"), sh * sw); ATTR();
     }
     PACK(pack_plain(c, L + "_objectness_score", false));
     {
@@ -848,19 +848,13 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       c->ops.push_back(o);
       flops += conv_flops(c->var(L + "_objectness_score/weights"), sh * sw); ATTR();
     }
-    PACK(pack_branch(c, L + "_inception2", 0));
+    PACK(pack_inception(c, L + "_inception2"));
     {
-      Op o = conv_op(Ln + "_inception2_3x3", T(Ln + "_hcat"), T(Ln + "_inc2"), rc, 3, 1, 1, sh, sw);
-      o.in_coff = 1024; o.in_C = 1024; o.out_coff = 0;
+      Op o = conv_op(Ln + "_inception2", T(Ln + "_hcat"), T(Ln + "_inc2"), rc, 3, 1, 1, sh, sw);
+      o.in_coff = 1024; o.in_C = 1024; o.center_from = 512;
       c->ops.push_back(o);
-      flops += conv_flops(c->var(L + "_inception2/Branch_0/Conv2d_3x3/weights"), sh * sw); ATTR();
-    }
-    PACK(pack_branch(c, L + "_inception2", 1));
-    {
-      Op o = conv_op(Ln + "_inception2_1x1", T(Ln + "_hcat"), T(Ln + "_inc2"), rc, 1, 0, 1, sh, sw);
-      o.in_coff = 1024; o.in_C = 1024; o.out_coff = 512;
-      c->ops.push_back(o);
-      flops += conv_flops(c->var(L + "_inception2/Branch_1/Conv2d_1x1/weights"), sh * sw); ATTR();
+      flops += conv_flops(c->var(L + "_inception2/Branch_0/Conv2d_3x3/weights"), sh * sw) +
+               conv_flops(c->var(L + "_inception2/Branch_1/Conv2d_1x1/weights"), sh * sw); ATTR();
     }
     PACK(pack_plain(c, L + "_inception2/Conv2d_pred_3x3", false));
     {
@@ -938,6 +932,7 @@ static int describe_conv(const ron_ctx* c, const Op& o, int n, const ron_heads* 
   L.wgt = p.d_w; L.wgt_bytes = p.w_bytes; L.wgt_c64 = p.d_w_c64; L.bias = p.d_bias; L.oscale = p.oscale; L.Cout = p.Cout; L.Npad = p.Npad;
   L.kh = o.kh; L.kw = o.kw; L.stride = o.stride; L.dil = o.dil; L.cpad = o.cpad; L.relu = o.relu;
   L.up = o.up; L.up_cout = o.up_cout; L.Ho = o.Ho; L.Wo = o.Wo; L.pool = o.pool;
+  L.center_from = o.center_from;
   L.scratch = c->d_splitk[o.lane]; L.scratch_bytes = c->splitk_bytes[o.lane];
   L.halo_skip = (c->cfg.flags & RON_CFG_NO_HALO_SKIP) ? 0 : 1;
   *out_l = L;

@@ -122,6 +122,7 @@ int setup_conv(const ron_conv_desc* d, const float* w, const float* bias, bool w
     c.res = S->d_res.p;
   }
   c.splitk = d->splitk;
+  c.center_from = d->transpose ? 0 : d->center_from;
   const int64_t sb = conv_scratch_bytes(c);
   if (sb > 0) {
     if ((rc = S->d_scratch.alloc(sb, false))) return rc;

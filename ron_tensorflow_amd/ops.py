@@ -208,14 +208,14 @@ def softmax_last(x, pick=-1):
 # single operators (parity tests of the conv kernels)
 # --------------------------------------------------------------------------- #
 def conv2d_nhwc(x, w, bias=None, residual=None, stride=1, dilation=1, relu=True, transpose=False, dtype='bf16',
-                tile_cfg=-1, splitk=-1, pool=False, in_cstride=0, in_coff=0):
+                tile_cfg=-1, splitk=-1, pool=False, in_cstride=0, in_coff=0, center_from=0):
     """x GPU fp32 [N,H,W,Cin]; w, bias host numpy (HWIO, or [kh,kw,Cout,Cin] when transpose)."""
     x = x.contiguous()
     w = np.ascontiguousarray(w, dtype=np.float32)
     n, h, wd, cin = x.shape
     kh, kw = w.shape[:2]
     cout = w.shape[2] if transpose else w.shape[3]
-    d = _lib.ConvDesc(n, h, wd, cin, cout, kh, kw, stride, dilation, int(relu), int(transpose), _lib.DTYPES[dtype], tile_cfg, in_cstride, in_coff, int(pool), splitk)
+    d = _lib.ConvDesc(n, h, wd, cin, cout, kh, kw, stride, dilation, int(relu), int(transpose), _lib.DTYPES[dtype], tile_cfg, in_cstride, in_coff, int(pool), splitk, center_from)
     ho, wo = (h * stride, wd * stride) if transpose else (h // stride, wd // stride)
     if pool:
         ho, wo = ho // 2, wo // 2

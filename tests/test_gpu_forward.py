@@ -319,15 +319,15 @@ def test_grouped_launch_plan_is_active(pkg, dev, weights_reduced, weights_full, 
     net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=1, fuse_pools=True).load_weights(w)
     plan = net.launch_plan()
     groups = [n for n in plan if n.startswith('group[')]
-    assert net.grouped_launches() == 8 and len(groups) == 8, plan
-    assert groups == ['group[block7_trio3+2]', 'group[block7_objectness_score+5]', 'group[block6_trio3+1]',
-                      'group[block6_inception2_3x3+2]', 'group[block7_cls_pred+3]', 'group[block6_cls_pred+2]',
-                      'group[block5_inception2_3x3+1]', 'group[block4_objectness_score+1]'], groups
+    assert net.grouped_launches() == 7 and len(groups) == 7, plan
+    assert groups == ['group[block7_trio3+1]', 'group[block7_objectness_score+3]', 'group[block6_trio3+1]',
+                      'group[block6_inception2+1]', 'group[block7_cls_pred+2]', 'group[block6_cls_pred+2]',
+                      'group[block4_objectness_score+1]'], groups
     assert plan[0] == 'conv1_1+conv1_2+pool1' and plan[-1] == 'post_np'
     launches = [n for n in plan[:-1] if not n.startswith('(')]
-    assert len(launches) == 34, (len(launches), launches)       # fused stem + 13 backbone convs / pools + fc6 + fc7 + 18 head launches
+    assert len(launches) == 32, (len(launches), launches)       # fused stem + 13 backbone convs / pools + fc6 + fc7 + 16 head launches
     clone = net.clone()
-    assert clone.launch_plan() == plan and clone.grouped_launches() == 8
+    assert clone.launch_plan() == plan and clone.grouped_launches() == 7
     clone.close()
     net.close()
     net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=1, fuse_pools=True, group_heads=False).load_weights(w)

@@ -55,6 +55,11 @@ LAYERS = [
     ('b4_loc', 40, 40, 512, 40, 3, 1, 1, 0),
     ('b4_obj', 40, 40, 512, 20, 3, 1, 1, 0),
     ('b4_left', 40, 40, 512, 512, 3, 1, 1, 0),
+    ('b4_quad', 40, 40, 512, 2048, 3, 1, 1, 0),      # trio3 + the 1x1 inception branch in the centre tap: --center-from 1536
+    ('b4_inc2x', 40, 40, 1024, 1024, 3, 1, 1, 0),     # inception-2 3x3 + 1x1: --center-from 512
+    ('b4_inc2_3x3', 40, 40, 1024, 512, 3, 1, 1, 0),
+    ('b4_inc2_1x1', 40, 40, 1024, 512, 1, 1, 1, 0),
+    ('b4_inc1_1x1', 40, 40, 512, 512, 1, 1, 1, 0),
     ('b5_left', 20, 20, 512, 512, 3, 1, 1, 0),
 ]
 
@@ -69,6 +74,7 @@ def main():
     ap.add_argument('--cstride', type=int, default=0)
     ap.add_argument('--coff', type=int, default=0)
     ap.add_argument('--splitk', type=int, default=-1)
+    ap.add_argument('--center-from', type=int, default=0, help='output channels >= this run the centre tap only (timing: the weights are random everywhere)')
     a = ap.parse_args()
     lib = _lib.lib()
     ncfg = lib.ron_conv_num_tile_cfgs()
@@ -81,7 +87,7 @@ def main():
         flop = 2.0 * a.batch * (h * w if tr else ho * wo) * k * k * cin * cout
         cells = []
         for cfg in cfgs:
-            d = _lib.ConvDesc(a.batch, h, w, cin, cout, k, k, stride, rate, 1, tr, _lib.DTYPES[a.dtype], cfg, a.cstride, a.coff, 0, a.splitk)
+            d = _lib.ConvDesc(a.batch, h, w, cin, cout, k, k, stride, rate, 1, tr, _lib.DTYPES[a.dtype], cfg, a.cstride, a.coff, 0, a.splitk, a.center_from)
             ms = C.c_float()
             rc = lib.ron_conv2d_bench(C.byref(d), 3, a.iters, C.byref(ms))
             if rc != 0:
