@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(handle, n), 'libron_hip.so does not export %s' % n
         assert n in _lib.SIGNATURES, 'no ctypes signature for %s' % n
     assert sorted(_lib.SIGNATURES) == names          # nothing bound that the header does not declare
-    assert handle.ron_abi_version() == 1
+    assert handle.ron_abi_version() == 2          # 2: ron_conv_desc.center_from, RON_DTYPE_F16X3, ron_num_grouped_launches
 
 
 def test_argument_errors_are_reported_not_raised_in_c():
