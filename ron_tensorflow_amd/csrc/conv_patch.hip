@@ -46,7 +46,11 @@ struct PatchArgs {
 // no weight traffic (zero-record descriptors: timing only, results wrong).
 // One tile of convolution `p` (geometry `pa`): workgroup `bid` of the `nwg` that convolution's launch -- or its share of a pair
 // launch -- consists of.
-template <class Tr, int BN, int WN, int SB, int EXP = 0>
+// TPS: filter taps per step (= per barrier).  1: the form above.  3: a step is a whole filter ROW -- three taps' weights staged
+// together, 3 x KS k-steps of MFMAs between two barriers.  For N <= 64 a tap is only MR * NR * KS = 16 MFMAs per wave, too few to
+// hide a step's fixed cost (counted wait + barrier, LDS-DMA issue, first-fragment latency: ~1500 cycles per step whatever is in
+// flight, profiles/r03/skinny_heads_pair.txt); three taps per barrier triple the work behind it.
+template <class Tr, int BN, int WN, int SB, int EXP = 0, int TPS = 1>
 __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const ConvArgs& p, const unsigned bid, const unsigned nwg) {
   constexpr int BM = 256, WM = 8 / WN, kThreads = 512;
   constexpr int MT = Tr::kMT, kGroups = 64 / MT, KS = 8 / kGroups, EPA = MT * MT / 64;
@@ -55,7 +59,9 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
   constexpr int B_IT = BN / 64;                   // B pieces per thread and step
   constexpr int G = B_IT + 1;                     // LDS-DMA instructions per thread and step (the weights + one patch piece)
   constexpr int kPatchBytes = kPatchRows * kRowBytes;
-  constexpr int kBBytes = BN * kRowBytes;
+  constexpr int kTapBytes = BN * kRowBytes;       // one tap's weights of this N tile
+  constexpr int kBBytes = TPS * kTapBytes;        // one weight stage
+  static_assert(TPS == 1 || TPS == 3, "taps per step");
   static_assert(MT == 16 && TM % MT == 0 && TN % MT == 0 && NR <= 8 && SB >= 2, "bad wave tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // layout: [patch 0][patch 1][B stage 0 .. SB-1][pp: BM ints][out_off: BM ints][sink 1 KB]
@@ -65,7 +71,9 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
   // a zero-record LDS-DMA still writes (zeros): the placeholder pieces that keep the vmcnt groups uniform land here
   char* s_sink = reinterpret_cast<char*>(s_out_off + BM);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // `wave` is wave-uniform; said explicitly, or hipcc wraps every LDS-DMA whose descriptor / LDS address depends on it (the
+  // "piece lies inside the patch buffer" tests below) in a waterfall loop
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
   const unsigned xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
@@ -186,6 +194,112 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
   // groups stay uniform).  The wait at the top of a step leaves the newest SB-2 groups AND the piece behind them in
   // flight: a patch piece gets two steps to land, not one (measured: with the piece issued first, the patch stream alone
   // cost more than the eight times larger weight stream alone).  The prologue is shaped the same way.
+  if constexpr (TPS == 3) {
+    // ---- one filter row per step -------------------------------------------------------------------------------------------
+    // LDS-DMA group of a step (issue order = retire order): the 3 * B_IT weight pieces of step + SB - 1 (taps kx = 0, 1, 2 of its
+    // filter row: blocks (3 ky + kx) * chunks + c of the packed weights), then 3 pieces of the next chunk's patch in the chunk's
+    // first two steps, placeholders into the sink in its third: the wait at the top of a step leaves the youngest SB - 2 groups and
+    // the 3 pieces behind them in flight, so the patch of chunk c + 1 has landed one whole step before it is read.
+    constexpr int GR = 3 * B_IT + 3;
+    static_assert(kPatchPieces == 6, "three patch pieces in each of a chunk's first two steps");
+    const int n_rows = pa.chunks * 3;
+    // weights of filter row `row_step` (= chunk * 3 + ky), tap kx: block (3 ky + kx) * chunks + chunk of the packed weights
+#define W_SOFF(row_step_, kx_) ((((row_step_) % 3) * 3 + (kx_)) * pa.chunks + (row_step_) / 3) * kWeightBlockBytes
+#pragma unroll
+    for (int k = 0; k < kPatchPieces; ++k) PATCH_PIECE(k, 0, 0, true);
+#pragma unroll
+    for (int t = 0; t < SB - 1; ++t) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_B(t < n_rows), (lds_void*)(s_b + t * kBBytes + kx * kTapBytes + (it * 64 + wave * 8) * kRowBytes),
+                                                   16, b_voff[it], W_SOFF(min(t, n_rows - 1), kx), 0, 0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(false), (lds_void*)s_sink, 16, p_voff[0], 0, 0, 0);
+    }
+    int cc = 0, ky = 0, st_rd = 0, st_wr = SB - 1;
+    for (int step = 0; step < n_rows; ++step) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((SB - 2) * GR + 3) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const char* sa = smem + (cc & 1) * kPatchBytes;
+      const char* sb = s_b + st_rd * kBBytes + b_base;
+      if (++st_rd == SB) st_rd = 0;
+      // fragment addresses of the row's three taps: A = patch row pp + ky * PW + kx (k-step 1 = the same ^ 64 bytes)
+      int a_off[3][MR];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+          const int row = pp[i] + ky * pa.PW + kx;
+          a_off[kx][i] = row * kRowBytes + ((fh ^ patch_key(row)) << 4);
+        }
+      u32x4 fa[2][MR], fb[2][NR];
+      // fragments of k-step q_ (= 2 kx + k-step of the tap) into register set set_
+#define READ_FRAGS(set_, q_)                                                                                                       \
+      do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MR; ++i)                                                                             \
+          fa[set_][i] = *reinterpret_cast<const u32x4*>(sa + (a_off[(q_) >> 1][i] ^ (((q_) & 1) << 6)));                            \
+        _Pragma("unroll") for (int j = 0; j < NR; ++j)                                                                             \
+          fb[set_][j] = *reinterpret_cast<const u32x4*>(sb + ((q_) >> 1) * kTapBytes + j * MT * kRowBytes + rd_off_b[(q_) & 1]);   \
+      } while (0)
+      READ_FRAGS(0, 0);
+      // this step's LDS-DMA group
+      {
+        const int nxt = step + SB - 1;
+        const bool live = nxt < n_rows;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int it = 0; it < B_IT; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_B(live), (lds_void*)(s_b + st_wr * kBBytes + kx * kTapBytes + (it * 64 + wave * 8) * kRowBytes),
+                                                     16, b_voff[it], W_SOFF(min(nxt, n_rows - 1), kx), 0, 0);
+        if (++st_wr == SB) st_wr = 0;
+        const bool more = cc + 1 < pa.chunks && ky < 2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int piece = ky * 3 + k;               // 0..5 in the chunk's first two steps
+          int voff = p_voff[0];
+#pragma unroll
+          for (int q = 1; q < kPatchPieces; ++q) voff = piece == q ? p_voff[q] : voff;
+          const bool in_ = piece * 64 + wave * 8 + 8 <= kPatchRows;
+          char* d_ = (more && in_) ? smem + ((cc + 1) & 1) * kPatchBytes + (piece * kThreads + wave * 64) * 16 : s_sink;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(more && in_), (lds_void*)d_, 16, voff, (cc + 1) * kRowBytes, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        if (q < 5) READ_FRAGS((q + 1) & 1, q + 1);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) Tr::mma(fa[q & 1][i], fb[q & 1][j], acc[i][j]);
+      }
+      // issue order: first fragments | k-step 0: MFMAs with the next reads and the GR DMA instructions between them | k-steps 1..4:
+      // MFMAs with the next reads | last k-step
+      {
+        constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma;
+        __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int ps = q == 0 ? GR : 0;
+#pragma unroll
+          for (int m = 0; m < MM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q < 5 && m < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (((m + 1) * ps) / MM > (m * ps) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+          if (q < 5 && RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+#pragma unroll
+          for (int x = 0; x < 16; ++x)
+            if (x < ps - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+      if (++ky == 3) { ky = 0; ++cc; }
+    }
+#undef READ_FRAGS
+#undef W_SOFF
+  } else {
   const int n_steps = pa.chunks * 9;
 #pragma unroll
   for (int k = 0; k < kPatchPieces; ++k) PATCH_PIECE(k, 0, 0, true);
@@ -272,6 +386,7 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
     if (++tap == 9) { tap = 0; ++cc; ky = 0; kx = 0; }
     else if (++kx == 3) { kx = 0; ++ky; }
   }
+  }
 #undef PATCH_PIECE
 #undef B_PIECE
 #undef RS_A
@@ -281,37 +396,37 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
   conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n0 + nloc, 0);
 }
 
-template <class Tr, int BN, int WN, int SB, int EXP = 0>
+template <class Tr, int BN, int WN, int SB, int EXP = 0, int TPS = 1>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
-  conv3x3_patch_tile<Tr, BN, WN, SB, EXP>(pa, pa.c, blockIdx.x, gridDim.x);
+  conv3x3_patch_tile<Tr, BN, WN, SB, EXP, TPS>(pa, pa.c, blockIdx.x, gridDim.x);
 }
 
 // Two convolutions over the SAME input tensor geometry (channel slices of one map: the Cout = 20 / 40 heads of a scale read
 // slices of the per-scale concatenated tensor, nets/ron_vgg_320.py:406-415,427-428) in ONE launch: workgroups [0, first) run
 // `pa.c`, the rest `second`, each exactly as its own launch would.  Alone each fills 200 of the 512 workgroup slots.
-template <class Tr, int BN, int WN, int SB>
+template <class Tr, int BN, int WN, int SB, int TPS>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_pair_kernel(PatchArgs pa, ConvArgs second, int first) {
   const int b = (int)blockIdx.x;
-  if (b < first) conv3x3_patch_tile<Tr, BN, WN, SB, 0>(pa, pa.c, (unsigned)b, (unsigned)first);
-  else conv3x3_patch_tile<Tr, BN, WN, SB, 0>(pa, second, (unsigned)(b - first), gridDim.x - (unsigned)first);
+  if (b < first) conv3x3_patch_tile<Tr, BN, WN, SB, 0, TPS>(pa, pa.c, (unsigned)b, (unsigned)first);
+  else conv3x3_patch_tile<Tr, BN, WN, SB, 0, TPS>(pa, second, (unsigned)(b - first), gridDim.x - (unsigned)first);
 }
 
-template <class Tr, int BN, int WN, int SB>
+template <class Tr, int BN, int WN, int SB, int TPS>
 int launch_patch_pair_t(const PatchArgs& a, const ConvArgs& second, int first, int grid, hipStream_t s) {
-  const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
+  const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * TPS * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
   static PerDeviceOnce once;
-  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_patch_pair_kernel<Tr, BN, WN, SB>), (int)lds));
-  hipLaunchKernelGGL((conv3x3_patch_pair_kernel<Tr, BN, WN, SB>), dim3(grid), dim3(512), lds, s, a, second, first);
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_patch_pair_kernel<Tr, BN, WN, SB, TPS>), (int)lds));
+  hipLaunchKernelGGL((conv3x3_patch_pair_kernel<Tr, BN, WN, SB, TPS>), dim3(grid), dim3(512), lds, s, a, second, first);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
 
-template <class Tr, int BN, int WN, int SB, int EXP = 0>
+template <class Tr, int BN, int WN, int SB, int EXP = 0, int TPS = 1>
 int launch_patch_t(const PatchArgs& a, int grid, hipStream_t s) {
-  const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
+  const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * TPS * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
   static PerDeviceOnce once;
-  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN, SB, EXP>), (int)lds));
-  hipLaunchKernelGGL((conv3x3_patch_kernel<Tr, BN, WN, SB, EXP>), dim3(grid), dim3(512), lds, s, a);
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN, SB, EXP, TPS>), (int)lds));
+  hipLaunchKernelGGL((conv3x3_patch_kernel<Tr, BN, WN, SB, EXP, TPS>), dim3(grid), dim3(512), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -411,9 +526,9 @@ int launch_conv_patch_pair(const ConvLaunch& ca, const ConvLaunch& cb, hipStream
   const int BN = patch_bn(cfg);
 #define RON_PATCH_PAIR(Tr)                                                                          \
   do {                                                                                              \
-    if (BN == 256) return launch_patch_pair_t<Tr, 256, 2, 2>(a, b.c, grid_a, grid, stream);         \
-    if (BN == 128) return launch_patch_pair_t<Tr, 128, 2, 3>(a, b.c, grid_a, grid, stream);         \
-    return launch_patch_pair_t<Tr, 64, 2, 3>(a, b.c, grid_a, grid, stream);                         \
+    if (BN == 256) return launch_patch_pair_t<Tr, 256, 2, 2, 1>(a, b.c, grid_a, grid, stream);      \
+    if (BN == 128) return launch_patch_pair_t<Tr, 128, 2, 3, 1>(a, b.c, grid_a, grid, stream);      \
+    return launch_patch_pair_t<Tr, 64, 2, 2, 3>(a, b.c, grid_a, grid, stream);                      \
   } while (0)
   if (ca.dtype == RON_DTYPE_BF16) RON_PATCH_PAIR(TraitsBF16S);
   if (ca.dtype == RON_DTYPE_F16) RON_PATCH_PAIR(TraitsF16S);
@@ -441,7 +556,7 @@ int launch_conv_patch(const ConvLaunch& c, int cfg, hipStream_t stream) {
     RON_PATCH_EXP(Tr)                                                               \
     if (BN == 256) return launch_patch_t<Tr, 256, 2, 2>(a, grid, stream);           \
     if (BN == 128) return launch_patch_t<Tr, 128, 2, 3>(a, grid, stream);           \
-    return launch_patch_t<Tr, 64, 2, 3>(a, grid, stream);                           \
+    return launch_patch_t<Tr, 64, 2, 2, 0, 3>(a, grid, stream);                     \
   } while (0)
   if (c.dtype == RON_DTYPE_BF16) RON_PATCH_DISPATCH(TraitsBF16S);
   if (c.dtype == RON_DTYPE_F16) RON_PATCH_DISPATCH(TraitsF16S);
