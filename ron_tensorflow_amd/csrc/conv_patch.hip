@@ -193,7 +193,8 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
   // piece of the next chunk's patch (a zero-record placeholder into the sink when there is none to fetch, so that the
   // groups stay uniform).  The wait at the top of a step leaves the newest SB-2 groups AND the piece behind them in
   // flight: a patch piece gets two steps to land, not one (measured: with the piece issued first, the patch stream alone
-  // cost more than the eight times larger weight stream alone).  The prologue is shaped the same way.
+  // cost more than the eight times larger weight stream alone).  The prologue (patch of chunk 0, weights of the first SB - 1
+  // steps) is waited for as a whole.
   if constexpr (TPS == 3) {
     // ---- one filter row per step -------------------------------------------------------------------------------------------
     // LDS-DMA group of a step (issue order = retire order): the 3 * B_IT weight pieces of step + SB - 1 (taps kx = 0, 1, 2 of its
@@ -215,9 +216,11 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
         for (int it = 0; it < B_IT; ++it)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_B(t < n_rows), (lds_void*)(s_b + t * kBBytes + kx * kTapBytes + (it * 64 + wave * 8) * kRowBytes),
                                                    16, b_voff[it], W_SOFF(min(t, n_rows - 1), kx), 0, 0);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(false), (lds_void*)s_sink, 16, p_voff[0], 0, 0, 0);
     }
+    // everything the prologue issued lands before the first step (no placeholder pieces here: identical back-to-back LDS-DMA
+    // instructions into the sink are dead stores to the compiler, which kept one of three and left the first step's counted wait
+    // two short -- its weights of taps 1 and 2 could still be in flight)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int cc = 0, ky = 0, st_rd = 0, st_wr = SB - 1;
     for (int step = 0; step < n_rows; ++step) {
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((SB - 2) * GR + 3) : "memory");
@@ -308,8 +311,8 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
     const int soff = ((t % 9) * pa.chunks + t / 9) * kWeightBlockBytes;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) B_PIECE(it, t, soff, t < n_steps);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_A(false), (lds_void*)s_sink, 16, p_voff[0], 0, 0, 0);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the prologue lands as a whole (see the row-step form above)
 
   int tap = 0, cc = 0, ky = 0, kx = 0;
   int ntap = (SB - 1) % 9, ncc = (SB - 1) / 9;      // tap / chunk of step + SB - 1

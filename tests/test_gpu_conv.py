@@ -209,6 +209,25 @@ def test_conv_with_fused_maxpool(ops, dev, dtype, cfg):
     assert np.array_equal(ops.maxpool2x2_nhwc(full, dtype=dtype).cpu().numpy(), got)
 
 
+@pytest.mark.parametrize('dtype,shape', [('fp32', (2, 320, 320, 64, 64)), ('bf16', (2, 40, 40, 512, 40)), ('fp32', (2, 40, 40, 512, 20))])
+def test_patch_kernel_first_step_waits_for_all_its_weights(ops, dev, dtype, shape):
+    """The row-step form of the halo-patch kernel (N tile 64) once entered its first step with the weights of taps 1 and 2
+    possibly still in flight: the compiler had merged the prologue's three placeholder LDS-DMA instructions into one and the
+    counted wait came out two short.  It showed as run-to-run differences of up to 13 % on conv1_2 in fp32 at batch 2 (800
+    workgroups), nowhere else in the suite.  Same launch eight times: identical bits, and equal to the row-gather kernel."""
+    n, h, w, cin, cout = shape
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.randn(n, h, w, cin).astype(np.float32)).to(dev)
+    wt = (rs.randn(3, 3, cin, cout) * 0.05).astype(np.float32)
+    b = (rs.randn(cout) * 0.1).astype(np.float32)
+    ref = ops.conv2d_nhwc(x, wt, b, relu=True, dtype=dtype, tile_cfg=3)
+    outs = [ops.conv2d_nhwc(x, wt, b, relu=True, dtype=dtype, tile_cfg=6) for _ in range(8)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    tol = 1e-5 if dtype == 'fp32' else 1e-2       # bf16: the two kernels add in different orders before the output rounding
+    assert float((outs[0] - ref).abs().max()) <= tol * float(ref.abs().max())
+
+
 PATCH_SHAPES = [  # n, h, w, cin, cout
     (2, 40, 40, 64, 128),     # flat runs of 256 positions (41 per row with the shared halo), crossing rows and the two images
     (1, 20, 20, 128, 256),    # flat, N tile 256, two chunks
