@@ -55,6 +55,8 @@ def parse():
     ap.add_argument('--multi-stream', action='store_true',
                     help='run the block7/6/5 head branches on side streams (RON_CFG_MULTI_STREAM): +5 %% images/s measured, but the '
                          'per-launch durations then overlap and no longer describe one kernel each, so it is off by default')
+    ap.add_argument('--head-plan', default=None, choices=['level', 'batch'],
+                    help='grouped launch plan of the RON heads (default: by batch, RON_CFG_LEVEL_GROUPS / RON_CFG_BATCH_GROUPS)')
     ap.add_argument('--in-flight', type=int, default=2,
                     help='batches in flight per GPU (execution slots over one set of weights, one stream each; '
                          'ron_tensorflow_amd/pipeline.py).  1 = strictly one launch at a time: per-launch durations are then '
@@ -198,7 +200,7 @@ def main():
     else:
         weights = synthetic_weights(args.variant, seed=1)     # seed 1: ~4.8 k candidates, ~230 detections per image (full)
         net = ron_class(ron_params, variant=args.variant, dtype=args.dtype, max_batch=args.batch, device=dev, fuse_pools=True,
-                        multi_stream=args.multi_stream)
+                        multi_stream=args.multi_stream, head_plan=args.head_plan)
     net.load_weights(weights)
     images = torch.from_numpy(synthetic_images(args.batch, seed=3 + rank, img_shape=ron_params.img_shape)).to(dev)   # resident in HBM
     top_k = 400

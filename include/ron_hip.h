@@ -295,6 +295,12 @@ typedef struct {
  * skips the filter rows that fall outside the image for all of its rows (bit-identical results: only products with zeros go).
  * This flag keeps the image-major order and the full K loop (tests compare the two). */
 #define RON_CFG_NO_HALO_SKIP 16u
+/* Which grouped plan the RON heads run: by default contexts with max_batch <= 2 launch the heads one launch per dependency
+ * level (10 launches, the large convolutions grouped too: at such batches every launch is latency-bound), larger ones the
+ * plan above (16 launches).  RON_CFG_LEVEL_GROUPS / RON_CFG_BATCH_GROUPS force one or the other (A/B tests; same results up to
+ * the order of the fp32 partial sums). */
+#define RON_CFG_LEVEL_GROUPS 32u
+#define RON_CFG_BATCH_GROUPS 64u
 
 int ron_create(ron_ctx** out, const ron_config* cfg);
 int ron_destroy(ron_ctx* ctx);

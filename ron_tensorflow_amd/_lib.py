@@ -21,6 +21,8 @@ RON_CFG_MULTI_STREAM = 2
 RON_CFG_NO_STEM2 = 4
 RON_CFG_NO_GROUPS = 8
 RON_CFG_NO_HALO_SKIP = 16
+RON_CFG_LEVEL_GROUPS = 32
+RON_CFG_BATCH_GROUPS = 64
 
 DTYPES = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp16': 2, 'f16': 2, 'float16': 2,
           'f16x3': 3, 'fp16x3': 3}     # f16x3: split precision (two f16 planes per value, 3 MFMAs per product; include/ron_hip.h)

@@ -29,6 +29,7 @@ using namespace ron;
 namespace {
 
 constexpr float kBnEps = 1e-5f;
+constexpr int kLevelPlanMaxBatch = 4;      // contexts up to this max_batch run the heads one launch per dependency level (plan_groups)
 const char* kFeatLayers[4] = {"block7", "block6", "block5", "block4"};
 
 struct Var {
@@ -483,7 +484,24 @@ void plan_groups(ron_ctx* c) {
       {-1, {"block4_inception2"}},
       {-1, {"block4_cls_pred"}},
   };
-  const std::vector<Slot>& order = c->is_ssd() ? ssd_order : ron_order;
+  // Small batches (RON_CFG_LEVEL_GROUPS, the default when max_batch <= kLevelPlanMaxBatch): every head convolution is a
+  // latency-bound launch of a few hundred workgroups (25-40 us each with its split-K finalize, whatever its size), so
+  // the heads go out one launch per dependency level, the large convolutions included: 16 head launches -> 10.
+  const std::vector<Slot> ron_levels = {
+      {-1, {"block7_conv_left"}},
+      {T64, {"block7_trio3", "block6_deconv_right"}},
+      {T64, {"block6_conv_left", "block7_objectness_score", "block7_inception2", "block7_loc_pred"}},
+      {T128, {"block6_trio3", "block5_deconv_right", "block7_cls_pred"}},
+      {T64, {"block5_conv_left", "block6_objectness_score", "block6_inception2", "block6_loc_pred"}},
+      {T128, {"block5_trio3", "block4_deconv_right", "block6_cls_pred"}},
+      {T64, {"block4_conv_left", "block5_objectness_score", "block5_inception2", "block5_loc_pred"}},
+      {T128, {"block4_trio3", "block5_cls_pred"}},
+      {-1, {"block4_inception2"}},
+      {T64, {"block4_cls_pred", "block4_objectness_score", "block4_loc_pred"}},
+  };
+  const bool levels = !(c->cfg.flags & RON_CFG_BATCH_GROUPS) &&
+                      ((c->cfg.flags & RON_CFG_LEVEL_GROUPS) || c->cfg.max_batch <= kLevelPlanMaxBatch);
+  const std::vector<Slot>& order = c->is_ssd() ? ssd_order : (levels ? ron_levels : ron_order);
   std::map<std::string, int> at;
   for (size_t i = 0; i < c->ops.size(); ++i) at[c->ops[i].name] = (int)i;
   size_t first_head = c->ops.size(), n_named = 0;
@@ -1099,6 +1117,7 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
       if (o.fuse_next_pool && oi + 1 < c->ops.size() && c->ops[oi + 1].kind == OP_POOL) {
         // conv4_3 / conv5_3: both the map and its pool are read later.  When this launch does not split K (it does at small
         // batches: the pool epilogue needs whole sums) the pool comes out of the same accumulators and the pool launch is skipped.
+        // (The pool inside the split-K finalize pass instead was measured at batch 1: conv4_3 30.9 + pool4 8.7 us -> 40.9 us, no gain.)
         ConvLaunch F = L;
         F.out2 = L.out;                           // the kernel choice of a two-output launch (row-gather kernel only) ...
         if (conv_scratch_bytes(F) == 0) {         // ... would not split K at this batch

@@ -40,7 +40,7 @@ class RONNet(object):
         prior_scaling=[0.1, 0.1, 0.2, 0.2])
 
     def __init__(self, params=None, variant='reducedfc', dtype='bf16', max_batch=32, device=None, fuse_pools=False,
-                 multi_stream=False, group_heads=True):
+                 multi_stream=False, group_heads=True, head_plan=None):
         self.params = params if isinstance(params, RONParams) else RONNet.default_params
         if variant not in _lib.VARIANTS:
             raise ValueError('Unknown RON variant %s' % variant)
@@ -54,6 +54,10 @@ class RONNet(object):
         self.multi_stream = multi_stream
         # group_heads: the small independent head convolutions of the coarse scales share launches (RON_CFG_NO_GROUPS off)
         self.no_groups = not group_heads
+        # head_plan: None = by max_batch (<= 2: one launch per dependency level, else the batch plan); 'level' / 'batch' force one
+        if head_plan not in (None, 'level', 'batch'):
+            raise ValueError('head_plan must be None, "level" or "batch"')
+        self.head_plan = head_plan
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self._ctx = None
         self._anchors_dev = None
@@ -68,7 +72,8 @@ class RONNet(object):
                               (_lib.RON_CFG_MULTI_STREAM if getattr(self, 'multi_stream', False) else 0) |
                               (_lib.RON_CFG_NO_STEM2 if getattr(self, 'no_stem2', False) else 0) |
                               (_lib.RON_CFG_NO_GROUPS if getattr(self, 'no_groups', False) else 0) |
-                              (_lib.RON_CFG_NO_HALO_SKIP if getattr(self, 'no_halo_skip', False) else 0))
+                              (_lib.RON_CFG_NO_HALO_SKIP if getattr(self, 'no_halo_skip', False) else 0) |
+                              {None: 0, 'level': _lib.RON_CFG_LEVEL_GROUPS, 'batch': _lib.RON_CFG_BATCH_GROUPS}[getattr(self, 'head_plan', None)])
             h = C.c_void_p()
             check(lib().ron_create(C.byref(h), C.byref(cfg)))
             self._ctx = h

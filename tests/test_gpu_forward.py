@@ -316,7 +316,7 @@ def test_grouped_launch_plan_is_active(pkg, dev, weights_reduced, weights_full, 
     """The grouped head launches are keyed on op names inside libron_hip (plan_groups): a rename in the graph builder would
     silently fall back to one launch per convolution (-7 % of the step) while every equivalence test still passed.  Read the plan."""
     w = weights_reduced if variant == 'reducedfc' else weights_full
-    net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=1, fuse_pools=True).load_weights(w)
+    net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=8, fuse_pools=True).load_weights(w)
     plan = net.launch_plan()
     groups = [n for n in plan if n.startswith('group[')]
     assert net.grouped_launches() == 7 and len(groups) == 7, plan
@@ -333,6 +333,41 @@ def test_grouped_launch_plan_is_active(pkg, dev, weights_reduced, weights_full, 
     net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=1, fuse_pools=True, group_heads=False).load_weights(w)
     assert net.grouped_launches() == 0 and not any(n.startswith('group[') for n in net.launch_plan())
     net.close()
+    # small contexts (max_batch <= 4): the heads go out one launch per dependency level, the large convolutions grouped too
+    net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=4, fuse_pools=True).load_weights(w)
+    plan = net.launch_plan()
+    groups = [n for n in plan if n.startswith('group[')]
+    assert groups == ['group[block7_trio3+1]', 'group[block6_conv_left+3]', 'group[block6_trio3+2]', 'group[block5_conv_left+3]',
+                      'group[block5_trio3+2]', 'group[block4_conv_left+3]', 'group[block4_trio3+1]', 'group[block4_cls_pred+2]'], groups
+    assert len([n for n in plan[:-1] if not n.startswith('(')]) == 26 and net.grouped_launches() == 8
+    net.close()
+    forced = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=4, fuse_pools=True, head_plan='batch').load_weights(w)
+    assert forced.grouped_launches() == 7
+    forced.close()
+    forced = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=8, fuse_pools=True, head_plan='level').load_weights(w)
+    assert forced.grouped_launches() == 8
+    forced.close()
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-5), ('bf16', 2e-2), ('f16x3', 2e-5)])
+def test_level_plan_matches_batch_plan(pkg, dev, weights_reduced, images, dtype, tol):
+    """RON_CFG_LEVEL_GROUPS vs RON_CFG_BATCH_GROUPS: the same convolutions in other launches (tiles and the split of K differ, i.e.
+    the order of the fp32 partial sums); both deterministic."""
+    x = torch.from_numpy(images).to(dev)
+    a = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=2, fuse_pools=True, head_plan='level').load_weights(weights_reduced)
+    b = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=2, fuse_pools=True, head_plan='batch').load_weights(weights_reduced)
+    ha, hb = a.forward_heads(x), b.forward_heads(x)
+    for ta, tb in zip(ha, hb):
+        for u, v in zip(ta, tb):
+            assert _rel_err(u.cpu().numpy(), v.cpu().numpy()) <= tol
+    for name in ('block7_ref', 'block6_ref', 'block5_ref', 'block4_ref'):
+        assert _rel_err(a.end_point(name, 2).cpu().numpy(), b.end_point(name, 2).cpu().numpy()) <= tol, name
+    ha2 = a.forward_heads(x)
+    for ta, tb in zip(ha, ha2):
+        for u, v in zip(ta, tb):
+            assert torch.equal(u, v)
+    a.close()
+    b.close()
 
 
 def test_network_fn_uses_full_variant(pkg, dev, weights_full, images):
