@@ -295,7 +295,7 @@ typedef struct {
  * skips the filter rows that fall outside the image for all of its rows (bit-identical results: only products with zeros go).
  * This flag keeps the image-major order and the full K loop (tests compare the two). */
 #define RON_CFG_NO_HALO_SKIP 16u
-/* Which grouped plan the RON heads run: by default contexts with max_batch <= 2 launch the heads one launch per dependency
+/* Which grouped plan the RON heads run: by default contexts with max_batch <= 4 launch the heads one launch per dependency
  * level (10 launches, the large convolutions grouped too: at such batches every launch is latency-bound), larger ones the
  * plan above (16 launches).  RON_CFG_LEVEL_GROUPS / RON_CFG_BATCH_GROUPS force one or the other (A/B tests; same results up to
  * the order of the fp32 partial sums). */
@@ -346,7 +346,8 @@ double ron_flops_per_image(const ron_ctx* ctx);
  * no work of their own.  *name points into the context and stays valid until ron_destroy. */
 int ron_profile_enable(ron_ctx* ctx, int enable);
 int ron_profile_num_ops(const ron_ctx* ctx);
-/* Grouped launches in the plan of this context: 7 (RON-320), 5 (SSD-512); 0 with RON_CFG_NO_GROUPS / RON_CFG_MULTI_STREAM. */
+/* Grouped launches in the plan of this context: 7 (RON-320; 8 in the level plan of small contexts, RON_CFG_LEVEL_GROUPS), 5 (SSD-512);
+ * 0 with RON_CFG_NO_GROUPS / RON_CFG_MULTI_STREAM. */
 int ron_num_grouped_launches(const ron_ctx* ctx);
 int ron_profile_get(ron_ctx* ctx, int i, const char** name, int* is_conv, double* flops_per_image,
                     double* total_ms, int* launches, double* act_bytes_per_image, double* weight_bytes);

@@ -54,7 +54,7 @@ class RONNet(object):
         self.multi_stream = multi_stream
         # group_heads: the small independent head convolutions of the coarse scales share launches (RON_CFG_NO_GROUPS off)
         self.no_groups = not group_heads
-        # head_plan: None = by max_batch (<= 2: one launch per dependency level, else the batch plan); 'level' / 'batch' force one
+        # head_plan: None = by max_batch (<= 4: one launch per dependency level, else the batch plan); 'level' / 'batch' force one
         if head_plan not in (None, 'level', 'batch'):
             raise ValueError('head_plan must be None, "level" or "batch"')
         self.head_plan = head_plan

@@ -27,6 +27,15 @@ cp $O/pmc/traffic_*.json $O/ 2>/dev/null
 cp $O/pmc/mfma_busy_*.json $O/ 2>/dev/null
 python3 tools/post_regimes.py > $O/post_regimes.txt 2>> $O/err.txt
 BATCHES="1 2 4 8 16 32" bash tools/batch_sweep.sh > $O/batch_sweep.txt 2>> $O/err.txt
+# small batches: the two grouped plans of the heads side by side (contexts with max_batch <= 4 take the level plan by default)
+echo "# --head-plan batch" >> $O/batch_sweep.txt
+BATCHES="1 2 4 8" EXTRA="--head-plan batch" bash tools/batch_sweep.sh >> $O/batch_sweep.txt 2>> $O/err.txt
+echo "# --head-plan level" >> $O/batch_sweep.txt
+BATCHES="1 2 4 8" EXTRA="--head-plan level" bash tools/batch_sweep.sh >> $O/batch_sweep.txt 2>> $O/err.txt
+python3 bench.py --no-cpu-baseline --batch 1 --in-flight 1 --steps 200 --warmup 20 --layers $O/layers_cfg2_batch1.txt > $O/bench_cfg2_batch1.json 2>> $O/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --in-flight 1 --batch 1 > $O/bench_cfg2_batch1_under_rocprof.json 2>> $O/err.txt
+f=$(ls $O/prof_b1/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_batch1.csv
+rm -rf $O/prof_b1
 rm -rf $O/prof_if1 $O/prof_if2 $O/pmc/pmc_fetch $O/pmc/pmc_write $O/pmc/pmc_mfma
 ls -la $O
 tail -3 $O/pmc.log; tail -30 $O/pmc_mfma.log
