@@ -190,9 +190,42 @@ struct ImageLds {
   int keep[kMaxTopK];              // sorted row -> kept?
   int cstart[66];                  // first class-grouped position of every class
   float gbox[kMaxTopK][4];         // boxes in class-grouped order (class-wise NMS: no double indirection in the pair loop)
+  int rend[kMaxTopK];              // class-grouped position -> one past the last position of its class
 };
 
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int j) {
+  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v & 0xFFFFFFFFull), j, 64);
+  const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), j, 64);
+  return ((u64)hi << 32) | lo;
+}
+
 __device__ void bitonic_sort_desc(u64* s, int n2, int tid, int nthreads) {
+  if (n2 <= nthreads) {
+    // one key per thread: exchanges at distance < 64 are wave shuffles (45 of the 55 stages of a 1024-key sort), only the
+    // others go through LDS and a barrier
+    u64 key = tid < n2 ? s[tid] : 0;
+    for (int k = 2; k <= n2; k <<= 1) {
+      const bool desc = (tid & k) == 0;
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        u64 other;
+        if (j >= 64) {
+          __syncthreads();                       // the previous stage's reads of s are done
+          if (tid < n2) s[tid] = key;
+          __syncthreads();
+          other = tid < n2 ? s[tid ^ j] : 0;
+        } else {
+          other = shfl_xor_u64(key, j);
+        }
+        const bool take_max = ((tid & j) == 0) == desc;
+        const u64 hi = key > other ? key : other, lo = key > other ? other : key;
+        key = take_max ? hi : lo;
+      }
+    }
+    __syncthreads();
+    if (tid < n2) s[tid] = key;
+    __syncthreads();
+    return;
+  }
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < n2; i += nthreads) {
@@ -394,38 +427,53 @@ __device__ void nms_scan_classwise(ImageLds& lds, int n, float nms_thr, int num_
   const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
   const int words = (n + 63) >> 6;
   u64* mask = lds.sort;    // [n][kMaskWords], indexed by class-grouped position
-  for (int i = tid; i < 64; i += nth) lds.hist[i] = 0;
+  // class-grouped order, stable inside a class (n <= kMaxTopK <= blockDim: one row per thread).  Rank of a row among the
+  // rows of its class = same-class rows in earlier waves + same-class lanes below it in its own wave (ballots).
+  int* wcnt = reinterpret_cast<int*>(lds.sort);      // [kMaskWords waves][64 classes]; the mask is written after this phase
+  for (int i = tid; i < kMaskWords * 64; i += nth) wcnt[i] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += nth) atomicAdd(&lds.hist[lds.cls[i] & 63], 1u);
+  const int c_me = tid < n ? (lds.cls[tid] & 63) : -1;
+  int rank_me = 0;
+  if ((wave << 6) < n) {
+    u64 todo = __ballot(c_me >= 0);
+    while (todo != 0) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int lc = __shfl(c_me, leader, 64);
+      const u64 same = __ballot(c_me == lc);
+      if (c_me == lc) rank_me = __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) wcnt[(wave << 6) + lc] = __popcll(same);
+      todo &= ~same;
+    }
+  }
   __syncthreads();
-  if (tid < 64) {            // exclusive scan of the class counts
-    const int c = (int)lds.hist[tid];
-    int incl = c;
+  if (tid < 64) {            // per class: exclusive prefix over the waves, then the exclusive scan of the class totals
+    int run = 0;
+    for (int w = 0; w < words; ++w) {
+      const int t = wcnt[(w << 6) + tid];
+      wcnt[(w << 6) + tid] = run;
+      run += t;
+    }
+    int incl = run;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int v = __shfl_up(incl, d, 64);
       if (lane >= d) incl += v;
     }
-    lds.cstart[tid] = incl - c;
+    lds.cstart[tid] = incl - run;
     if (tid == 63) lds.cstart[64] = incl;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += nth) {       // stable rank inside the class
-    const int c = lds.cls[i];
-    int r = 0;
-    for (int j = 0; j < i; ++j) r += (lds.cls[j] == c) ? 1 : 0;
-    lds.order[lds.cstart[c & 63] + r] = i;
-    lds.keep[i] = 0;
-  }
-  __syncthreads();
-  for (int a = tid; a < n; a += nth) {       // boxes in grouped order
-    const int ia = lds.order[a];
+  if (tid < n) {
+    const int pos = lds.cstart[c_me] + wcnt[(wave << 6) + c_me] + rank_me;
+    lds.order[pos] = tid;
+    lds.rend[pos] = lds.cstart[c_me + 1];       // one past the last grouped position of the row's class
+    lds.keep[tid] = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) lds.gbox[a][q] = lds.box[ia][q];
+    for (int q = 0; q < 4; ++q) lds.gbox[pos][q] = lds.box[tid][q];     // boxes in grouped order
   }
-  __syncthreads();
+  __syncthreads();                             // wcnt (in lds.sort) is dead from here: the mask goes there
   for (int a = wave; a < n; a += nwaves) {   // suppression bits of grouped row a: only the words that overlap (a, end of its class)
-    const int s1 = lds.cstart[(lds.cls[lds.order[a]] & 63) + 1];
+    const int s1 = lds.rend[a];
     const int w0 = a >> 6, w1 = (s1 - 1) >> 6;
     float ba[4];
 #pragma unroll
@@ -440,20 +488,34 @@ __device__ void nms_scan_classwise(ImageLds& lds, int n, float nms_thr, int num_
   }
   __syncthreads();
   for (int c = wave; c < 64 && c < num_classes; c += nwaves) {   // one wave per class
-    const int s0 = lds.cstart[c], s1 = lds.cstart[c + 1];
+    // (read through readfirstlane: the class bounds are wave-uniform, and the row loop below then runs on scalar registers)
+    const int s0 = __builtin_amdgcn_readfirstlane(lds.cstart[c]), s1 = __builtin_amdgcn_readfirstlane(lds.cstart[c + 1]);
     if (s0 >= s1) continue;
-    const int w1 = (s1 - 1) >> 6;
-    u64 removed = 0;                           // lane w: word w of the class's "removed" set
-    for (int a = s0; a < s1; ++a) {
-      const int wi = a >> 6;
-      const unsigned lo = __builtin_amdgcn_readlane((unsigned)(removed & 0xFFFFFFFFull), wi);
-      const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), wi);
-      const u64 rw = ((u64)hi << 32) | lo;
-      if (((rw >> (a & 63)) & 1ull) == 0) {
-        // only a kept row pays the LDS round trip for its mask (measured: fetching every row one ahead, or holding 64 rows in
-        // registers and chaining readlanes, both take longer on a 218-row class); words [a >> 6, w1] of row a were written
-        if (lane >= wi && lane <= w1) removed |= mask[a * kMaskWords + lane];
-        if (lane == 0) lds.keep[lds.order[a]] = 1;
+    const int wfirst = s0 >> 6, wlast = (s1 - 1) >> 6;
+    u64 removed = 0;                           // lane w: word w of the class's "removed" set (grouped positions)
+    // 64 rows at a time.  Lane i holds the row's bits for its own block (the diagonal word); the greedy pass over the block then
+    // runs on scalar registers -- a bit test per row and, for a kept row, two readlanes -- instead of one LDS round trip per kept
+    // row (a class of 200 rows: ~20 us -> ~5).  The kept rows' bits for the later blocks are OR-reduced across the wave.
+    for (int wb = wfirst; wb <= wlast; ++wb) {
+      const int r = (wb << 6) + lane;
+      const bool in_cls = r >= s0 && r < s1;
+      const u64 diag = in_cls ? mask[r * kMaskWords + wb] : 0ull;       // words [r >> 6, wlast] of a class row were written above
+      const unsigned dlo = (unsigned)(diag & 0xFFFFFFFFull), dhi = (unsigned)(diag >> 32);
+      // (the builtin returns int: through unsigned, or the low half sign-extends into the high one)
+      u64 rem = ((u64)(unsigned)__builtin_amdgcn_readlane((unsigned)(removed >> 32), wb) << 32) |
+                (u64)(unsigned)__builtin_amdgcn_readlane((unsigned)(removed & 0xFFFFFFFFull), wb);
+      const int i0 = max(s0 - (wb << 6), 0), i1 = min(s1 - (wb << 6), 64);
+      for (int i = i0; i < i1; ++i) {
+        if (((rem >> i) & 1ull) == 0)
+          rem |= ((u64)(unsigned)__builtin_amdgcn_readlane(dhi, i) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane(dlo, i);
+      }
+      const bool kept = in_cls && ((rem >> lane) & 1ull) == 0;
+      if (kept) lds.keep[lds.order[r]] = 1;
+      for (int w2 = wb + 1; w2 <= wlast; ++w2) {
+        u64 m = kept ? mask[r * kMaskWords + w2] : 0ull;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m |= shfl_xor_u64(m, d);
+        if (lane == w2) removed |= m;
       }
     }
   }
