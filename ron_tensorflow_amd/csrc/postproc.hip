@@ -114,34 +114,47 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(HeadsDev hd, Pos
     gate = objp > pc.obj_thr;   // eval_ron_network.py:227-229
   }
 
-  // scores of this anchor (registers)
+  // scores of this anchor.  The row's exponentials are computed ONCE and kept in the row's own LDS slots (the three passes
+  // below divide the same values by the same sum: the bits of a score do not depend on which pass computed it).
   float inv_sum = 1.f, mx = 0.f;
-  const float* row = stage + tid * C;
+  float* row = stage + tid * C;
   const bool is_prob = (pc.flags & RON_IN_CLS_IS_PROB) != 0;
+  const bool argmax_mode = pc.sel_thr == 0.f;
   if (gate && !is_prob) {
     mx = row[0];
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float mx1 = -INFINITY;                       // best non-background logit
+    for (int c = 1; c < C; ++c) mx1 = fmaxf(mx1, row[c]);
+    mx = fmaxf(mx, mx1);
+    // softmax_c = exp(x_c - mx) / sum <= exp(x_c - mx) (the sum holds exp(0) = 1): when even the best class stays below the
+    // threshold by a margin far above any rounding of the real computation, the anchor selects nothing and its 2 C
+    // exponentials and C divisions are skipped (background-dominated anchors: most of a real image)
+    if (!argmax_mode && mx1 - mx < logf(pc.sel_thr) - 1e-2f) gate = false;
+  }
+  if (gate && !is_prob) {
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += expf(row[c] - mx);
+    for (int c = 0; c < C; ++c) {
+      const float e = expf(row[c] - mx);
+      row[c] = e;
+      s += e;
+    }
     inv_sum = s;
   }
   int n_sel = 0;
   // select_threshold 0 / None: the "score > no-label" branch of ssd_bboxes_select_layer (np_methods.py:82-89): ONE candidate per
   // anchor, the arg-max over ALL classes (first maximum, like np.argmax), kept when it is not the background class.  A gated-out
   // anchor is an all-zero row there: arg-max 0, dropped.
-  const bool argmax_mode = pc.sel_thr == 0.f;
   int best_c = 0;
   float best_sc = 0.f;
   if (gate && argmax_mode) {
-    best_sc = is_prob ? row[0] : expf(row[0] - mx) / inv_sum;
+    best_sc = is_prob ? row[0] : row[0] / inv_sum;
     for (int c = 1; c < C; ++c) {
-      const float sc = is_prob ? row[c] : expf(row[c] - mx) / inv_sum;
+      const float sc = is_prob ? row[c] : row[c] / inv_sum;
       if (sc > best_sc) { best_sc = sc; best_c = c; }
     }
     n_sel = best_c > 0 ? 1 : 0;
   } else if (gate) {
     for (int c = 1; c < C; ++c) {
-      const float sc = is_prob ? row[c] : expf(row[c] - mx) / inv_sum;
+      const float sc = is_prob ? row[c] : row[c] / inv_sum;
       n_sel += (sc > pc.sel_thr) ? 1 : 0;
     }
   }
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(HeadsDev hd, Pos
       return;
     }
     for (int c = 1; c < C; ++c) {
-      const float sc = is_prob ? row[c] : expf(row[c] - mx) / inv_sum;
+      const float sc = is_prob ? row[c] : row[c] / inv_sum;
       if (sc > pc.sel_thr) {
         if (pos < cap) out[pos] = make_key(sc, p0 + (unsigned)(c - 1));
         ++pos;
