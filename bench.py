@@ -53,8 +53,9 @@ def parse():
     ap.add_argument('--cpu-images', type=int, default=6, help='images run one by one (batch 1) in the bounded CPU-baseline sample; '
                     'one batch of up to --batch images follows')
     ap.add_argument('--multi-stream', action='store_true',
-                    help='run the block7/6/5 head branches on side streams (RON_CFG_MULTI_STREAM): +5 %% images/s measured, but the '
-                         'per-launch durations then overlap and no longer describe one kernel each, so it is off by default')
+                    help='run the block7/6/5 head branches on side streams (RON_CFG_MULTI_STREAM, round 1; it excludes the grouped '
+                         'launches that replaced it and is slower than the default now: 5.2 k vs 6.9 k images/s with two batches in '
+                         'flight).  Kept for A/B runs and the bitwise-equivalence test')
     ap.add_argument('--head-plan', default=None, choices=['level', 'batch'],
                     help='grouped launch plan of the RON heads (default: by batch, RON_CFG_LEVEL_GROUPS / RON_CFG_BATCH_GROUPS)')
     ap.add_argument('--in-flight', type=int, default=2,
