@@ -91,8 +91,10 @@ enum {
   kExpIgemm128x64S3 = 25,  // 128 x 64 with three / four stages (two / three K steps in flight): the latency-bound small layers
   kExpIgemm128x64S4 = 26,
   kExpIgemm128S3 = 27,     // 128 x 128 with three stages
+  kExpIgemm256x128 = 28,   // 256 x 128 on 4 x 2 waves of 64 x 64 (N = 128 layers, few-tile layers): 96 KB, one workgroup per CU
+  kExpIgemm256x128Early = 29,
 #ifdef RON_EXP
-  kNumCfgsBuilt = 28
+  kNumCfgsBuilt = 30
 #else
   kNumCfgsBuilt = kNumCfgs
 #endif

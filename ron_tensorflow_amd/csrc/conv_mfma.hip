@@ -534,6 +534,8 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case kExpIgemm128x64S3: return launch_t<Tr, 128, 64, 2, 2, 3, 2>(a, s);
     case kExpIgemm128x64S4: return launch_t<Tr, 128, 64, 2, 2, 4, 2>(a, s);
     case kExpIgemm128S3: return launch_t<Tr, 128, 128, 2, 2, 3, 1>(a, s);
+    case kExpIgemm256x128: return launch_t<Tr, 256, 128, 4, 2, 2, 1>(a, s);
+    case kExpIgemm256x128Early: return launch_t<Tr, 256, 128, 4, 2, 2, 2>(a, s);
     case kExpIgemm256H: return launch_h_t<Tr, 256, 256, 4, 2, 4, false>(a, s);
     case kExpIgemm256HTapsInner: return launch_h_t<Tr, 256, 256, 4, 2, 4, true>(a, s);
 #endif
@@ -563,10 +565,11 @@ static bool igemm_is256(int cfg) {
   return cfg == kCfgIgemm256 || cfg == kCfgIgemm256TapsInner || (cfg >= kExpIgemm256NoA && cfg <= kExpIgemm256Early) ||
          cfg == kExpIgemm256A3Early || cfg == kExpIgemm256NtA || cfg == kExpIgemm256W4 || cfg == kExpIgemm256W2x4 || cfg == kExpIgemm256H || cfg == kExpIgemm256HTapsInner;
 }
-static int igemm_bm(int cfg) { return igemm_is256(cfg) ? 256 : 128; }
+static bool igemm_is256x128(int cfg) { return cfg == kExpIgemm256x128 || cfg == kExpIgemm256x128Early; }
+static int igemm_bm(int cfg) { return (igemm_is256(cfg) || igemm_is256x128(cfg)) ? 256 : 128; }
 static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : ((cfg == kCfgIgemm128x64 || cfg == kExpIgemm128x64S3 || cfg == kExpIgemm128x64S4) ? 64 : 128); }
 // workgroups of a configuration the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
-static int igemm_slots(int cfg) { return (igemm_is256(cfg) || cfg == kExpIgemm128x64S4 || cfg == kExpIgemm128S3) ? 256 : 512; }
+static int igemm_slots(int cfg) { return (igemm_is256(cfg) || igemm_is256x128(cfg) || cfg == kExpIgemm128x64S4 || cfg == kExpIgemm128S3) ? 256 : 512; }
 
 // Split-K factor for grids that leave most CUs idle: such launches are a serial chain of KT dependent
 // HBM round trips per workgroup, so the K loop is spread over enough workgroups to fill the chip (>= 8 steps each).
@@ -580,12 +583,20 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
 // Default tile of the row-gather kernel, from tools/sweep_conv.py on MI355X at batch 32 (profiles/r01/sweep_*.txt).
 // The 256x256 tile wins once it yields >= ~160 workgroups; below that the grid is the problem and the 128x128 /
 // 2-workgroups-per-CU form keeps more CUs busy.
-int conv_pick_igemm_cfg(int M, int Npad, int taps) {
+int conv_pick_igemm_cfg(int M, int Npad, int taps, int KT, bool may_split) {
   const int tm256 = (M + 255) / 256;
   if (Npad % 128 != 0) return kCfgIgemm128x64;
-  if (Npad % 256 == 0 && tm256 * (Npad / 256) >= 160) return (taps > 1 && Npad <= 512) ? kCfgIgemm256TapsInner : kCfgIgemm256;
-  // many rounds of small tiles (conv2_x): issuing a tile's LDS-DMA pieces early in the stage wins a few per cent
-  return ((M + 127) / 128) * (Npad / 128) >= 2048 ? kCfgIgemm128Early : kCfgIgemm128;
+  if (Npad % 256 == 0) {
+    const int t256 = tm256 * (Npad / 256);
+    if (t256 >= 160) return (taps > 1 && Npad <= 512) ? kCfgIgemm256TapsInner : kCfgIgemm256;
+    // few fat tiles with a long K: split-K fills the chip with them too, at twice the arithmetic per staged byte of the 128 x 128
+    // tiles (tools/sweep_conv.py, round 3: block6_conv_left 26 tiles x 576 steps 132 -> 126 us, fc6 at batch 8 214 -> 191,
+    // cls_pred / inception2 shapes of 50-100 tiles x 144 steps +3-10 %; with K = 72 steps or a handful of tiles the 128 x 128 form wins)
+    if (may_split && t256 <= 128 && ((t256 >= 48 && KT >= 144) || (t256 >= 24 && KT >= 512))) return kCfgIgemm256;     // <= 128 tiles: K gets split
+  }
+  // the 128 x 128 tile with a stage's LDS-DMA pieces issued during its first k-step: level or 3-8 % ahead of the spread-out issue on
+  // every layer and batch of the round-3 sweep (profiles/r03/sweep_conv_128_early.txt), not only on conv2_x's many rounds
+  return kCfgIgemm128Early;
 }
 
 // Order of the tiles inside the run of workgroups that shares an XCD's L2 (1/8 of the launch): N fastest re-reads few activation
@@ -638,7 +649,9 @@ int conv_pick_cfg(const ConvLaunch& c) {
     if (cfg >= 0) return cfg;
   }
   // centre-tap-only columns are a ninth of a column's work: the grid that has to fill the chip is the long columns'
-  const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw);
+  // (split K: not with a fused pool / transposed conv, and a launch with centre-tap-only columns counts those tiles too)
+  const bool may_split = c.center_from == 0 && !c.pool && c.up == 0 && c.splitk < 0;      // (the same answer when the scratch is being sized)
+  const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype), may_split);
   return (cfg == kCfgIgemm256TapsInner && c.center_from > 0) ? kCfgIgemm256 : cfg;      // a tap must be a contiguous K range
 }
 
@@ -735,7 +748,7 @@ int launch_group_t(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
 template <class Tr>
 int launch_group_cfg(int cfg, const ConvGroupArgs& g, bool any_split, hipStream_t s) {
   if (cfg == kCfgIgemm128x64) return launch_group_t<Tr, 128, 64, 2, 2, 2, 2>(g, any_split, s);
-  if (cfg == kCfgIgemm128) return launch_group_t<Tr, 128, 128, 2, 2, 2, 1>(g, any_split, s);
+  if (cfg == kCfgIgemm128) return launch_group_t<Tr, 128, 128, 2, 2, 2, 2>(g, any_split, s);      // pieces issued early, as kCfgIgemm128Early
   ron::set_error("conv group: tile config %d has no grouped form", cfg);
   return RON_ERR_INVALID;
 }

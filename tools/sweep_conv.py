@@ -61,6 +61,8 @@ LAYERS = [
     ('b4_inc2_1x1', 40, 40, 1024, 512, 1, 1, 1, 0),
     ('b4_inc1_1x1', 40, 40, 512, 512, 1, 1, 1, 0),
     ('b5_left', 20, 20, 512, 512, 3, 1, 1, 0),
+    ('b5_cls420', 20, 20, 1024, 420, 3, 1, 1, 0),     # cls_pred with the real 2 x 10 x 21 outputs
+    ('b4_cls420', 40, 40, 1024, 420, 3, 1, 1, 0),
 ]
 
 
