@@ -520,6 +520,7 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case kCfgIgemm128Early: return launch_t<Tr, 128, 128, 2, 2, 2, 2>(a, s);
     case kCfgIgemm128x64: return launch_t<Tr, 128, 64, 2, 2, 2, 2>(a, s);
     case kCfgIgemm256TapsInner: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 0, 2, true>(a, s);
+    case kCfgIgemm128EarlyTapsInner: return launch_t<Tr, 128, 128, 2, 2, 2, 2, 0, 2, true>(a, s);
 #ifdef RON_EXP
     case kExpIgemm256NoA: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 1>(a, s);
     case kExpIgemm256NoB: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 2>(a, s);
@@ -623,7 +624,7 @@ static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int 
 // Only the tap-major K order (a skipped filter row is a contiguous K range), no fused pool / transposed conv; split-K slices
 // share what is left of a tile's K range.
 static int pick_pos_major(const ConvLaunch& c, int cfg, int BM) {
-  if (!c.halo_skip || c.pool || c.up > 0 || c.kh < 2 || cfg == kCfgIgemm256TapsInner) return 0;
+  if (!c.halo_skip || c.pool || c.up > 0 || c.kh < 2 || conv_cfg_taps_inner(cfg)) return 0;
   // at most (kh - 1) * dil of a map's H output rows can skip anything: below 5 % there is nothing to decide (and no per-tile walk
   // over the thousands of tiles of a large map on the launch path)
   if ((c.kh - 1) * c.dil * 20 < c.in.H) return 0;
@@ -651,8 +652,17 @@ int conv_pick_cfg(const ConvLaunch& c) {
   // centre-tap-only columns are a ninth of a column's work: the grid that has to fill the chip is the long columns'
   // (split K: not with a fused pool / transposed conv, and a launch with centre-tap-only columns counts those tiles too)
   const bool may_split = c.center_from == 0 && !c.pool && c.up == 0 && c.splitk < 0;      // (the same answer when the scratch is being sized)
-  const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype), may_split);
-  return (cfg == kCfgIgemm256TapsInner && c.center_from > 0) ? kCfgIgemm256 : cfg;      // a tap must be a contiguous K range
+  const int KT = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
+  const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, KT, may_split);
+  if (cfg == kCfgIgemm256TapsInner && c.center_from > 0) return kCfgIgemm256;      // a tap must be a contiguous K range
+  if (cfg == kCfgIgemm128Early && c.kh * c.kw > 1 && c.up == 0 && c.center_from == 0) {
+    // taps innermost for the 128 x 128 tile too (consecutive steps re-read almost the same input lines): 3-6 % on launches that do
+    // not split K (with split-K it loses: conv5_1 at batch 4 +10 %), and where no filter rows can be skipped instead
+    const int tiles = ((M + 127) / 128) * (c.Npad / 128);
+    const bool splits = may_split && conv_pick_splitk(tiles, KT, igemm_slots(kCfgIgemm128Early)) > 1;
+    if (!splits && !pick_pos_major(c, kCfgIgemm128Early, 128)) return kCfgIgemm128EarlyTapsInner;
+  }
+  return cfg;
 }
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
@@ -671,7 +681,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   RON_REQUIRE(cfg >= 0 && cfg < kNumCfgsBuilt, "conv: tile config %d out of range [0, %d)", cfg, kNumCfgsBuilt);
   if (conv_cfg_is_patch(cfg)) return launch_conv_patch(c, cfg, stream);
   if (cfg == kCfgC64Resident) return launch_conv_c64(c, stream);
-  RON_REQUIRE(cfg != kCfgIgemm256TapsInner || c.up == 0, "conv: the taps-innermost order is for plain convolutions");
+  RON_REQUIRE(!conv_cfg_taps_inner(cfg) || c.up == 0, "conv: the taps-innermost order is for plain convolutions");
   const int esz = (int)dtype_size(c.dtype);
   const int chunk = conv_k_chunk(c.dtype);
   RON_REQUIRE(c.in.C % chunk == 0, "conv: Cin %d is not a multiple of the K chunk %d", c.in.C, chunk);
@@ -709,7 +719,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
   a.pos_major = pick_pos_major(c, cfg, BM);
   if (c.center_from > 0)
-    RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1) && cfg != kCfgIgemm256TapsInner && c.up == 0,
+    RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1) && !conv_cfg_taps_inner(cfg) && c.up == 0,
                 "conv: centre-tap-only columns need an odd filter, the tap-major K order and a boundary on the N tile (%d)", BN);
   RON_REQUIRE((int64_t)c.Npad * K * esz == c.wgt_bytes, "conv: packed weight size mismatch");
   int rc;

@@ -119,7 +119,7 @@ def test_maxpool(ops, dev, dtype):
     assert np.array_equal(got, orf.max_pool2x2_np(x))
 
 
-IGEMM_CFGS = [0, 1, 2, 3, 7]        # conv_mfma.h: 256x256, 128x128, 128x128 early-issue, 128x64, 256x256 taps-innermost
+IGEMM_CFGS = [0, 1, 2, 3, 7, 9]     # conv_mfma.h: 256x256, 128x128, 128x128 early-issue, 128x64, 256x256 / 128x128 taps-innermost
 PATCH_CFGS = {256: 4, 128: 5, 64: 6}  # halo-patch kernel by N tile
 
 
@@ -129,7 +129,7 @@ def test_every_tile_configuration(ops, dev, cfg, dtype):
     """Each tile configuration of the row-gather kernel on a ragged multi-tile problem, K = 18 steps.  The shipped library
     holds exactly the configurations conv_pick_cfg() can select (the ablation builds live in libron_hip_diag.so)."""
     from ron_tensorflow_amd import _lib
-    assert _lib.lib().ron_conv_num_tile_cfgs() == 9
+    assert _lib.lib().ron_conv_num_tile_cfgs() == 10
     rs = np.random.RandomState(40 + cfg)
     x = rs.randn(3, 13, 11, 128).astype(np.float32)            # M = 429: two 256-row or four 128-row tiles, ragged
     wt = (rs.randn(3, 3, 128, 192) * 0.03).astype(np.float32)  # Cout 192 -> padded to 256
@@ -153,7 +153,7 @@ def test_no_entry_accepts_a_configuration_it_cannot_run(ops, dev):
     from ron_tensorflow_amd._lib import RonError
     x = torch.zeros((1, 10, 10, 64), device=dev)
     w3 = np.zeros((3, 3, 64, 64), np.float32)
-    for cfg in (9, 30, 100):
+    for cfg in (10, 31, 100):
         with pytest.raises(RonError):
             ops.conv2d_nhwc(x, w3, None, dtype='bf16', tile_cfg=cfg)
     with pytest.raises(RonError):                                        # 1x1 conv through the 3x3 patch kernel
@@ -191,7 +191,7 @@ def test_split_k(ops, dev, dtype, splitk):
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'f16x3'])
-@pytest.mark.parametrize('cfg', [-1, 0, 1, 3])
+@pytest.mark.parametrize('cfg', [-1, 0, 1, 3, 7, 9])
 def test_conv_with_fused_maxpool(ops, dev, dtype, cfg):
     """conv3x3 + bias + ReLU + 2x2/2 max-pool in one kernel == pool(conv) (nets/ron_vgg_320.py:454-466)."""
     rs = np.random.RandomState(70)

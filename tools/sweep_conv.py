@@ -3,7 +3,7 @@
 
   python tools/sweep_conv.py [--dtype bf16] [--batch 32] [--cfgs 0,2,4] [--only name-substring]
 Prints us and TFLOP/s per (layer, cfg); used to choose conv_pick_cfg() / conv_patch_pick() (csrc/conv_mfma.hip, conv_patch.hip).
-Configurations: csrc/conv_mfma.h kCfg* (0-3, 7 row-gather tiles, 4-6 halo-patch N tiles, 8 resident-weight 3x3 on 64 channels; 9+ with --exp); n/a = does not cover that layer."""
+Configurations: csrc/conv_mfma.h kCfg* (0-3, 7, 9 row-gather tiles, 4-6 halo-patch N tiles, 8 resident-weight 3x3 on 64 channels; 10+ with --exp); n/a = does not cover that layer."""
 import argparse
 import ctypes as C
 import sys, os
