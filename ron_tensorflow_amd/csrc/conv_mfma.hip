@@ -584,16 +584,17 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
 // Default tile of the row-gather kernel, from tools/sweep_conv.py on MI355X at batch 32 (profiles/r01/sweep_*.txt).
 // The 256x256 tile wins once it yields >= ~160 workgroups; below that the grid is the problem and the 128x128 /
 // 2-workgroups-per-CU form keeps more CUs busy.
-int conv_pick_igemm_cfg(int M, int Npad, int taps, int KT, bool may_split) {
+int conv_pick_igemm_cfg(int M, int Npad, int taps, int K, bool may_split) {
   const int tm256 = (M + 255) / 256;
   if (Npad % 128 != 0) return kCfgIgemm128x64;
   if (Npad % 256 == 0) {
     const int t256 = tm256 * (Npad / 256);
     if (t256 >= 160) return (taps > 1 && Npad <= 512) ? kCfgIgemm256TapsInner : kCfgIgemm256;
-    // few fat tiles with a long K: split-K fills the chip with them too, at twice the arithmetic per staged byte of the 128 x 128
-    // tiles (tools/sweep_conv.py, round 3: block6_conv_left 26 tiles x 576 steps 132 -> 126 us, fc6 at batch 8 214 -> 191,
-    // cls_pred / inception2 shapes of 50-100 tiles x 144 steps +3-10 %; with K = 72 steps or a handful of tiles the 128 x 128 form wins)
-    if (may_split && t256 <= 128 && ((t256 >= 48 && KT >= 144) || (t256 >= 24 && KT >= 512))) return kCfgIgemm256;     // <= 128 tiles: K gets split
+    // few fat tiles with a long K (in elements: the split-precision and fp32 forms take twice the steps for the same K): split-K
+    // fills the chip with them too, at twice the arithmetic per staged byte of the 128 x 128 tiles (tools/sweep_conv.py, round 3:
+    // block6_conv_left 26 tiles x 36 864 132 -> 126 us, fc6 at batch 8 214 -> 191, cls_pred / inception2 shapes of 50-100 tiles x 9 216
+    // +3-10 %; with K = 4 608 or a handful of tiles the 128 x 128 form wins, in f16x3 as well: conv5_1 188 vs 202 us)
+    if (may_split && t256 <= 128 && ((t256 >= 48 && K >= 9216) || (t256 >= 24 && K >= 32768))) return kCfgIgemm256;     // <= 128 tiles: K gets split
   }
   // the 128 x 128 tile with a stage's LDS-DMA pieces issued during its first k-step: level or 3-8 % ahead of the spread-out issue on
   // every layer and batch of the round-3 sweep (profiles/r03/sweep_conv_128_early.txt), not only on conv2_x's many rounds
@@ -653,7 +654,7 @@ int conv_pick_cfg(const ConvLaunch& c) {
   // (split K: not with a fused pool / transposed conv, and a launch with centre-tap-only columns counts those tiles too)
   const bool may_split = c.center_from == 0 && !c.pool && c.up == 0 && c.splitk < 0;      // (the same answer when the scratch is being sized)
   const int KT = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
-  const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, KT, may_split);
+  const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, c.kh * c.kw * c.in.C, may_split);
   if (cfg == kCfgIgemm256TapsInner && c.center_from > 0) return kCfgIgemm256;      // a tap must be a contiguous K range
   if (cfg == kCfgIgemm128Early && c.kh * c.kw > 1 && c.up == 0 && c.center_from == 0) {
     // taps innermost for the 128 x 128 tile too (consecutive steps re-read almost the same input lines): 3-6 % on launches that do
