@@ -577,7 +577,11 @@ static int igemm_slots(int cfg) { return (igemm_is256(cfg) || igemm_is256x128(cf
 int conv_pick_splitk(int tiles, int KT, int slots) {
   if (tiles < 1 || tiles * 2 > slots || KT < 16) return 1;
   int sk = slots / tiles;
-  if (sk > KT / 8) sk = KT / 8;
+  int min_steps = 8;
+#ifdef RON_EXP
+  if (const char* e = getenv("RON_EXP_SK_MINSTEPS")) min_steps = atoi(e);      // timing experiments (8 measured best in rounds 1 and 3)
+#endif
+  if (sk > KT / min_steps) sk = KT / min_steps;
   return sk < 1 ? 1 : sk;
 }
 
