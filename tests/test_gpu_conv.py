@@ -65,6 +65,26 @@ def test_conv2d(ops, dev, shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'f16x3'])
+@pytest.mark.parametrize('cfg', [7, 9])
+@pytest.mark.parametrize('shape', [(2, 10, 10, 64, 256, 3, 1, 3), (1, 10, 10, 64, 256, 7, 1, 1), (2, 10, 10, 128, 256, 2, 2, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_taps_innermost_orders_with_stride_rate_and_large_filters(ops, dev, shape, cfg, dtype):
+    """The chunk-major / taps-innermost K order of tile configurations 7 (256 x 256) and 9 (128 x 128) only re-sequences the
+    (tap, channel chunk) steps: rate 3, 7 x 7 and 2 x 2 / stride 2 filters against the oracle."""
+    n, h, w, cin, cout, k, stride, rate = shape
+    rs = np.random.RandomState(hash(shape) % 1000)
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    b = (rs.randn(cout) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt), stride, rate) + b, 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, stride=stride, dilation=rate, relu=True, dtype=dtype, tile_cfg=cfg,
+                          splitk=1).cpu().numpy()
+    assert got.shape == ref.shape
+    _check(got, ref, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'f16x3'])
 def test_conv2d_no_relu_no_bias_and_residual(ops, dev, dtype):
     rs = np.random.RandomState(5)
     x = rs.randn(2, 10, 10, 128).astype(np.float32)
