@@ -659,8 +659,10 @@ int conv_pick_cfg(const ConvLaunch& c) {
   const bool may_split = c.center_from == 0 && !c.pool && c.up == 0 && c.splitk < 0;      // (the same answer when the scratch is being sized)
   const int KT = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
   const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, c.kh * c.kw * c.in.C, may_split);
-  if (cfg == kCfgIgemm256TapsInner && c.center_from > 0) return kCfgIgemm256;      // a tap must be a contiguous K range
-  if (cfg == kCfgIgemm128Early && c.kh * c.kw > 1 && c.up == 0 && c.center_from == 0) {
+  // taps innermost: not where a tap must be a contiguous K range (centre-tap-only columns), and only for the stride-1 convolutions
+  // it has been measured and tested on (the stride-2 3x3 convolutions of SSD-512's extra blocks keep the tap-major order)
+  if (cfg == kCfgIgemm256TapsInner && (c.center_from > 0 || c.stride != 1)) return kCfgIgemm256;
+  if (cfg == kCfgIgemm128Early && c.kh * c.kw > 1 && c.up == 0 && c.center_from == 0 && c.stride == 1) {
     // taps innermost for the 128 x 128 tile too (consecutive steps re-read almost the same input lines): 3-6 % on launches that do
     // not split K (with split-K it loses: conv5_1 at batch 4 +10 %), and where no filter rows can be skipped instead
     const int tiles = ((M + 127) / 128) * (c.Npad / 128);
