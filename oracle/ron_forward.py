@@ -188,6 +188,28 @@ def _reverse_module(net, left, right, layer, num_anchors, num_classes, collect=N
             loc.reshape(n, h, w, num_anchors, 4))
 
 
+def _vgg_body(net, x, end_points, collect=None):
+    """conv1_1 .. conv5_3 with the five 2x2 pools (nets/ron_vgg_320.py:454-475) -> pool5.  PINNED: golden G8 holds every one of
+    these tensors up to conv5_3 as computed by the reference's own torch VGG16 (tests/test_oracle_forward.py)."""
+    for bi, (name, reps, _) in enumerate(VGG_BLOCKS):
+        for r in range(reps):
+            x = net.conv_bias(x, '%s/%s_%d' % (name, name, r + 1))
+            if collect is not None:
+                collect['%s_%d' % (name, r + 1)] = x
+        end_points['block%d' % (bi + 1)] = x
+        x = net.pool(x)
+        if collect is not None:
+            collect['pool%d' % (bi + 1)] = x
+    return x
+
+
+def vgg_body(images, weights, backend='numpy', round_fn=None):
+    """The VGG-16 body alone (what ron_forward runs first), every conv / pool output by name: for the G8 pin."""
+    collect = {}
+    _vgg_body(_Net(weights, backend, round_fn), np.asarray(images, dtype=F32), {}, collect)
+    return collect
+
+
 def ron_forward(images, weights, variant='reducedfc', num_classes=21, num_anchors=10, backend='numpy',
                 round_fn=None, collect=None):
     """RON-320 forward.  images [N,320,320,3] fp32 (mean-subtracted RGB).
@@ -198,16 +220,7 @@ def ron_forward(images, weights, variant='reducedfc', num_classes=21, num_anchor
     from . import np_post
     net = _Net(weights, backend, round_fn)
     end_points = {}
-    x = np.asarray(images, dtype=F32)
-    for bi, (name, reps, _) in enumerate(VGG_BLOCKS):
-        for r in range(reps):
-            x = net.conv_bias(x, '%s/%s_%d' % (name, name, r + 1))
-            if collect is not None:
-                collect['%s_%d' % (name, r + 1)] = x
-        end_points['block%d' % (bi + 1)] = x
-        x = net.pool(x)
-        if collect is not None:
-            collect['pool%d' % (bi + 1)] = x
+    x = _vgg_body(net, np.asarray(images, dtype=F32), end_points, collect)
     if variant == 'full':        # nets/ron_vgg_320.py:478-483
         x = net.conv_bias(x, 'fc6')                # 7x7 512 -> 4096
     elif variant == 'reducedfc':  # nets/ron_vgg_320.py:553-556

@@ -104,9 +104,10 @@ def l2_normalization(x, gamma):
     return (x / np.sqrt(np.maximum(ss, F32(1e-12))) * gamma).astype(F32)
 
 
-def ssd_forward(images, weights, num_classes=21, round_fn=None, collect=None, backend='numpy'):
+def ssd_forward(images, weights, num_classes=21, round_fn=None, collect=None, backend='numpy', stop_after=None):
     """Returns (predictions, localisations, logits, end_points) like SSDNet.net (nets/ssd_vgg_512.py:459).
-    backend 'torch' swaps every conv / pool for the independent torch-CPU operator (tests/test_oracle_forward.py)."""
+    backend 'torch' swaps every conv / pool for the independent torch-CPU operator (tests/test_oracle_forward.py);
+    stop_after='block7' returns after the VGG backbone (for the G8 pin: only conv1_1 .. conv7 weights are needed)."""
     from .ron_forward import BACKENDS
     rnd = round_fn if round_fn is not None else (lambda a: a)
     conv_same, _, pool2 = BACKENDS[backend]
@@ -127,6 +128,8 @@ def ssd_forward(images, weights, num_classes=21, round_fn=None, collect=None, ba
 
     end_points = {}
     x = np.asarray(images, dtype=F32)
+    # conv1_1 .. conv7 (nets/ssd_vgg_512.py:364-400): PINNED - golden G8 holds every one of these tensors as computed by the
+    # reference's own torch VGG16 (convert_pytorch_vgg.py:13-58), tests/test_oracle_forward.py
     for bi, reps in enumerate([2, 2, 3, 3, 3]):
         for r in range(reps):
             x = conv(x, 'conv%d/conv%d_%d' % (bi + 1, bi + 1, r + 1))
@@ -140,6 +143,10 @@ def ssd_forward(images, weights, num_classes=21, round_fn=None, collect=None, ba
     end_points['block6'] = x
     x = conv(x, 'conv7')
     end_points['block7'] = x
+    if collect is not None:
+        collect['conv6'], collect['conv7'] = end_points['block6'], end_points['block7']
+    if stop_after == 'block7':
+        return None, None, None, end_points
     for b in range(8, 13):
         x = conv(x, 'block%d/conv1x1' % b)
         if collect is not None:

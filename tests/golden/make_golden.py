@@ -5,6 +5,7 @@ Runs only in the build container (needs /root/reference).  It imports
 
   * ``nets/np_methods.py``  (numpy only)                      -> G2, G3, G4, G5 (SSD-512 pipeline)
   * ``nets/ron_vgg_320.py`` under a stubbed ``tensorflow``     -> G1 (anchor grids)
+  * ``convert_pytorch_vgg.py`` (its torch ``VGG16`` / ``vgg``)  -> G8 (the conv backbone, every layer, 320^2 and 512^2)
 
 and stores inputs (or the seed that regenerates them) together with the outputs the
 reference produced.  Nothing of the reference's source text is stored: the .npz
@@ -348,6 +349,65 @@ def g4_edge(npm):
     np.savez_compressed(os.path.join(HERE, 'g4_edge.npz'), **out)
 
 
+def load_ref_torch_vgg():
+    """The reference's only EXECUTABLE conv stack: ``VGG16`` and ``vgg(cfg, i)`` of convert_pytorch_vgg.py:13-58 (plain torch:
+    13 convs, pools M M C M, pool5 3x3 s1, conv6 3x3 dilation 6, conv7 1x1 = nets/ssd_vgg_512.py:364-400 up to block7 and
+    conv1_1 .. conv5_3 of nets/ron_vgg_320.py:454-475).  The file imports keras / mmdnn / pytorch2keras at module level for its
+    converter functions (not installed, not needed by the two definitions): those three are stubbed in sys.modules and the
+    module body is executed up to its ``__main__`` guard, in memory - nothing of its text is stored."""
+    for name in ('keras', 'mmdnn', 'mmdnn.conversion', 'mmdnn.conversion.keras', 'mmdnn.conversion.keras.keras2_parser',
+                 'pytorch2keras', 'pytorch2keras.converter'):
+        sys.modules.setdefault(name, mock.MagicMock(name=name))
+    with open(os.path.join(REF, 'convert_pytorch_vgg.py')) as f:
+        text = f.read()
+    text = text[:text.index("if __name__ == '__main__':")]
+    mod = types.ModuleType('ref_convert_pytorch_vgg')
+    mod.__dict__['os'] = os            # VGG16.load_weights (unused here) expects it
+    exec(compile(text, os.path.join(REF, 'convert_pytorch_vgg.py'), 'exec'), mod.__dict__)
+    return mod
+
+
+def g8_vgg_backbone():
+    """Golden G8: the reference's torch VGG16 run on seeded weights and seeded 320^2 / 512^2 images, every one of its 35 modules
+    captured.  Stored per tensor (NCHW -> NHWC): the values at synth.g8_sample_index rows x columns (all channels) and float64
+    sum / sum of squares over the WHOLE tensor.  Weights and images are regenerated from the seeds (oracle/synth.py)."""
+    import torch
+    ref = load_ref_torch_vgg()
+    seed_w = 80
+    model = ref.VGG16(ref.vgg(list(synth.VGG_CFG), 3))
+    assert len(model.vgg) == 35
+    convs = [m for m in model.vgg if isinstance(m, torch.nn.Conv2d)]
+    wts = synth.vgg_backbone_weights_oihw(seed_w)
+    assert len(convs) == len(wts) == 15
+    with torch.no_grad():
+        for m, (w, b) in zip(convs, wts):
+            assert tuple(m.weight.shape) == w.shape
+            m.weight.copy_(torch.from_numpy(w))
+            m.bias.copy_(torch.from_numpy(b))
+    model.eval()
+    # module outputs in order; a Conv2d's tensor is overwritten by the in-place ReLU behind it, so taps are taken after ReLU / pool
+    taps = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: taps.append(out.detach().clone()))
+             for m in model.vgg if not isinstance(m, torch.nn.Conv2d)]
+    out = {'seed_weights': np.int64(seed_w)}
+    for size, seed_x in ((320, 81), (512, 82)):
+        img = synth.vgg_backbone_image(seed_x, size)
+        del taps[:]
+        with torch.no_grad():
+            y = model(torch.from_numpy(img).permute(0, 3, 1, 2).contiguous())
+        assert len(taps) == len(synth.VGG_TAPS) == 20 and y.shape[1] == 1024
+        out['seed_image_%d' % size] = np.int64(seed_x)
+        for name, t in zip(synth.VGG_TAPS, taps):
+            a = t.permute(0, 2, 3, 1).contiguous().numpy()
+            iy, ix = synth.g8_sample_index(a.shape[1]), synth.g8_sample_index(a.shape[2])
+            out['%d/%s/shape' % (size, name)] = np.array(a.shape, dtype=np.int64)
+            out['%d/%s/sample' % (size, name)] = a[:, iy][:, :, ix].copy()
+            out['%d/%s/sum' % (size, name)] = np.array([a.sum(dtype=np.float64), (a.astype(np.float64) ** 2).sum()])
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(HERE, 'g8_vgg_backbone.npz'), **out)
+
+
 def main():
     npm = load_np_methods()
     ron = load_ref_ron()
@@ -359,6 +419,7 @@ def main():
     g3_pipeline(npm, anchors)
     g5_pipeline_ssd(npm, ssd_anchors)
     g4_edge(npm)
+    g8_vgg_backbone()
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith('.npz'):
             print(fn, os.path.getsize(os.path.join(HERE, fn)), 'bytes')
