@@ -13,7 +13,9 @@ all-gathered over RCCL (the only exchange the path has).
 
 Rank 0 prints ONE JSON line (contract in the task description) with `roofline` (dominant kernel = the
 implicit-GEMM conv kernel, MFMA-bound; achieved = algorithmic conv FLOPs per launch / HIP-event duration of
-those launches inside the timed region) and, at N = 1, `cpu_baseline` (the oracle port timed on the host cores).
+those launches inside the timed region) and, at N = 1, `cpu_baseline` (the oracle port timed on the host cores) and
+`parity_mode` (the same workload in dtype f16x3, the arithmetic that meets the 1e-4 clause: its own timed steps after the
+headline's timed region, with its agreement against the fp32 oracle).
 """
 import argparse
 import json
@@ -50,6 +52,10 @@ def parse():
                     help="bf16 = BASELINE config 2 (default); f16x3 = split precision: detections within 1e-4 of the fp32 CPU reference "
                          "on the f16 matrix cores (three MFMAs per product); fp32 = exact-fp32 MFMA parity mode")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity-mode', action='store_true',
+                    help='skip the second, untimed-by-the-headline leg that runs the same workload in the arithmetic that meets '
+                         'north_star\'s 1e-4 clause (dtype f16x3) and reports it as "parity_mode"')
+    ap.add_argument('--parity-steps', type=int, default=10)
     ap.add_argument('--cpu-images', type=int, default=6, help='images run one by one (batch 1) in the bounded CPU-baseline sample; '
                     'one batch of up to --batch images follows')
     ap.add_argument('--multi-stream', action='store_true',
@@ -162,6 +168,46 @@ def load_traffic(args):
            'note': 'committed PMC measurement of an earlier run of this command (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes); '
                    'not collected in this run'}
     return t.get('hbm_bytes_per_conv_launch'), src
+
+
+def parity_mode_leg(args, ron_class, ron_params, weights, images, dev, detect_args, top_k, ref_dets):
+    """The same workload in the arithmetic that meets north_star's float tolerance (split precision, dtype f16x3: detections
+    within 1e-4 of the fp32 CPU reference), AFTER the headline's timed region and outside its clock: a second context over the
+    same weights and images, `--parity-steps` timed steps through the same two-slot pipeline and the same bench_loop.
+    `ref_dets`: the fp32 oracle's detections of the first images (from the cpu_baseline leg), or None."""
+    import torch
+    from ron_tensorflow_amd import parallel
+    from ron_tensorflow_amd.metrics import detection_agreement
+    from ron_tensorflow_amd.pipeline import DetectPipeline
+    dtype = 'f16x3'
+    if args.variant == 'ssd512':
+        net = ron_class(ron_params, dtype=dtype, max_batch=args.batch, device=dev, fuse_pools=True)
+    else:
+        net = ron_class(ron_params, variant=args.variant, dtype=dtype, max_batch=args.batch, device=dev, fuse_pools=True,
+                        head_plan=args.head_plan)
+    net.load_weights(weights)
+    in_flight = max(1, args.in_flight)
+    pipe = DetectPipeline(net, slots=in_flight, top_k=top_k)
+    steps = max(1, args.parity_steps)
+    res = parallel.bench_loop(pipe, images, steps, 3, in_flight, detect_args, top_k, device=dev)
+    dt, det = res['dt'], res['det']
+    tflops = net.flops_per_image() * args.batch * steps / dt / 1e12
+    out = {'dtype': dtype, 'images_per_s': args.batch * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'warmup': 3,
+           'batches_in_flight': in_flight, 'conv_stack_tflops': tflops, 'peak_tflops': PEAK_F16X3_TFLOPS,
+           'roofline_frac_of_833': tflops / PEAK_F16X3_TFLOPS,
+           'note': 'same weights, images, pipeline and loop as the headline, run after its timed region; three f16 MFMAs per '
+                   'algorithmic product, hence the peak of 2500 / 3 TFLOP/s'}
+    if ref_dets is not None:
+        got = det.to_lists()
+        agr = [detection_agreement(got[i], ref_dets[i], tol=1e-4) for i in range(len(ref_dets))]
+        nref = max(sum(a['n_ref'] for a in agr), 1)
+        out['agreement'] = {'images': len(ref_dets), 'reference_detections': sum(a['n_ref'] for a in agr),
+                            'reproduced': sum(a['reproduced'] * a['n_ref'] for a in agr) / nref,
+                            'within_1e-4_of_reproduced': float(np.mean([a['within_tol'] for a in agr])),
+                            'max_score_diff': max(a['max_score_diff'] for a in agr), 'max_box_diff': max(a['max_box_diff'] for a in agr)}
+    pipe.close()
+    net.close()
+    return out
 
 
 def main():
@@ -352,6 +398,9 @@ def main():
                 'max_score_diff': max(a['max_score_diff'] for a in agr), 'max_box_diff': max(a['max_box_diff'] for a in agr),
                 'note': 'same (class, anchor_index) pairs after NMS, first %d images of the batch; fp32 device mode reproduces >= 98 %% '
                         'with scores / boxes within 1e-4 (tests/test_gpu_forward.py)' % n1}
+        if world == 1 and not use_dist and not args.no_parity_mode and args.dtype not in ('f16x3', 'fp32'):
+            out['parity_mode'] = parity_mode_leg(args, ron_class, ron_params, weights, images, dev, detect_args, top_k,
+                                                 ref_dets if not args.no_cpu_baseline else None)
         if args.layers:
             rows = solo_rows                         # each kernel alone
             with open(args.layers, 'w') as f:

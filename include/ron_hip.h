@@ -52,7 +52,12 @@ typedef enum { RON_VARIANT_REDUCEDFC = 0, RON_VARIANT_FULL = 1, RON_VARIANT_SSD5
  *           4 bytes per element: 32 hi followed by 32 lo per 128-byte channel chunk) and a product is three f16 MFMAs
  *           hi*hi + lo*hi + hi*lo into the fp32 accumulator (the dropped lo*lo term is 2^-22 relative); weights carry a
  *           per-layer power-of-two scale (undone in the epilogue) so that their lo plane stays a normal f16.  fp32-grade
- *           head tensors (detections within 1e-4 of the fp32 CPU reference) at a third of the f16 matrix peak. */
+ *           head tensors (detections within 1e-4 of the fp32 CPU reference) at a third of the f16 matrix peak.
+ *           VALID ACTIVATION RANGE (activations carry no scale): 22 bits hold for 2^-3 <= |v| < 65504.  Above, a value
+ *           saturates instead of overflowing: up to 131008 it is kept as 65504 + rest (f16 spacing of 32), beyond it clips;
+ *           NaN stays NaN.  Below 2^-3 the lo plane is an f16 subnormal (the matrix core does not flush it): an ABSOLUTE error
+ *           floor of 2^-25 per stored value, i.e. a tensor whose whole scale is 2^-10 keeps ~15 bits.  RON / SSD activations on
+ *           unscaled mean-subtracted images are O(1) .. O(10^3).  tests/test_gpu_conv.py holds both regimes against float64. */
 typedef enum { RON_DTYPE_F32 = 0, RON_DTYPE_BF16 = 1, RON_DTYPE_F16 = 2, RON_DTYPE_F16X3 = 3 } ron_dtype;
 
 const char* ron_last_error(void);

@@ -10,6 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tooling (tools/sweep_conv.py --exp / --diag) may point RON_HIP_LIB at the experimental / diagnostic build of the same ABI
 LIB_PATH = os.environ.get('RON_HIP_LIB') or os.path.join(_HERE, 'libron_hip.so')
 
+# the ABI this binding was written against (include/ron_hip.h, ron_abi_version): a stale libron_hip.so (git-ignored, but shipped by
+# gpurun) with a shorter ron_conv_desc would silently ignore the new fields
+EXPECTED_ABI = 2
+
 RON_MAX_LAYERS = 8
 RON_MAX_TOPK = 512
 
@@ -147,6 +151,10 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the symbol is missing: fail loudly
             fn.restype = res
             fn.argtypes = args
+        have = handle.ron_abi_version()
+        if have != EXPECTED_ABI:
+            raise RonError('%s has ABI version %d, this package needs %d: rebuild libron_hip.so (`make -C ron_tensorflow_amd/csrc`)'
+                           % (LIB_PATH, have, EXPECTED_ABI))
         _lib = handle
     return _lib
 

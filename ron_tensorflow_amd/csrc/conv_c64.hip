@@ -11,13 +11,13 @@
 //   * wave w owns tile row w: a fragment's rows are consecutive patch rows; 16x16x32 MFMAs (on random data the chip holds a
 //     higher clock under them than under 32x32x16: conv2_1 115 -> 110 us, a 64-output layer 270 -> 250 us), 16-row fragments,
 //     chunk swizzle ((row >> 1) & 3) << 1: conflict-free ds_read_b128 at every tap shift (the LDS-DMA applies it on the source
-//     address).  The first form (32x32x16, 32-row fragments, (row >> 1) & 7) is kept in the experimental build with the ablation
-//     switches and cycle stamps the numbers below were taken with;
+//     address).  The first form (32x32x16, 32-row fragments, (row >> 1) & 7) and the ablation
+//     switches and cycle stamps the numbers below were taken with are in tools/experiments/ (README.md there);
 //   * one barrier per tile;
 //   * epilogue: + bias, ReLU, a lane holds four adjacent channels of eight pixels: 8-byte stores, 16 lanes = one 128-B line.  The
 //     stores of tile t go out between the MFMAs of tile t+1, one per K step: the layer writes 210 MB at batch 32, and with every
 //     workgroup storing its tile at the same moment between two tap loops nothing computed while HBM took the burst (stores
-//     alone 36 us, patch staging alone 31 us, both 75 us of a 113 us launch: RON_C64_ABL in the experimental build);
+//     alone 36 us, patch staging alone 31 us, both 75 us of a 113 us launch);
 //   * a wave's vmcnt counts loads and stores, which do not retire in order with respect to each other: the one wait per tile
 //     (after the taps) is for everything - the next patch and the previous tile's stores, both issued a tap loop earlier.
 // The workgroups of the halves of one tile sequence share an XCD (they stage the same patches: the second read hits L2).
@@ -48,13 +48,7 @@ struct C64Args {
   int out_Hp, out_Wp, out_pad, out_cstride, out_coff;
   int n_img, H, W, halves, relu;
   int n_slots;                // tile sequences (a multiple of 8): grid = n_slots * halves
-  int abl;                    // experimental builds only (RON_C64_ABL): 1 = no patch staging after the first, 2 = no taps, 4 = no stores
 };
-#ifdef RON_EXP
-#define RON_C64_ABL(bit_) (p.abl & (bit_))
-#else
-#define RON_C64_ABL(bit_) 0
-#endif
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_c64;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_c64;
@@ -71,187 +65,6 @@ struct C64F16 : TraitsF16 {
   }
 };
 
-#ifdef RON_EXP   // the first form of this kernel (32x32x16 MFMAs), with its ablation switches and cycle stamps: RON_C64_MF32=1
-// RW = tile rows per wave: 1 (8 waves; shipped) or 2 (experimental builds: 4 waves, one per SIMD, a weight fragment feeds two pixel
-// rows, 1.0 instead of 1.5 ds_read_b128 per MFMA - measured: the same run time, the fragment reads are not what bounds the loop).
-template <class Tr, int RW>
-__global__ __launch_bounds__(512 / RW) void conv3x3_c64_kernel(C64Args p) {
-  constexpr int NW = 8 / RW, kThreads = 64 * NW;
-  constexpr int kPiecesPerWave = (kC6Pieces + NW - 1) / NW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* s_w = smem;
-  char* s_p = smem + kC6WBytes;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  // workgroup -> (half, tile sequence): the halves of a sequence are neighbours on one XCD (blockIdx % 8)
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int half = idx % p.halves;
-  const int slot = (idx / p.halves) * 8 + xcd;
-  const int tiles_x = p.W / kC6TW, tiles_y = p.H / kC6TH;
-  const int n_tiles = p.n_img * tiles_y * tiles_x;
-
-  // LDS-DMA pieces of a patch: piece i (1 KB = 8 patch rows) is issued by wave i % NW; lane -> (row 8i + lane / 8, slot lane % 8),
-  // source chunk = slot ^ key(row).  Offsets relative to the tile's first patch pixel; rows past the patch re-read its last row.
-  // fixed-size array on purpose: with a template-dependent bound the LDS-DMA builtin's voffset becomes a type-dependent expression
-  // and hipcc (ROCm 7.2) silently drops the kernel
-  int voff[11];
-  static_assert(kPiecesPerWave <= 11, "pieces per wave");
-#pragma unroll
-  for (int k = 0; k < kPiecesPerWave; ++k) {
-    const int q = min((wave + NW * k) * 8 + (lane >> 3), kC6Rows - 1);
-    const int chunk = (lane & 7) ^ ((q >> 1) & 7);
-    voff[k] = ((q / kC6PW) * p.in_Wp + q % kC6PW) * 128 + chunk * 16;
-  }
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-#define RON_C64_STAGE(tile_, buf_)                                                                                    \
-  do {                                                                                                                \
-    const int t_ = (tile_);                                                                                           \
-    const int fx = t_ % tiles_x, fy = (t_ / tiles_x) % tiles_y, fimg = t_ / (tiles_x * tiles_y);                      \
-    /* patch row 0 = input pixel (y0 - 1, x0 - 1) */                                                                  \
-    const int soff = ((fimg * p.in_Hp + p.in_pad + fy * kC6TH - 1) * p.in_Wp + p.in_pad + fx * kC6TW - 1) * 128;      \
-    char* dst_ = s_p + (buf_) * kC6PatchBytes + wave * 1024;                                                          \
-    _Pragma("unroll") for (int k = 0; k < kPiecesPerWave; ++k)                                                        \
-      if (wave + NW * k < kC6Pieces)                                                                                  \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst_ + k * NW * 1024), 16, voff[k], soff, 0, 0);     \
-  } while (0)
-
-  if (slot < n_tiles) RON_C64_STAGE(slot, 0);
-  // this half's weights: the host packed the exact LDS image
-  {
-    const u32x4* wsrc = p.wimg + (size_t)half * (kC6WBytes / 16);
-    for (int i = tid; i < kC6WBytes / 16; i += kThreads) reinterpret_cast<u32x4*>(s_w)[i] = wsrc[i];
-  }
-  const int n0 = half * 64;
-  const float b0 = p.bias[n0 + 2 * r], b1 = p.bias[n0 + 2 * r + 1];
-  const int key_b = (r >> 1) & 7;
-  // stores: buffer addressing, per-lane offset fixed for the life of the workgroup (pixel 4h of a row, channels n0 + 2r, 2r + 1),
-  // the tile / row / accumulator-register part is a scalar offset: no address arithmetic per store
-  const int st_voff = (4 * h * p.out_cstride + p.out_coff + n0 + 2 * r) * 2;
-  const int st_rowb = p.out_Wp * p.out_cstride * 2;                                  // bytes from one output row to the next
-  const int st_row = __builtin_amdgcn_readfirstlane(wave) * RW * st_rowb;
-  const float lo = p.relu ? 0.f : -__builtin_huge_valf();
-  // the previous tile's accumulators and where they go; before the first tile: a descriptor without records (stores dropped)
-  f32x16 prev[RW][2];
-#pragma unroll
-  for (int w = 0; w < RW; ++w)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) prev[w][t][e] = 0.f;
-  int prev_off = 0;
-  unsigned prev_records = 0;
-#define RON_C64_STORE(w_, e_)                                                                                         \
-  do {                                                                                                                \
-    if (RON_C64_ABL(4)) break;                                                                                        \
-    const int m_ = ((e_) & 3) + 8 * ((e_) >> 2);          /* + 4h: pixel of the row this accumulator register holds */  \
-    const float v0_ = fmaxf(prev[w_][0][e_] + b0, lo), v1_ = fmaxf(prev[w_][1][e_] + b1, lo);                         \
-    __builtin_amdgcn_raw_buffer_store_b32(Tr::cvt2(v0_, v1_), rs_st, st_voff, prev_off + (w_) * st_rowb + m_ * p.out_cstride * 2, 0); \
-  } while (0)
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // first patch + the weight image (ds_write) of this wave
-
-#ifdef RON_EXP   // RON_C64_ABL & 8: where a wave's cycles go (barrier / taps / the wait / the rest), printed by two workgroups
-  unsigned long long t_bar = 0, t_taps = 0, t_wait = 0, t_rest = 0, c0 = __builtin_readcyclecounter();
-  int n_done = 0;
-#define RON_C64_T(acc_) do { const unsigned long long c1_ = __builtin_readcyclecounter(); acc_ += c1_ - c0; c0 = c1_; } while (0)
-#else
-#define RON_C64_T(acc_) do {} while (0)
-#endif
-  int buf = 0;
-  for (int tile = slot; tile < n_tiles; tile += p.n_slots, buf ^= 1) {
-    // every wave's pieces of this tile's patch have landed (each waited for its own before it got here), and nobody reads the
-    // other buffer any more.  A raw barrier: __syncthreads() would also wait for the previous tile's stores.
-    __builtin_amdgcn_s_barrier();
-    RON_C64_T(t_bar);
-    if (tile + p.n_slots < n_tiles && !RON_C64_ABL(1)) RON_C64_STAGE(tile + p.n_slots, buf ^ 1);
-    const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, prev_records, 0x00020000);
-    const char* sp = s_p + buf * kC6PatchBytes;
-    f32x16 acc[RW][2];
-#pragma unroll
-    for (int w = 0; w < RW; ++w)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[w][t][e] = 0.f;
-    // 36 k-steps (9 taps x 4 groups of 16 input channels), 2 RW MFMAs each.  The fragments of step i + 3 are read while step i
-    // multiplies (a ring of four register sets): left to itself hipcc reads each fragment right before the MFMA that needs it
-    // and every MFMA waits out an LDS round trip.  The previous tile's 16 RW stores go out behind the steps 2 .. 17, RW each
-    // (early: the wait below is for them too).
-    u32x4 fa[4][RW], fb0[4], fb1[4];
-    auto frag_read = [&](int i) {
-      const int tap = i >> 2, ks = i & 3, j = i & 3;
-      const char* pb = s_w + tap * 8192 + r * 128 + (((2 * ks + h) ^ key_b) << 4);
-#pragma unroll
-      for (int w = 0; w < RW; ++w) {
-        const int prow = (wave * RW + w + tap / 3) * kC6PW + r + tap % 3;
-        const int key_a = (prow >> 1) & 7;
-        fa[j][w] = *reinterpret_cast<const u32x4*>(sp + prow * 128 + (((2 * ks + h) ^ key_a) << 4));
-      }
-      fb0[j] = *reinterpret_cast<const u32x4*>(pb);
-      fb1[j] = *reinterpret_cast<const u32x4*>(pb + 32 * 128);
-    };
-    if (!RON_C64_ABL(2)) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) frag_read(i);
-#pragma unroll
-      for (int i = 0; i < 36; ++i) {
-        if (i + 3 < 36) frag_read(i + 3);
-#pragma unroll
-        for (int w = 0; w < RW; ++w) {
-          Tr::mma(fa[i & 3][w], fb0[i & 3], acc[w][0]);
-          Tr::mma(fa[i & 3][w], fb1[i & 3], acc[w][1]);
-        }
-        if (i >= 2 && i < 18) {
-#pragma unroll
-          for (int w = 0; w < RW; ++w) RON_C64_STORE(w, i >= 2 && i < 18 ? i - 2 : 0);
-        }
-      }
-      // pin that order: the reads of a step spread between its MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (RW + 2), 0);
-#pragma unroll
-      for (int i = 0; i < 36; ++i) {
-#pragma unroll
-        for (int q = 0; q < 2 * RW; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (i + 3 < 36) {
-            // RW + 2 reads over 2 RW MFMAs: RW = 1: 2 + 1, RW = 2: 1 each
-            if (RW == 1 && q == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          }
-        }
-        if (i >= 2 && i < 18) __builtin_amdgcn_sched_group_barrier(0x040, RW, 0);
-      }
-    }
-    // this wave's pieces of the next patch (and the stores above) are done
-    RON_C64_T(t_taps);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    RON_C64_T(t_wait);
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, img = tile / (tiles_x * tiles_y);
-    prev_off = ((img * p.out_Hp + p.out_pad + ty * kC6TH) * p.out_Wp + p.out_pad + tx * kC6TW) * p.out_cstride * 2 + st_row;   // bytes
-    prev_records = p.out_bytes;
-#pragma unroll
-    for (int w = 0; w < RW; ++w) { prev[w][0] = acc[w][0]; prev[w][1] = acc[w][1]; }
-#ifdef RON_EXP
-    RON_C64_T(t_rest);
-    ++n_done;
-#endif
-  }
-#ifdef RON_EXP
-  if ((p.abl & 8) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 101) && (wave == 0 || wave == NW - 1))
-    printf("c64 wg %d wave %d: %d tiles, cycles per tile: barrier %llu taps %llu wait %llu rest %llu\n", (int)blockIdx.x, wave, n_done,
-           t_bar / n_done, t_taps / n_done, t_wait / n_done, t_rest / n_done);
-#endif
-  {   // the last tile's stores (no records if this workgroup had no tile)
-    const __amdgpu_buffer_rsrc_t rs_st = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, prev_records, 0x00020000);
-#pragma unroll
-    for (int w = 0; w < RW; ++w)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) RON_C64_STORE(w, e);
-  }
-#undef RON_C64_STORE
-#undef RON_C64_STAGE
-}
-
-#endif   // RON_EXP
 
 // ---- the same kernel on 16x16x32 MFMAs --------------------------------------------------------------------------------
 // On random data the chip holds a higher clock under v_mfma_f32_16x16x32 than under 32x32x16 (CDNA4 guide, DVFS: 1.12-1.14 x the
@@ -408,45 +221,24 @@ int launch_c64_16_t(const C64Args& a, hipStream_t s) {
   return RON_OK;
 }
 
-#ifdef RON_EXP
-template <class Tr, int RW>
-int launch_c64_t(const C64Args& a, hipStream_t s) {
-  static PerDeviceOnce once;
-  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_c64_kernel<Tr, RW>), kC6Lds));
-  hipLaunchKernelGGL((conv3x3_c64_kernel<Tr, RW>), dim3(a.n_slots * a.halves), dim3(512 / RW), kC6Lds, s, a);
-  RON_HIP_CHECK(hipGetLastError());
-  return RON_OK;
-}
-#endif
 
 }  // namespace detail
 using namespace detail;
 
 // LDS images for conv3x3_c64_kernel from fp32 rows [npad][K = 9 * 64] (row n, k = tap * 64 + cin): per 64-channel half, tap-major,
-// row (j * 32 + r) of a tap holds output channel 64 * half + 2r + j, its 64 input channels as 8 chunks of 16 B, chunk c in slot
-// c ^ ((row >> 1) & 7).
-// which MFMA shape the kernel runs on, and so which weight image is packed: 16x16x32, except RON_C64_MF32=1 in the experimental build
-static bool c64_mf16() {
-#ifdef RON_EXP
-  static const bool v = getenv("RON_C64_MF32") == nullptr;
-  return v;
-#else
-  return true;
-#endif
-}
+// row (j * 16 + c) of a tap holds output channel 64 * half + 4c + j, its 64 input channels as 8 chunks of 16 B, chunk q in slot
+// q ^ (((row >> 1) & 3) << 1) (the 16x16x32 MFMA's fragments, conflict-free at every tap shift).
 
 std::vector<uint8_t> pack_conv_c64_weights(const std::vector<float>& rows, int npad, int dtype) {
   const int halves = npad / 64;
-  const bool mf16 = c64_mf16();
   std::vector<uint16_t> img((size_t)halves * 9 * 64 * 64, 0);
   for (int hf = 0; hf < halves; ++hf)
     for (int tap = 0; tap < 9; ++tap)
       for (int row = 0; row < 64; ++row) {
-        // 32x32 form: row (j * 32 + r) = channel 2r + j, key (row >> 1) & 7; 16x16 form: row (j * 16 + c) = channel 4c + j, key ((row >> 1) & 3) << 1
-        const int ch = 64 * hf + (mf16 ? 4 * (row % 16) + row / 16 : 2 * (row % 32) + row / 32);
+        const int ch = 64 * hf + 4 * (row % 16) + row / 16;
         for (int cin = 0; cin < 64; ++cin) {
           const float v = rows[(size_t)ch * 576 + tap * 64 + cin];
-          const int chunk = cin / 8, slot = chunk ^ (mf16 ? ((row >> 1) & 3) << 1 : (row >> 1) & 7);
+          const int chunk = cin / 8, slot = chunk ^ (((row >> 1) & 3) << 1);
           img[(((size_t)hf * 9 + tap) * 64 + row) * 64 + slot * 8 + cin % 8] = dtype == RON_DTYPE_BF16 ? f32_to_bf16_rne(v) : f32_to_f16_rne(v);
         }
       }
@@ -475,17 +267,6 @@ int launch_conv_c64(const ConvLaunch& c, hipStream_t stream) {
   a.n_img = c.in.N; a.H = c.Ho; a.W = c.Wo; a.halves = c.Cout / 64; a.relu = c.relu;
   const int n_tiles = c.in.N * (c.Ho / kC6TH) * (c.Wo / kC6TW);
   a.n_slots = std::min(256 / a.halves, (n_tiles + 7) / 8 * 8);
-  a.abl = 0;
-#ifdef RON_EXP
-  if (const char* e = getenv("RON_C64_ABL")) a.abl = atoi(e);
-#endif
-#ifdef RON_EXP   // RON_C64_MF32=1: the 32x32x16 form (RON_C64_RW=2: on four waves of two tile rows each: same run time)
-  if (!c64_mf16()) {
-    const char* e = getenv("RON_C64_RW");
-    if (e != nullptr && atoi(e) == 2) return c.dtype == RON_DTYPE_BF16 ? launch_c64_t<C64BF16, 2>(a, stream) : launch_c64_t<C64F16, 2>(a, stream);
-    return c.dtype == RON_DTYPE_BF16 ? launch_c64_t<C64BF16, 1>(a, stream) : launch_c64_t<C64F16, 1>(a, stream);
-  }
-#endif
   return c.dtype == RON_DTYPE_BF16 ? launch_c64_16_t<C64BF16S>(a, stream) : launch_c64_16_t<C64F16S>(a, stream);
 }
 

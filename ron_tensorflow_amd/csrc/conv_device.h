@@ -65,8 +65,6 @@ struct ConvArgs {
   // Column tiles at or beyond output channel center_from_n (0: none) hold a 1x1 branch whose weights sit in the centre tap of the
   // kh x kw filter, zeros elsewhere: they run the K steps of that tap only.
   int center_from_n;
-  // diagnostic builds only (ABL 5): per-wave cycle sums {wait, barrier, compute, K steps}, 4 x u64 per wave
-  unsigned long long* dbg;
 };
 
 // MFMA shape of a traits class: kMT x kMT output tile per instruction (32: v_mfma_f32_32x32x16, 16 accumulator registers;
@@ -186,6 +184,16 @@ struct TraitsF32S : TraitsF32 {
 // 16 x 16 x 32 block into one fp32 accumulator.  hi*hi is exact in the matrix core (11 x 11 bits), the dropped lo*lo term is
 // 2^-22 of the product.  Element index i of a tensor -> f16 index (i / 32) * 64 + i % 32 (+ 32 for the lo plane): pixel
 // strides and channel slices are multiples of 32 elements everywhere.
+// One value -> its two f16 planes.  Both conversions SATURATE at the largest finite f16 (65504) instead of overflowing to inf:
+// hi = +inf, lo = -inf would read back as NaN and poison every later layer; saturated, |v| up to 131008 is still representable
+// (hi = 65504, lo = the rest, with the f16 spacing of 32 up there) and larger values clip.  NaN stays NaN.  Accuracy contract
+// (include/ron_hip.h, RON_DTYPE_F16X3): 22 mantissa bits for 2^-3 <= |v| < 65504; below, lo is an f16 subnormal (not flushed by
+// the matrix core), i.e. an ABSOLUTE error floor of 2^-25 per stored value.
+static __device__ __forceinline__ float sat_f16(float v) { return v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v); }
+static __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)sat_f16(v);
+  lo = (_Float16)sat_f16(v - (float)hi);
+}
 struct TraitsF16X3S {
   typedef f32x4 acc_t;
   static constexpr int kMT = 16;
@@ -202,17 +210,17 @@ struct TraitsF16X3S {
   }
   static __device__ __forceinline__ void store(void* p, int i, float v) {
     _Float16* h = reinterpret_cast<_Float16*>(p) + hidx(i);
-    const _Float16 hi = (_Float16)v;
+    _Float16 hi, lo;
+    split_f16(v, hi, lo);
     h[0] = hi;
-    h[32] = (_Float16)(v - (float)hi);
+    h[32] = lo;
   }
   template <int N> static __device__ __forceinline__ void store_vec(void* p, int i, const float* v) {
     static_assert(32 % N == 0, "a vector must not straddle a 32-element chunk");
     EVec<_Float16, N> hi, lo;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      hi.v[j] = (_Float16)v[j];
-      lo.v[j] = (_Float16)(v[j] - (float)hi.v[j]);
+      split_f16(v[j], hi.v[j], lo.v[j]);
     }
     _Float16* h = reinterpret_cast<_Float16*>(p) + hidx(i);
     *reinterpret_cast<EVec<_Float16, N>*>(h) = hi;
@@ -382,7 +390,6 @@ inline void fill_conv_args(const ConvLaunch& c, ConvArgs* out) {
   a.m_fastest = 0;
   a.pos_major = 0; a.n_img = c.in.N; a.in_H = c.in.H; a.cpad = c.cpad; a.kh = c.kh;
   a.center_from_n = c.center_from;
-  a.dbg = c.dbg;
   *out = a;
 }
 

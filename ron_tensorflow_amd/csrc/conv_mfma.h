@@ -54,7 +54,6 @@ struct ConvLaunch {
   int splitk = -1;               // split-K factor; -1 = pick by grid size, 1 = off
   void* scratch = nullptr;       // fp32 slabs for split-K (conv_scratch_bytes); null disables split-K
   int64_t scratch_bytes = 0;
-  unsigned long long* dbg = nullptr;   // diagnostic library only (stamp builds): 4 x u64 per wave of the grid
 };
 
 constexpr int kWeightBlockRows = 64;     // packed weights: [Npad / 64][K steps][64 rows][128 B] (pack.h, block_rows)
@@ -71,39 +70,10 @@ enum {
   kCfgIgemm256TapsInner = 7,   // 256 x 256 with K ordered chunk-major, taps innermost (layers with <= 2 column tiles)
   kCfgC64Resident = 8,     // 3x3 on a 64-channel map with the weights resident in LDS (conv_c64.hip)
   kCfgIgemm128EarlyTapsInner = 9,   // 128 x 128, early issue, K ordered chunk-major with the taps innermost (launches that do not split K)
-  kNumCfgs = 10,
-  // experimental builds only (make EXP=1 -> libron_hip_exp.so, tools/sweep_conv.py): timing variants, some with wrong results
-  kExpPatch128S4 = 10,     // halo-patch, 128 channels, 4 weight stages (three steps of lead)
-  kExpPatch256NoA = 11,    // halo-patch 256 without the patch traffic / without the weight traffic / without either
-  kExpPatch256NoB = 12,
-  kExpPatch256NoAB = 13,
-  kExpIgemm256NoA = 14,    // row-gather 256 x 256 likewise
-  kExpIgemm256NoB = 15,
-  kExpIgemm256NoAB = 16,
-  kExpIgemm256A3 = 17,     // row-gather 256 x 256 with three activation stages (+ two weight stages = all 160 KB of LDS)
-  kExpIgemm256Early = 18,  // row-gather 256 x 256 with all pieces of a stage issued during its first k-step
-  kExpIgemm128A3 = 19,     // row-gather 128 x 128 with three activation stages (80 KB: still two workgroups per CU)
-  kExpIgemm256A3Early = 20,
-  kExpIgemm256NtA = 21,    // row-gather 256 x 256 with non-temporal activation loads (the weights keep the L2)
-  kExpIgemm256W4 = 22,     // row-gather 256 x 256 on 4 waves of 128 x 128 (a third fewer LDS fragment reads, one wave per SIMD)
-  kExpIgemm256W2x4 = 23,   // row-gather 256 x 256 on 2 x 4 waves of 128 x 64 (the shipped one is 4 x 2 of 64 x 128)
-  kExpIgemm256H = 24,      // row-gather 256 x 256 with half-chunk stages: four stages of 32 KB, three in flight
-  kExpIgemm256HTapsInner = 25,
-  kExpIgemm128x64S3 = 26,  // 128 x 64 with three / four stages (two / three K steps in flight): the latency-bound small layers
-  kExpIgemm128x64S4 = 27,
-  kExpIgemm128S3 = 28,     // 128 x 128 with three stages
-  kExpIgemm256x128 = 29,   // 256 x 128 on 4 x 2 waves of 64 x 64 (N = 128 layers, few-tile layers): 96 KB, one workgroup per CU; level with 128 x 128
-  kExpIgemm256x128Early = 30,
-#ifdef RON_EXP
-  kNumCfgsBuilt = 31
-#else
-  kNumCfgsBuilt = kNumCfgs
-#endif
+  kNumCfgs = 10
 };
-inline bool conv_cfg_taps_inner(int cfg) { return cfg == kCfgIgemm256TapsInner || cfg == kCfgIgemm128EarlyTapsInner || cfg == kExpIgemm256HTapsInner; }
-inline bool conv_cfg_is_patch(int cfg) {
-  return (cfg >= kCfgPatch256 && cfg <= kCfgPatch64) || (cfg >= kExpPatch128S4 && cfg <= kExpPatch256NoAB);
-}
+inline bool conv_cfg_taps_inner(int cfg) { return cfg == kCfgIgemm256TapsInner || cfg == kCfgIgemm128EarlyTapsInner; }
+inline bool conv_cfg_is_patch(int cfg) { return cfg >= kCfgPatch256 && cfg <= kCfgPatch64; }
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream);
 // 3x3 / stride 1 / pad 1 on a 64-channel map, weights resident in LDS (conv_c64.hip); pack_conv_c64_weights builds wgt_c64

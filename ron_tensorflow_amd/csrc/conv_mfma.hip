@@ -16,12 +16,9 @@
 // Epilogue: + bias, ReLU, optional relu(x + residual) (reverse-connection sum), optional pixel-shuffle addressing
 // (2x2 stride-2 transposed conv), optional fused 2x2 max-pool, store as dtype or fp32.
 //
-// This file holds the configurations conv_pick_cfg() can select, nothing else.  The ablation / stamp / experimental
-// builds of this kernel live in diag/ and are compiled only into libron_hip_diag.so (make DIAG=1).
+// This file holds the configurations conv_pick_cfg() can select, nothing else.  The ablation / stamp / experimental forms of
+// this kernel that rounds 1-3 measured (HISTORY.md) are not in the tree: tools/experiments/README.md says where they are.
 #include "conv_device.h"
-#ifdef RON_EXP
-#include <stdlib.h>
-#endif
 
 namespace ron {
 namespace detail {
@@ -56,16 +53,10 @@ __device__ __forceinline__ void pin_ksteps() {
 
 // Tile configuration: BM x BN block tile, WM x WN waves (each wave owns (BM/WM) x (BN/WN)), S LDS stages.
 // SPREAD 1: the LDS-DMA pieces of a tile are shared out over the k-steps of the stage; 2: all go out during k-step 0.
-// EXP (experimental builds only, make EXP=1): 1 = the A descriptor has no records (only the weights move), 2 = the B
-// descriptor has none, 3 = neither moves (timing-only, results are wrong); 8 = non-temporal activation loads (results
-// valid, 10-20 % slower).  0 in everything the shipped library holds.
+// TI: K ordered chunk-major with the taps innermost (see below).
 // One tile of launch `p`: workgroup `bid` of the `nwg` that launch consists of (a launch of its own, or a range of the
 // workgroups of a grouped launch).
-// SA: stages of the A (activation) ring; the B (weight) ring has S.  SA = S + 1 gives the activation pieces two K steps to
-// land instead of one: the two operands of a 256 x 256 x 64 step are 32 KB each, so three A stages + two B stages are
-// exactly the CU's 160 KB of LDS.  The per-row tables then alias a weight stage during set-up and the output offsets are
-// recomputed after the K loop.
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S, bool TI = false>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, bool TI = false>
 __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigned bid, const unsigned nwg, char* smem) {
   constexpr int kLanesPerRow = kRowBytes / 16;       // 16-byte chunks per row
   constexpr int MT = Tr::kMT;                        // MFMA output tile (16)
@@ -79,20 +70,16 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   constexpr int A_IT = BM / kRowsPerIt, B_IT = BN / kRowsPerIt;
   constexpr int LPT = A_IT + B_IT;                   // LDS-DMA instructions per thread and K step
   constexpr int kABytes = BM * kRowBytes, kBBytes = BN * kRowBytes;
-  constexpr int kRingBytes = SA * kABytes + S * kBBytes;
-  constexpr bool kTablesAlias = SA > S;               // the deeper ring takes the LDS the tables would need: see SA above
+  constexpr int kRingBytes = S * (kABytes + kBBytes);
   constexpr int kChunkElems = kRowBytes / Tr::kEsz;
-  static_assert(SA == S || SA == S + 1, "activation ring: as deep as the weight ring, or one deeper");
-  static_assert(!kTablesAlias || 3 * BM * (int)sizeof(int) <= kBBytes, "tables must fit a weight stage");
   static_assert(BM % kRowsPerIt == 0 && BN % kRowsPerIt == 0 && kRowsPerIt % 16 == 0, "tile / thread-count mismatch");
   static_assert(TM % 32 == 0 && TN % 32 == 0 && S >= 2 && S <= 5, "bad wave tile / stage count");
   static_assert(NR <= 8, "vector epilogue: at most 8 channels per lane");
   static_assert(SPREAD == 1 || SPREAD == 2, "SPREAD");
-  // layout: [A stage 0 .. SA-1][B stage 0 .. S-1][in_off: BM ints][out_off: BM ints]; kTablesAlias: the tables sit in the
-  // last B stage until the K loop starts (the first LDS-DMA into that stage is issued in step 0)
+  // layout: [A stage 0 .. S-1][B stage 0 .. S-1][in_off: BM ints][out_off: BM ints][out2_off: BM ints]
   char* s_a = smem;
-  char* s_b = smem + SA * kABytes;
-  int* s_in_off = reinterpret_cast<int*>(kTablesAlias ? s_b + (S - 1) * kBBytes : smem + kRingBytes);
+  char* s_b = smem + S * kABytes;
+  int* s_in_off = reinterpret_cast<int*>(smem + kRingBytes);
   int* s_out_off = s_in_off + BM;
   int* s_out2_off = s_out_off + BM;                   // fused pool with the un-pooled map as a second output (ConvArgs::out2)
 
@@ -157,8 +144,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
     kt1 = min(hi, kt0 + per);
   }
 
-  // per-row addressing, once per tile (kTablesAlias: the output offsets once more after the K loop)
-  auto fill_tables = [&](int* in_off, int* out_off) {
+  // per-row addressing, once per tile
   for (int r = tid; r < BM; r += kThreads) {
     int img, oy, ox, off;
     bool valid;
@@ -173,7 +159,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
       oy = 2 * py + ((r >> 1) & 1);
       ox = 2 * px + (r & 1);
       off = ((img * p.out_Hp + py + p.out_pad) * p.out_Wp + px + p.out_pad) * p.out_cstride + p.out_coff;
-      if (p.out2 != nullptr && in_off != nullptr)
+      if (p.out2 != nullptr)
         s_out2_off[r] = valid ? ((img * p.out2_Hp + oy + p.out2_pad) * p.out2_Wp + ox + p.out2_pad) * p.out2_cstride + p.out2_coff : -1;
     } else {
       int m = m0 + r;
@@ -189,11 +175,9 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
       off = ((img * p.out_Hp + oy * os + p.out_pad) * p.out_Wp + ox * os + p.out_pad) * p.out_cstride + p.out_coff;
     }
     const int iy = oy * p.stride + p.in_org, ix = ox * p.stride + p.in_org;
-    if (in_off != nullptr) in_off[r] = (int)((((unsigned)(img * p.in_Hp + iy) * p.in_Wp + ix) * p.in_cstride + p.in_coff) * Tr::kEsz);
-    out_off[r] = valid ? off : -1;
+    s_in_off[r] = (int)((((unsigned)(img * p.in_Hp + iy) * p.in_Wp + ix) * p.in_cstride + p.in_coff) * Tr::kEsz);
+    s_out_off[r] = valid ? off : -1;
   }
-  };
-  fill_tables(s_in_off, s_out_off);
   __syncthreads();
 
   // LDS-DMA source offsets (bytes): thread -> (row = it*kRowsPerIt + tid/8, slot = tid%8), source chunk = slot ^ key(row)
@@ -225,31 +209,29 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   // coming back to them a whole sweep of the channels later: the re-reads hit L2 without another workgroup's help.  Worth
   // 1-6 % on layers with one or two column tiles (nobody else on the XCD stages the same input rows at the same time), nothing
   // or -1 % on the wide ones (profiles/r02/sweep_conv_exp_v4_tapsinner.txt); conv_pick_igemm_cfg selects it accordingly.
-  static_assert(!TI || SA == S, "taps-innermost order: equal ring depths");
   const int n_taps = p.KT / chunks_per_tap;
   const int tap0 = TI ? kt0 % n_taps : kt0 / chunks_per_tap;
   int ky = tap0 / p.kw, kx = tap0 - (tap0 / p.kw) * p.kw;
   int cc = (TI ? kt0 / n_taps : kt0 - tap0 * chunks_per_tap) * kChunkElems;
   int tb = TI ? kt0 % n_taps : 0, cb = TI ? kt0 / n_taps : 0;          // weight ring: tap / chunk of its next tile
-  // One K step issues LPT LDS-DMA pieces per thread: the B_IT weight pieces of tile kt+S-1 first, then the A_IT
-  // activation pieces of tile kt+SA-1 (a wave's vmcnt retires in issue order: the pieces that may stay in flight longest
-  // go out last).  RON_STAGE_BEGIN computes the wave-uniform part once per step, RON_STAGE_PIECE issues piece j
+  // One K step issues LPT LDS-DMA pieces per thread: the B_IT weight pieces of tile kt+S-1 first, then its A_IT
+  // activation pieces.  RON_STAGE_BEGIN computes the wave-uniform part once per step, RON_STAGE_PIECE issues piece j
   // (compile-time), RON_STAGE_END advances the tap of the activation ring.
 #define RON_STAGE_BEGIN(kt_)                                                                                         \
     /* past the last tile: zero-record descriptors, the DMA moves nothing but keeps the vmcnt bookkeeping uniform */  \
-    const int kta_ = (kt_) + SA - 1, ktb_ = (kt_) + S - 1;                                                           \
+    const int ktb_ = (kt_) + S - 1;                                                                                  \
     const __amdgpu_buffer_rsrc_t rs_a =                                                                              \
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (kta_ < kt1 && !(EXP & 1)) ? p.in_bytes : 0u, 0x00020000); \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, ktb_ < kt1 ? p.in_bytes : 0u, 0x00020000);     \
     const __amdgpu_buffer_rsrc_t rs_b =                                                                              \
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (ktb_ < kt1 && !(EXP & 2)) ? p.wgt_bytes : 0u, 0x00020000); \
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, ktb_ < kt1 ? p.wgt_bytes : 0u, 0x00020000);   \
     const int a_soff = ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz;                         \
     const int b_soff = (TI ? tb * chunks_per_tap + cb : ktb_) * kWeightBlockBytes;                                   \
-    char* dst_a = s_a + ((kta_ - kt0) % SA) * kABytes + wave * 1024;                                                 \
+    char* dst_a = s_a + ((ktb_ - kt0) % S) * kABytes + wave * 1024;                                                  \
     char* dst_b = s_b + ((ktb_ - kt0) % S) * kBBytes + wave * 1024;
 #define RON_STAGE_PIECE_B(i_)                                                                                        \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(dst_b + (i_) * kRowsPerIt * kRowBytes), 16, b_voff[i_], b_soff, 0, 0)
 #define RON_STAGE_PIECE_A(i_)                                                                                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst_a + (i_) * kRowsPerIt * kRowBytes), 16, a_voff[i_], a_soff, 0, (EXP & 8) ? 2 : 0)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(dst_a + (i_) * kRowsPerIt * kRowBytes), 16, a_voff[i_], a_soff, 0, 0)
 #define RON_STAGE_PIECE(j_)                                                                                          \
     do {                                                                                                             \
       if ((j_) < B_IT) RON_STAGE_PIECE_B((j_) < B_IT ? (j_) : 0);                                                    \
@@ -285,28 +267,25 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   const int a_base = wm * TM * kRowBytes;
   const int b_base = wn * TN * kRowBytes;
 
-  // prologue: the steps before the first one, in the order the loop issues them: SA-1 activation tiles and S-1 weight
-  // tiles in flight (a step before tile 0 only issues what exists)
+  // prologue: the steps before the first one, in the order the loop issues them: S-1 tiles in flight
 #pragma unroll
-  for (int t = -(SA - 1); t < 0; ++t) {
+  for (int t = -(S - 1); t < 0; ++t) {
     RON_STAGE_BEGIN(kt0 + t)
-    if (t + S - 1 >= 0) {
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i) RON_STAGE_PIECE_B(i);
-    }
+    for (int i = 0; i < B_IT; ++i) RON_STAGE_PIECE_B(i);
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) RON_STAGE_PIECE_A(i);
     RON_STAGE_END();
   }
 
   for (int kt = kt0; kt < kt1; ++kt) {
-    // this wave's share of tile kt has landed; the youngest S-2 groups and the activation pieces one group further back
-    // (SA = S + 1) may still be in flight
-    wait_vmcnt<(S - 2) * LPT + (SA - S) * A_IT>();
+    // this wave's share of tile kt has landed; the youngest S-2 groups of LPT pieces may still be in flight.  The count relies on
+    // the compiler emitting exactly LPT LDS-DMA instructions per step (prologue included): tests/test_isa_protocol.py checks the ISA
+    wait_vmcnt<(S - 2) * LPT>();
     __builtin_amdgcn_s_barrier();           // ... everyone's has, and everyone is done reading tile kt-1
     // refill the stages tile kt-1 occupied; the LPT pieces go out between the MFMAs below
     RON_STAGE_BEGIN(kt)
-    const char* sbuf_a = s_a + ((kt - kt0) % SA) * kABytes;
+    const char* sbuf_a = s_a + ((kt - kt0) % S) * kABytes;
     const char* sbuf_b = s_b + ((kt - kt0) % S) * kBBytes;
     // fragments of k-step s+1 are read while the MFMAs of k-step s run (two register sets)
     u32x4 fa[2][MR], fb[2][NR];
@@ -344,15 +323,6 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
 #undef RON_STAGE_PIECE_A
 #undef RON_STAGE_PIECE_B
 #undef RON_STAGE_END
-  if (kTablesAlias) {
-    // the output offsets were overwritten by the weight ring: once more, into the first activation stage (nobody reads
-    // the rings any more once every wave is past its last K step)
-    __syncthreads();
-    s_out_off = reinterpret_cast<int*>(s_a);
-    fill_tables(nullptr, s_out_off);
-    __syncthreads();
-  }
-
   // epilogue.  C/D layout of the 16x16 MFMA: column = lane % 16, row = e + 4 * (lane / 16), e < 4
   int tap_off = 0, n_base = n0;
   if (p.up > 0) {
@@ -377,21 +347,16 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
     }
     return;
   }
-  conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n_base + nloc, tap_off, kTablesAlias ? nullptr : s_out2_off);
+  conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n_base + nloc, tap_off, s_out2_off);
 }
 
-#ifdef RON_EXP
-#include "exp/conv_igemm_h.h"   // kExpIgemm256H: four half-chunk stages, three in flight (slower; see the header)
-#endif
 
-constexpr int igemm_lds_bytes(int BM, int BN, int S, int SA) {
-  return (SA * BM + S * BN) * kRowBytes + (SA > S ? 0 : 3 * BM * (int)sizeof(int));
-}
+constexpr int igemm_lds_bytes(int BM, int BN, int S) { return S * (BM + BN) * kRowBytes + 3 * BM * (int)sizeof(int); }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S, bool TI = false>
-__global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S, SA) > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, bool TI = false>
+__global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S) > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA, TI>(p, blockIdx.x, gridDim.x, smem);
+  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD, TI>(p, blockIdx.x, gridDim.x, smem);
 }
 
 // Several independent small convolutions in ONE launch (the per-scale head layers of the coarse scales, each of which
@@ -424,7 +389,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_group_kernel(ConvG
   for (int j = 1; j < kMaxGroup; ++j)
     if (j < g.n && b >= g.first[j]) k = j;
   const ConvArgs p = load_group_op(k);
-  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD, 0>(p, (unsigned)(b - g.first[k]), (unsigned)(g.first[k + 1] - g.first[k]), smem);
+  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD>(p, (unsigned)(b - g.first[k]), (unsigned)(g.first[k + 1] - g.first[k]), smem);
 }
 
 template <class Tr>
@@ -490,27 +455,16 @@ __global__ void splitk_finalize_group_kernel(ConvGroupArgs g) {
   if (p.splitk > 1) splitk_finalize_body<Tr>(p);
 }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, int EXP = 0, int SA = S, bool TI = false>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, bool TI = false>
 int launch_t(const ConvArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, SA);
+  const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S);
   static PerDeviceOnce once;
-  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA, TI>), (int)lds));
-  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, EXP, SA, TI>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, TI>), (int)lds));
+  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, TI>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
 
-#ifdef RON_EXP
-template <class Tr, int BM, int BN, int WM, int WN, int S, bool TI>
-int launch_h_t(const ConvArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)igemm_h_lds_bytes(BM, BN, S);
-  static PerDeviceOnce once;
-  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_h_kernel<Tr, BM, BN, WM, WN, S, TI>), (int)lds));
-  hipLaunchKernelGGL((conv_igemm_h_kernel<Tr, BM, BN, WM, WN, S, TI>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
-  RON_HIP_CHECK(hipGetLastError());
-  return RON_OK;
-}
-#endif
 
 template <class Tr>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
@@ -519,27 +473,8 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case kCfgIgemm128: return launch_t<Tr, 128, 128, 2, 2, 2, 1>(a, s);
     case kCfgIgemm128Early: return launch_t<Tr, 128, 128, 2, 2, 2, 2>(a, s);
     case kCfgIgemm128x64: return launch_t<Tr, 128, 64, 2, 2, 2, 2>(a, s);
-    case kCfgIgemm256TapsInner: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 0, 2, true>(a, s);
-    case kCfgIgemm128EarlyTapsInner: return launch_t<Tr, 128, 128, 2, 2, 2, 2, 0, 2, true>(a, s);
-#ifdef RON_EXP
-    case kExpIgemm256NoA: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 1>(a, s);
-    case kExpIgemm256NoB: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 2>(a, s);
-    case kExpIgemm256NoAB: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 3>(a, s);
-    case kExpIgemm256A3: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 0, 3>(a, s);
-    case kExpIgemm256NtA: return launch_t<Tr, 256, 256, 4, 2, 2, 1, 8>(a, s);
-    case kExpIgemm256Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0>(a, s);
-    case kExpIgemm128A3: return launch_t<Tr, 128, 128, 2, 2, 2, 1, 0, 3>(a, s);
-    case kExpIgemm256A3Early: return launch_t<Tr, 256, 256, 4, 2, 2, 2, 0, 3>(a, s);
-    case kExpIgemm256W4: return launch_t<Tr, 256, 256, 2, 2, 2, 1>(a, s);
-    case kExpIgemm256W2x4: return launch_t<Tr, 256, 256, 2, 4, 2, 1>(a, s);
-    case kExpIgemm128x64S3: return launch_t<Tr, 128, 64, 2, 2, 3, 2>(a, s);
-    case kExpIgemm128x64S4: return launch_t<Tr, 128, 64, 2, 2, 4, 2>(a, s);
-    case kExpIgemm128S3: return launch_t<Tr, 128, 128, 2, 2, 3, 1>(a, s);
-    case kExpIgemm256x128: return launch_t<Tr, 256, 128, 4, 2, 2, 1>(a, s);
-    case kExpIgemm256x128Early: return launch_t<Tr, 256, 128, 4, 2, 2, 2>(a, s);
-    case kExpIgemm256H: return launch_h_t<Tr, 256, 256, 4, 2, 4, false>(a, s);
-    case kExpIgemm256HTapsInner: return launch_h_t<Tr, 256, 256, 4, 2, 4, true>(a, s);
-#endif
+    case kCfgIgemm256TapsInner: return launch_t<Tr, 256, 256, 4, 2, 2, 1, true>(a, s);
+    case kCfgIgemm128EarlyTapsInner: return launch_t<Tr, 128, 128, 2, 2, 2, 2, true>(a, s);
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;
@@ -560,17 +495,13 @@ using namespace detail;
 size_t dtype_size(int dtype) { return dtype_is_half(dtype) ? 2 : 4; }     // F16X3: a hi and a lo f16 per element
 int conv_k_chunk(int dtype) { return kRowBytes / (int)dtype_size(dtype); }
 int conv_n_tile(int cout) { return cout <= 64 ? 64 : 128; }
-int conv_num_cfgs() { return kNumCfgsBuilt; }
+int conv_num_cfgs() { return kNumCfgs; }
 
-static bool igemm_is256(int cfg) {
-  return cfg == kCfgIgemm256 || cfg == kCfgIgemm256TapsInner || (cfg >= kExpIgemm256NoA && cfg <= kExpIgemm256Early) ||
-         cfg == kExpIgemm256A3Early || cfg == kExpIgemm256NtA || cfg == kExpIgemm256W4 || cfg == kExpIgemm256W2x4 || cfg == kExpIgemm256H || cfg == kExpIgemm256HTapsInner;
-}
-static bool igemm_is256x128(int cfg) { return cfg == kExpIgemm256x128 || cfg == kExpIgemm256x128Early; }
-static int igemm_bm(int cfg) { return (igemm_is256(cfg) || igemm_is256x128(cfg)) ? 256 : 128; }
-static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : ((cfg == kCfgIgemm128x64 || cfg == kExpIgemm128x64S3 || cfg == kExpIgemm128x64S4) ? 64 : 128); }
+static bool igemm_is256(int cfg) { return cfg == kCfgIgemm256 || cfg == kCfgIgemm256TapsInner; }
+static int igemm_bm(int cfg) { return igemm_is256(cfg) ? 256 : 128; }
+static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : (cfg == kCfgIgemm128x64 ? 64 : 128); }
 // workgroups of a configuration the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
-static int igemm_slots(int cfg) { return (igemm_is256(cfg) || igemm_is256x128(cfg) || cfg == kExpIgemm128x64S4 || cfg == kExpIgemm128S3) ? 256 : 512; }
+static int igemm_slots(int cfg) { return igemm_is256(cfg) ? 256 : 512; }
 
 // Split-K factor for grids that leave most CUs idle: such launches are a serial chain of KT dependent
 // HBM round trips per workgroup, so the K loop is spread over enough workgroups to fill the chip (>= 8 steps each).
@@ -578,9 +509,6 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
   if (tiles < 1 || tiles * 2 > slots || KT < 16) return 1;
   int sk = slots / tiles;
   int min_steps = 8;
-#ifdef RON_EXP
-  if (const char* e = getenv("RON_EXP_SK_MINSTEPS")) min_steps = atoi(e);      // timing experiments (8 measured best in rounds 1 and 3)
-#endif
   if (sk > KT / min_steps) sk = KT / min_steps;
   return sk < 1 ? 1 : sk;
 }
@@ -674,18 +602,7 @@ int conv_pick_cfg(const ConvLaunch& c) {
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg(c);
-#ifdef RON_EXP
-  if (const char* e = getenv("RON_EXP_REMAP")) {       // "1:27,3:26": the picked configuration a -> b (timing experiments)
-    for (const char* q = e; *q;) {
-      char* end;
-      const int a = (int)strtol(q, &end, 10);
-      const int b = (int)strtol(end + 1, &end, 10);
-      if (cfg == a) { cfg = b; break; }
-      q = *end ? end + 1 : end;
-    }
-  }
-#endif
-  RON_REQUIRE(cfg >= 0 && cfg < kNumCfgsBuilt, "conv: tile config %d out of range [0, %d)", cfg, kNumCfgsBuilt);
+  RON_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "conv: tile config %d out of range [0, %d)", cfg, kNumCfgs);
   if (conv_cfg_is_patch(cfg)) return launch_conv_patch(c, cfg, stream);
   if (cfg == kCfgC64Resident) return launch_conv_c64(c, stream);
   RON_REQUIRE(!conv_cfg_taps_inner(cfg) || c.up == 0, "conv: the taps-innermost order is for plain convolutions");
@@ -747,7 +664,7 @@ namespace detail {
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 int launch_group_t(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
-  const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, S);
+  const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S);
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), (int)lds));
   hipLaunchKernelGGL((conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(g.first[g.n]), dim3(WM * WN * 64), lds, s, g);

@@ -42,15 +42,13 @@ struct PatchArgs {
 };
 
 // SB weight stages: SB-1 steps of lead for the per-tap weight tiles.
-// EXP (experimental builds only, make EXP=1; 0 in everything the shipped library holds): bit 0 = no patch traffic, bit 1 =
-// no weight traffic (zero-record descriptors: timing only, results wrong).
 // One tile of convolution `p` (geometry `pa`): workgroup `bid` of the `nwg` that convolution's launch -- or its share of a pair
 // launch -- consists of.
 // TPS: filter taps per step (= per barrier).  1: the form above.  3: a step is a whole filter ROW -- three taps' weights staged
 // together, 3 x KS k-steps of MFMAs between two barriers.  For N <= 64 a tap is only MR * NR * KS = 16 MFMAs per wave, too few to
 // hide a step's fixed cost (counted wait + barrier, LDS-DMA issue, first-fragment latency: ~1500 cycles per step whatever is in
 // flight, profiles/r03/skinny_heads_pair.txt); three taps per barrier triple the work behind it.
-template <class Tr, int BN, int WN, int SB, int EXP = 0, int TPS = 1>
+template <class Tr, int BN, int WN, int SB, int TPS = 1>
 __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const ConvArgs& p, const unsigned bid, const unsigned nwg) {
   constexpr int BM = 256, WM = 8 / WN, kThreads = 512;
   constexpr int MT = Tr::kMT, kGroups = 64 / MT, KS = 8 / kGroups, EPA = MT * MT / 64;
@@ -165,8 +163,8 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
   const int b_base = wn * TN * kRowBytes;
 
   // descriptors are rebuilt at the use site with 0 records for pieces that have nothing to fetch
-#define RS_A(live_) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, ((live_) && !(EXP & 1)) ? p.in_bytes : 0u, 0x00020000)
-#define RS_B(live_) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, ((live_) && !(EXP & 2)) ? p.wgt_bytes : 0u, 0x00020000)
+#define RS_A(live_) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (live_) ? p.in_bytes : 0u, 0x00020000)
+#define RS_B(live_) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (live_) ? p.wgt_bytes : 0u, 0x00020000)
   // piece k_ (compile time) of the patch of chunk cc_ into buffer buf_; a wave whose 8 rows lie past the buffer sinks it
 #define PATCH_PIECE(k_, buf_, cc_, live_)                                                                            \
   do {                                                                                                               \
@@ -399,9 +397,9 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
   conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n0 + nloc, 0);
 }
 
-template <class Tr, int BN, int WN, int SB, int EXP = 0, int TPS = 1>
+template <class Tr, int BN, int WN, int SB, int TPS = 1>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
-  conv3x3_patch_tile<Tr, BN, WN, SB, EXP, TPS>(pa, pa.c, blockIdx.x, gridDim.x);
+  conv3x3_patch_tile<Tr, BN, WN, SB, TPS>(pa, pa.c, blockIdx.x, gridDim.x);
 }
 
 // Two convolutions over the SAME input tensor geometry (channel slices of one map: the Cout = 20 / 40 heads of a scale read
@@ -410,8 +408,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(PatchArgs pa) {
 template <class Tr, int BN, int WN, int SB, int TPS>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_pair_kernel(PatchArgs pa, ConvArgs second, int first) {
   const int b = (int)blockIdx.x;
-  if (b < first) conv3x3_patch_tile<Tr, BN, WN, SB, 0, TPS>(pa, pa.c, (unsigned)b, (unsigned)first);
-  else conv3x3_patch_tile<Tr, BN, WN, SB, 0, TPS>(pa, second, (unsigned)(b - first), gridDim.x - (unsigned)first);
+  if (b < first) conv3x3_patch_tile<Tr, BN, WN, SB, TPS>(pa, pa.c, (unsigned)b, (unsigned)first);
+  else conv3x3_patch_tile<Tr, BN, WN, SB, TPS>(pa, second, (unsigned)(b - first), gridDim.x - (unsigned)first);
 }
 
 template <class Tr, int BN, int WN, int SB, int TPS>
@@ -424,12 +422,12 @@ int launch_patch_pair_t(const PatchArgs& a, const ConvArgs& second, int first, i
   return RON_OK;
 }
 
-template <class Tr, int BN, int WN, int SB, int EXP = 0, int TPS = 1>
+template <class Tr, int BN, int WN, int SB, int TPS = 1>
 int launch_patch_t(const PatchArgs& a, int grid, hipStream_t s) {
   const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * TPS * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
   static PerDeviceOnce once;
-  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN, SB, EXP, TPS>), (int)lds));
-  hipLaunchKernelGGL((conv3x3_patch_kernel<Tr, BN, WN, SB, EXP, TPS>), dim3(grid), dim3(512), lds, s, a);
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN, SB, TPS>), (int)lds));
+  hipLaunchKernelGGL((conv3x3_patch_kernel<Tr, BN, WN, SB, TPS>), dim3(grid), dim3(512), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -464,7 +462,7 @@ bool conv_patch_applicable(const ConvLaunch& c) {
          patch_geom(c.in.N, c.in.H, c.in.W, c.in.pad, c.pool != 0, &g);
 }
 
-static int patch_bn(int cfg) { return cfg == kCfgPatch64 ? 64 : ((cfg == kCfgPatch128 || cfg == kExpPatch128S4) ? 128 : 256); }
+static int patch_bn(int cfg) { return cfg == kCfgPatch64 ? 64 : (cfg == kCfgPatch128 ? 128 : 256); }
 
 // Where the patch kernel is the better choice (tools/sweep_conv.py on MI355X, profiles/r02/sweep_conv_exp_v*.txt): the skinny
 // heads (Cout <= 64: objectness_score, loc_pred) once the grid fills the chip.  There the row-gather kernel is bound by
@@ -482,7 +480,7 @@ int conv_patch_pick(const ConvLaunch& c) {
 // Kernel arguments of launch `c` with N tile BN; *grid = its workgroups.
 static int patch_args(const ConvLaunch& c, int cfg, PatchArgs* out, int* grid) {
   RON_REQUIRE(conv_patch_applicable(c), "patch kernel: not a 3x3 / stride 1 / pad 1 conv on a map it can tile");
-  RON_REQUIRE(conv_cfg_is_patch(cfg) && cfg < kNumCfgsBuilt, "patch kernel: bad tile config %d", cfg);
+  RON_REQUIRE(conv_cfg_is_patch(cfg) && cfg < kNumCfgs, "patch kernel: bad tile config %d", cfg);
   RON_REQUIRE(c.out2.base == nullptr, "patch kernel: no second (un-pooled) output");
   const int BN = patch_bn(cfg);
   RON_REQUIRE(c.Npad % BN == 0, "patch kernel: Npad %d not a multiple of the N tile %d", c.Npad, BN);
@@ -545,27 +543,16 @@ int launch_conv_patch(const ConvLaunch& c, int cfg, hipStream_t stream) {
   const int rc0 = patch_args(c, cfg, &a, &grid);
   if (rc0) return rc0;
   const int BN = patch_bn(cfg);
-#ifdef RON_EXP
-#define RON_PATCH_EXP(Tr)                                                                            \
-    if (cfg == kExpPatch128S4) return launch_patch_t<Tr, 128, 2, 4>(a, grid, stream);                \
-    if (cfg == kExpPatch256NoA) return launch_patch_t<Tr, 256, 2, 2, 1>(a, grid, stream);            \
-    if (cfg == kExpPatch256NoB) return launch_patch_t<Tr, 256, 2, 2, 2>(a, grid, stream);            \
-    if (cfg == kExpPatch256NoAB) return launch_patch_t<Tr, 256, 2, 2, 3>(a, grid, stream);
-#else
-#define RON_PATCH_EXP(Tr)
-#endif
 #define RON_PATCH_DISPATCH(Tr)                                                      \
   do {                                                                              \
-    RON_PATCH_EXP(Tr)                                                               \
     if (BN == 256) return launch_patch_t<Tr, 256, 2, 2>(a, grid, stream);           \
     if (BN == 128) return launch_patch_t<Tr, 128, 2, 3>(a, grid, stream);           \
-    return launch_patch_t<Tr, 64, 2, 2, 0, 3>(a, grid, stream);                     \
+    return launch_patch_t<Tr, 64, 2, 2, 3>(a, grid, stream);                        \
   } while (0)
   if (c.dtype == RON_DTYPE_BF16) RON_PATCH_DISPATCH(TraitsBF16S);
   if (c.dtype == RON_DTYPE_F16) RON_PATCH_DISPATCH(TraitsF16S);
   RON_PATCH_DISPATCH(TraitsF32S);
 #undef RON_PATCH_DISPATCH
-#undef RON_PATCH_EXP
 }
 
 }  // namespace ron

@@ -49,6 +49,12 @@ template <> struct IO<SplitF16> {
   static constexpr int V = 8;
   static constexpr int kEsz = 4;
   static __device__ __forceinline__ long long hidx(long long off) { return ((off >> 5) << 6) + (off & 31); }
+  // saturating split, the same rule as conv_device.h::split_f16 (values beyond the f16 range clip instead of turning into inf - inf)
+  static __device__ __forceinline__ float sat(float v) { return v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v); }
+  static __device__ __forceinline__ void split(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)sat(v);
+    lo = (_Float16)sat(v - (float)hi);
+  }
   static __device__ __forceinline__ void load(const void* base, long long off, float* f) {
     const _Float16* h = reinterpret_cast<const _Float16*>(base) + hidx(off);
     const Vec<_Float16, 8> hi = *reinterpret_cast<const Vec<_Float16, 8>*>(h), lo = *reinterpret_cast<const Vec<_Float16, 8>*>(h + 32);
@@ -59,8 +65,7 @@ template <> struct IO<SplitF16> {
     Vec<_Float16, 8> hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      hi.v[e] = (_Float16)f[e];
-      lo.v[e] = (_Float16)(f[e] - (float)hi.v[e]);
+      split(f[e], hi.v[e], lo.v[e]);
     }
     _Float16* h = reinterpret_cast<_Float16*>(base) + hidx(off);
     *reinterpret_cast<Vec<_Float16, 8>*>(h) = hi;
@@ -72,9 +77,10 @@ template <> struct IO<SplitF16> {
   }
   static __device__ __forceinline__ void store1(void* base, long long off, float f) {
     _Float16* h = reinterpret_cast<_Float16*>(base) + hidx(off);
-    const _Float16 hi = (_Float16)f;
+    _Float16 hi, lo;
+    split(f, hi, lo);
     h[0] = hi;
-    h[32] = (_Float16)(f - (float)hi);
+    h[32] = lo;
   }
 };
 

@@ -446,9 +446,6 @@ int make_anchors_ssd(ron_ctx* c) {
 // members write disjoint tensors / channel slices.
 void plan_groups(ron_ctx* c) {
   if (c->cfg.flags & (RON_CFG_MULTI_STREAM | RON_CFG_NO_GROUPS)) return;
-#ifdef RON_DIAG      // libron_hip_diag.so holds the round-1 kernels: one launch per convolution
-  return;
-#endif
   struct Slot { int cfg; std::vector<const char*> names; };     // cfg < 0: launches of their own
   const int T64 = kCfgIgemm128x64, T128 = kCfgIgemm128;     // tiny convolutions / medium ones (Npad % 128 == 0)
   // SSD-512 (nets/ssd_vgg_512.py:395-458): blocks 8-12 are a chain of 1x1 -> 3x3 stride-2 convolutions on 16x16 ... 1x1 maps,

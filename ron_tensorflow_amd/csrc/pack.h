@@ -81,10 +81,6 @@ static inline std::vector<uint8_t> block_rows(const std::vector<uint8_t>& rows, 
 // accumulator by (1, or 2^-k in split-precision mode where the packed weights are w * 2^k).
 static inline std::vector<uint8_t> pack_conv_weights(const std::vector<float>& rows, int npad, int dtype, float* oscale) {
   *oscale = 1.f;
-#ifdef RON_DIAG      // libron_hip_diag.so: the round-1 kernels of csrc/diag read row-major weights
-  (void)npad;
-  return cast_rows(rows, dtype);
-#else
   const int64_t K = (int64_t)(rows.size() / (size_t)npad);
   if (dtype == RON_DTYPE_F16X3) {
     const int k = split_weight_exponent(rows);
@@ -92,7 +88,6 @@ static inline std::vector<uint8_t> pack_conv_weights(const std::vector<float>& r
     return block_rows(split_rows(rows, k), npad, K * 4);
   }
   return block_rows(cast_rows(rows, dtype), npad, K * (int64_t)dtype_size(dtype));
-#endif
 }
 
 // HWIO [kh,kw,cin,cout] -> rows[n][(ky*kw+kx)*cin + c], n < npad (extra rows zero)

@@ -12,12 +12,15 @@ import torch
 
 from . import ops
 
+from . import _HIP_UP_AT_IMPORT, _HW_QUEUES_PRESET      # state when the package was imported
+
 
 def _check_hw_queues(streams_needed):
     """One hardware queue per stream: slots + a consumer + RCCL's stream + the default stream are more than the HIP runtime's
     default of 4, and streams that share a queue serialise behind each other (measured: -1.8 % images/s).  The runtime reads
-    GPU_MAX_HW_QUEUES when it initialises, so a library cannot set it reliably: the APPLICATION exports it before its first
-    HIP call (bench.py does).  Here it is only checked."""
+    GPU_MAX_HW_QUEUES when it initialises: the package sets it to 8 at import (ron_tensorflow_amd/__init__.py) unless the
+    application exported a value of its own.  That cannot help when HIP was already initialised by then (e.g. torch.cuda used before
+    the import, or a profiler's preloaded library): the import time state is recorded below and the case is reported here."""
     try:
         have = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
     except ValueError:
@@ -26,6 +29,10 @@ def _check_hw_queues(streams_needed):
         warnings.warn('DetectPipeline: %d streams in use but GPU_MAX_HW_QUEUES=%s: streams will share hardware queues and serialise; '
                       'export GPU_MAX_HW_QUEUES=8 before the first HIP call' % (streams_needed, os.environ.get('GPU_MAX_HW_QUEUES', 'unset (4)')),
                       RuntimeWarning, stacklevel=3)
+    elif _HIP_UP_AT_IMPORT and not _HW_QUEUES_PRESET:
+        warnings.warn('DetectPipeline: HIP was initialised before ron_tensorflow_amd was imported and GPU_MAX_HW_QUEUES was not exported by '
+                      'then: the runtime keeps its default of 4 hardware queues for %d streams; export GPU_MAX_HW_QUEUES=8 before the '
+                      'first HIP call' % streams_needed, RuntimeWarning, stacklevel=3)
 
 
 class Ticket(object):
@@ -64,7 +71,10 @@ class DetectPipeline(object):
     ``submit(images)`` returns a Ticket; the detections it carries live in one of the slot's ``buffers_per_slot``
     output sets (allocated once for ``net.max_batch`` images; smaller batches get leading views) and stay valid for the
     next ``slots * buffers_per_slot - 1`` submissions, so a consumer (host copy, RCCL gather) can run on its own stream
-    without holding the slot's next batch back.  Reuse is safe by construction, see Ticket."""
+    without holding the slot's next batch back.  Reuse is safe by construction, see Ticket.
+
+    Needs one hardware queue per stream: GPU_MAX_HW_QUEUES >= slots + 3, read by the HIP runtime when it initialises (the package
+    sets 8 at import; an application that touches the GPU before importing it exports the variable itself)."""
 
     def __init__(self, net, slots=2, top_k=400, buffers_per_slot=2):
         assert slots >= 1 and buffers_per_slot >= 1

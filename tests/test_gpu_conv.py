@@ -385,6 +385,35 @@ def test_split_precision_is_fp32_grade(ops, dev, scale):
     assert errs['f16x3'] <= 0.1 * errs['fp16'], errs
 
 
+@pytest.mark.parametrize('exp', [-12, 14, 18])
+def test_split_precision_outside_its_22_bit_range(ops, dev, exp):
+    """The documented limits of dtype f16x3 (include/ron_hip.h, "VALID ACTIVATION RANGE") against float64, on inputs scaled by 2^exp:
+    2^-12: every lo plane is an f16 subnormal -> absolute floor 2^-25 per stored value: the error is bounded by the floor summed
+           over the K products (in quadrature: it is a rounding error), far better than f16 whose hi plane is itself subnormal there;
+    2^+14: N(0,1) * 16384 -- a few inputs exceed 65504: they saturate (hi = 65504, lo = the rest) instead of becoming inf - inf = NaN,
+           and the result stays fp32-grade;
+    2^+18: everything beyond 131008 clips: wrong by the clipping, but finite (no NaN / inf reaches the next layer)."""
+    rs = np.random.RandomState(13)
+    scale = 2.0 ** exp
+    x = (rs.randn(2, 12, 12, 64) * scale).astype(np.float32)
+    wt = (rs.randn(3, 3, 64, 64) * np.sqrt(2.0 / 576) * (2.0 ** -4 if exp > 0 else 1.0)).astype(np.float32)    # outputs stay < 65504 at 2^14
+    ref = orf.conv2d_np(x.astype(np.float64), wt.astype(np.float64))
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, None, relu=False, dtype='f16x3').cpu().numpy()
+    assert np.isfinite(got).all(), 'a value outside the f16 range turned into inf / NaN'
+    err = float(np.abs(got - ref).max() / np.abs(ref).max())
+    print('f16x3 at input scale 2^%d: max err / output scale %.3g' % (exp, err))
+    if exp == -12:
+        floor = 2.0 ** -25 * np.sqrt(576) * float(np.abs(wt).max()) * 4     # per-value floor x sqrt(K) x |w|, with margin
+        assert np.abs(got - ref).max() <= floor + 4e-6 * np.abs(ref).max(), err
+        f16 = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, None, relu=False, dtype='fp16').cpu().numpy()
+        assert err <= 0.25 * float(np.abs(f16 - ref).max() / np.abs(ref).max())
+    elif exp == 14:
+        assert (np.abs(x) > 65504).sum() > 0 and np.abs(x).max() < 131008
+        assert err <= 2e-5, err           # the few saturated inputs keep 12 bits of their rest, the others 22
+    else:
+        assert np.abs(got).max() <= 9 * 64 * 131008 * float(np.abs(wt).max())   # clipped inputs bound the output
+
+
 def test_split_precision_weight_scale_is_exact(ops, dev):
     """Weights far below / above 1 (the per-layer power-of-two scale brings them to [2^14, 2^15) and the epilogue undoes it): same
     relative error as at unit scale.  The activations are scaled the other way so that input and output stay inside what an

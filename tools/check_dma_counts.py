@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
-"""Static check of the halo-patch kernel's counted-wait protocol (csrc/conv_patch.hip) in the ISA hipcc actually emits.
+"""Static check of the counted-wait protocols of the conv kernels in the ISA hipcc actually emits (no GPU needed).
 
-The kernel's K loop waits with `s_waitcnt vmcnt(N)` for "everything but the newest N LDS-DMA instructions"; that is only right if
-every step issues exactly the group the source describes (3 B_IT + 3 instructions in the row-step form, B_IT + 1 in the one-tap
-form).  Round 3 found the compiler merging identical placeholder instructions of the PROLOGUE (dead stores to it), which left
-the first step's wait two short and showed as run-to-run differences; the prologue now waits for everything (vmcnt(0)) and
-counts nothing, but the loop still relies on its placeholder pieces (run-time destinations: not mergeable today) being emitted one
-for one.  This tool compiles conv_patch.hip to assembly (about a minute, no GPU needed) and checks,
-for every instantiation: LDS-DMA instructions per loop iteration == the group size, and the loop's vmcnt immediate ==
-(SB - 2) * group + pieces-behind-the-weights.  Run it after touching conv_patch.hip or changing ROCm:
+Both LDS-DMA kernels wait with `s_waitcnt vmcnt(N)` for "everything but the newest N LDS-DMA instructions"; that is only right if
+every K step -- and the prologue -- issues exactly the group of instructions the source describes:
+
+  conv_mfma.hip   conv_igemm_kernel / conv_igemm_group_kernel <Tr, BM, BN, WM, WN, S, SPREAD[, TI]>:
+                  LPT = (BM + BN) / (WM * WN * 8) instructions per step (zero-record placeholder descriptors past the last tile
+                  included), (S - 1) * LPT in the prologue, loop wait vmcnt((S - 2) * LPT);
+  conv_patch.hip  conv3x3_patch_kernel / conv3x3_patch_pair_kernel <Tr, BN, WN, SB, TPS>: 3 * B_IT + 3 instructions per step in the
+                  row-step form (TPS = 3), B_IT + 1 in the one-tap form, loop wait vmcnt((SB - 2) * group + pieces behind the
+                  weights); the prologue is waited for as a whole (vmcnt(0)).
+
+Round 3 found the compiler merging identical placeholder instructions of the patch kernel's prologue (dead stores to it), which
+left the first step's wait two short and showed only as run-to-run differences.  This tool compiles the two files to assembly
+(about a minute) and checks every instantiation; tests/test_isa_protocol.py runs it in the CPU suite, so a ROCm bump that changes
+the emitted counts fails a test, not a soak run.
     python tools/check_dma_counts.py"""
 import os
 import re
@@ -18,13 +24,25 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'ron_tensorflow_amd', 'csrc')
+DMA = re.compile(r'buffer_load_dword\w* .*\blds\b')
+KERNEL = re.compile(r'^(_ZN3ron6detail\d+(?:conv3x3_patch\w*kernel|conv_igemm\w*kernel)\w+):')
+
+
+def compile_asm(source):
+    """Device-only assembly of ron_tensorflow_amd/csrc/<source> with the flags of the Makefile."""
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 'k.s')
+        cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-I.', '--cuda-device-only', '-S', '-o', out, source]
+        subprocess.run(cmd, cwd=CSRC, check=True, stderr=subprocess.DEVNULL)
+        with open(out) as f:
+            return f.read()
 
 
 def kernels(asm):
-    """{mangled name: [lines]} of every conv3x3_patch kernel in the assembly text."""
+    """{mangled name: [lines]} of every conv kernel in the assembly text."""
     out, name = {}, None
     for line in asm.splitlines():
-        m = re.match(r'^(_ZN3ron6detail\d+conv3x3_patch\w*kernel\w+):', line)
+        m = KERNEL.match(line)
         if m:
             name = m.group(1)
             out[name] = []
@@ -35,31 +53,45 @@ def kernels(asm):
     return out
 
 
-def check(name, lines):
-    ints = [int(x) for x in re.findall(r'ELi(\d+)', name)]
-    pair = 'pair_kernel' in name
-    bn, wn, sb = ints[0], ints[1], ints[2]
-    tps = ints[3] if pair else ints[4]
-    b_it = bn // 64
-    group = 3 * b_it + 3 if tps == 3 else b_it + 1
-    behind = 3 if tps == 3 else 1
+def loops(lines):
+    """[(index of the K loop's counted wait, its vmcnt immediate, LDS-DMA instructions in the loop body, LDS-DMA instructions between
+    the previous loop (or the kernel's start) and this wait)]: a K loop = `s_waitcnt vmcnt(N) lgkmcnt(0)` directly followed by
+    s_barrier, up to the branch back to a label at or above it."""
     labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r'^(\.LBB\d+_\d+):', l)] if m}
     tops = [i for i, l in enumerate(lines) if re.search(r's_waitcnt vmcnt\(\d+\) lgkmcnt\(0\)', l)
             and any('s_barrier' in x for x in lines[i + 1:i + 3])]
-    problems = []
-    if not tops:
-        return ['no K-loop wait found']
-    for top in tops:                      # a pair kernel holds the loop twice (one tile function per convolution)
+    out, prev_end = [], 0
+    for top in tops:
         n = int(re.search(r'vmcnt\((\d+)\)', lines[top]).group(1))
         count, end = 0, None
         for i in range(top + 1, len(lines)):
-            if re.search(r'buffer_load_dword\w* .* lds', lines[i]):
+            if DMA.search(lines[i]):
                 count += 1
             m = re.search(r's_c?branch\w*\s+(\.LBB\d+_\d+)', lines[i])
             if m and labels.get(m.group(1), 1 << 30) <= top:
                 end = i
                 break
-        if end is None:
+        before = sum(1 for l in lines[prev_end:top] if DMA.search(l))
+        out.append((top, n, count if end is not None else None, before))
+        prev_end = end if end is not None else top
+    return out
+
+
+def template_ints(name):
+    return [int(x) for x in re.findall(r'ELi(\d+)', name)]
+
+
+def check_patch(name, lines):
+    bn, wn, sb, tps = template_ints(name)[:4]
+    b_it = bn // 64
+    group = 3 * b_it + 3 if tps == 3 else b_it + 1
+    behind = 3 if tps == 3 else 1
+    problems = []
+    found = loops(lines)
+    if not found:
+        return ['no K-loop wait found']
+    for top, n, count, _ in found:          # a pair kernel holds the loop twice (one tile function per convolution)
+        if count is None:
             problems.append('loop end not found after line %d' % top)
             continue
         if count != group:
@@ -69,22 +101,59 @@ def check(name, lines):
     return problems
 
 
-def main():
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, 'conv_patch.s')
-        cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-I.', '--cuda-device-only', '-S', '-o', out, 'conv_patch.hip']
-        subprocess.run(cmd, cwd=CSRC, check=True, stderr=subprocess.DEVNULL)
-        asm = open(out).read()
-    ks = kernels(asm)
-    bad = 0
+def check_igemm(name, lines):
+    bm, bn, wm, wn, s, spread = template_ints(name)[:6]
+    lpt = (bm + bn) // (wm * wn * 8)
+    problems = []
+    found = loops(lines)
+    if len(found) != 1:
+        return ['%d K loops found, expected 1' % len(found)]
+    top, n, count, before = found[0]
+    if count is None:
+        return ['loop end not found after line %d' % top]
+    if count != lpt:
+        problems.append('%d LDS-DMA instructions per K step, the protocol counts LPT = %d' % (count, lpt))
+    if n != (s - 2) * lpt:
+        problems.append('vmcnt(%d), expected (S - 2) * LPT = %d' % (n, (s - 2) * lpt))
+    if before != (s - 1) * lpt:
+        problems.append('%d LDS-DMA instructions in the prologue, the first wait assumes (S - 1) * LPT = %d' % (before, (s - 1) * lpt))
+    total = sum(1 for l in lines if DMA.search(l))
+    if total != before + count:
+        problems.append('%d LDS-DMA instructions outside the prologue and the K loop' % (total - before - count))
+    return problems
+
+
+def describe(name):
+    tr = re.search(r'Traits(\w+?)SE', name).group(1)
+    kind = re.search(r'\d+(conv\w+?kernel)I', name).group(1)
+    extra = ', TI' if 'ELb1E' in name else ''
+    return '%-5s %-26s <%s%s>' % (tr, kind, ', '.join(str(i) for i in template_ints(name)), extra)
+
+
+def check_file(source):
+    """[(description, [problems])] for every conv kernel instantiation of csrc/<source>."""
+    ks = kernels(compile_asm(source))
+    out = []
     for name, lines in sorted(ks.items()):
-        problems = check(name, lines)
-        ints = re.findall(r'ELi(\d+)', name)
-        tr = re.search(r'Traits(\w+?)SE', name).group(1)
-        print('%-5s %-28s <%s>: %s' % (tr, 'patch_pair_kernel' if 'pair' in name else 'patch_kernel', ', '.join(ints), 'ok' if not problems else '; '.join(problems)))
-        bad += len(problems)
-    print('%d kernels checked' % len(ks))
-    sys.exit(1 if bad or not ks else 0)
+        fn = check_patch if 'conv3x3_patch' in name else check_igemm
+        out.append((describe(name), fn(name, lines)))
+    return out
+
+
+# instantiations the Makefile's build holds (dtypes x tile forms); a different count means the check no longer sees all of them
+EXPECTED = {'conv_patch.hip': 3 * (3 + 3), 'conv_mfma.hip': 4 * (6 + 2)}
+
+
+def main():
+    bad = 0
+    for source in ('conv_patch.hip', 'conv_mfma.hip'):
+        res = check_file(source)
+        for desc, problems in res:
+            print('%s: %s' % (desc, 'ok' if not problems else '; '.join(problems)))
+            bad += len(problems)
+        print('%s: %d kernels checked (expected %d)' % (source, len(res), EXPECTED[source]))
+        bad += len(res) != EXPECTED[source]
+    sys.exit(1 if bad else 0)
 
 
 if __name__ == '__main__':

@@ -6,7 +6,8 @@ set -u
 export TMPDIR=/tmp
 OUT=$1; shift
 mkdir -p $OUT
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 "$@" > $OUT/pmc_mfma.log 2>&1
+rm -rf $OUT/pmc_mfma          # one run per call: never add another call's dispatches (see pmc_bench.sh)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --in-flight 1 "$@" > $OUT/pmc_mfma.log 2>&1
 python3 - "$OUT" "$@" <<'PY'
 import collections, csv, glob, json, os, sys
 out = sys.argv[1]
@@ -32,7 +33,7 @@ def frac(d):
     # the 8 XCDs (guide: effective clock = GRBM_GUI_ACTIVE / 8 / wall time) -> elapsed cycles of the dispatches = GRBM_GUI_ACTIVE / 8
     el = d.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
     return d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (SIMDS * el) if el > 0 else None
-res = {'command': 'bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 ' + ' '.join(args), 'commit': os.environ.get('RON_COMMIT'),
+res = {'command': 'bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --in-flight 1 ' + ' '.join(args), 'commit': os.environ.get('RON_COMMIT'),
        'formula': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), all dispatches of the run (7 steps) summed',
        'whole_run': {'counters': dict(tot), 'mfma_busy_fraction': frac(tot)},
        'per_kernel': {k: {'dispatches': n[k], 'mfma_busy_fraction': frac(per[k]), 'counters': dict(per[k])} for k in sorted(per)}}

@@ -6,17 +6,17 @@ export TMPDIR=/tmp
 O=gpurun_out/final
 mkdir -p $O
 python3 bench.py --layers $O/layers_cfg2_inflight2.txt > $O/bench_cfg2_default.json 2> $O/bench_cfg2_default.err
-python3 bench.py --no-cpu-baseline --in-flight 1 --layers $O/layers_cfg2_inflight1.txt > $O/bench_cfg2_inflight1.json 2>> $O/err.txt
+python3 bench.py --no-cpu-baseline --no-parity-mode --in-flight 1 --layers $O/layers_cfg2_inflight1.txt > $O/bench_cfg2_inflight1.json 2>> $O/err.txt
 # the modes that meet north_star's 1e-4 clause: split precision (three f16 MFMAs per product) and exact-fp32 MFMA; both lines carry
 # <dtype>_vs_fp32_oracle_agreement (cpu_baseline leg on)
 python3 bench.py --dtype f16x3 --layers $O/layers_cfg2_f16x3.txt > $O/bench_cfg2_f16x3.json 2>> $O/err.txt
-python3 bench.py --dtype f16x3 --no-cpu-baseline --in-flight 1 > $O/bench_cfg2_f16x3_inflight1.json 2>> $O/err.txt
+python3 bench.py --dtype f16x3 --no-cpu-baseline --no-parity-mode --in-flight 1 > $O/bench_cfg2_f16x3_inflight1.json 2>> $O/err.txt
 python3 bench.py --dtype fp32 --steps 10 --warmup 3 --layers $O/layers_cfg2_fp32.txt > $O/bench_cfg2_fp32.json 2>> $O/err.txt
-python3 bench.py --no-cpu-baseline --variant reducedfc --dtype fp16 --batch 64 --layers $O/layers_cfg4.txt > $O/bench_cfg4.json 2>> $O/err.txt
-python3 bench.py --no-cpu-baseline --variant ssd512 --batch 16 --layers $O/layers_cfg5.txt > $O/bench_cfg5.json 2>> $O/err.txt
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --no-cpu-baseline --check-gather > $O/bench_cfg2_torchrun_1rank.json 2>> $O/err.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg2_under_rocprof_inflight2.json 2>> $O/err.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --in-flight 1 > $O/bench_cfg2_under_rocprof_inflight1.json 2>> $O/err.txt
+python3 bench.py --no-cpu-baseline --no-parity-mode --variant reducedfc --dtype fp16 --batch 64 --layers $O/layers_cfg4.txt > $O/bench_cfg4.json 2>> $O/err.txt
+python3 bench.py --no-cpu-baseline --no-parity-mode --variant ssd512 --batch 16 --layers $O/layers_cfg5.txt > $O/bench_cfg5.json 2>> $O/err.txt
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --no-cpu-baseline --no-parity-mode --check-gather > $O/bench_cfg2_torchrun_1rank.json 2>> $O/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode > $O/bench_cfg2_under_rocprof_inflight2.json 2>> $O/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --in-flight 1 > $O/bench_cfg2_under_rocprof_inflight1.json 2>> $O/err.txt
 for d in if1 if2; do f=$(ls $O/prof_$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$d.csv; done
 bash tools/pmc_bench.sh $O/pmc --in-flight 1 > $O/pmc.log 2>&1
 cp $O/pmc/traffic_*.json $O/ 2>/dev/null
@@ -32,8 +32,8 @@ echo "# --head-plan batch" >> $O/batch_sweep.txt
 BATCHES="1 2 4 8" EXTRA="--head-plan batch" bash tools/batch_sweep.sh >> $O/batch_sweep.txt 2>> $O/err.txt
 echo "# --head-plan level" >> $O/batch_sweep.txt
 BATCHES="1 2 4 8" EXTRA="--head-plan level" bash tools/batch_sweep.sh >> $O/batch_sweep.txt 2>> $O/err.txt
-python3 bench.py --no-cpu-baseline --batch 1 --in-flight 1 --steps 200 --warmup 20 --layers $O/layers_cfg2_batch1.txt > $O/bench_cfg2_batch1.json 2>> $O/err.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --in-flight 1 --batch 1 > $O/bench_cfg2_batch1_under_rocprof.json 2>> $O/err.txt
+python3 bench.py --no-cpu-baseline --no-parity-mode --batch 1 --in-flight 1 --steps 200 --warmup 20 --layers $O/layers_cfg2_batch1.txt > $O/bench_cfg2_batch1.json 2>> $O/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity-mode --in-flight 1 --batch 1 > $O/bench_cfg2_batch1_under_rocprof.json 2>> $O/err.txt
 f=$(ls $O/prof_b1/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_batch1.csv
 rm -rf $O/prof_b1
 rm -rf $O/prof_if1 $O/prof_if2 $O/pmc/pmc_fetch $O/pmc/pmc_write $O/pmc/pmc_mfma

@@ -3,20 +3,16 @@
 
   python tools/sweep_conv.py [--dtype bf16] [--batch 32] [--cfgs 0,2,4] [--only name-substring]
 Prints us and TFLOP/s per (layer, cfg); used to choose conv_pick_cfg() / conv_patch_pick() (csrc/conv_mfma.hip, conv_patch.hip).
-Configurations: csrc/conv_mfma.h kCfg* (0-3, 7, 9 row-gather tiles, 4-6 halo-patch N tiles, 8 resident-weight 3x3 on 64 channels; 10+ with --exp); n/a = does not cover that layer."""
+Configurations: csrc/conv_mfma.h kCfg* (0-3, 7, 9 row-gather tiles, 4-6 halo-patch N tiles, 8 resident-weight 3x3 on 64 channels); n/a = does not
+cover that layer.  RON_HIP_LIB=<path> points the package at another build of the same ABI (an experiment build, tools/experiments/README.md)."""
 import argparse
 import ctypes as C
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-# --exp / --diag: the experimental (make EXP=1) or the round-1 diagnostic (make DIAG=1) build of the library
 if '--zeros' in sys.argv:       # all-zero operands: the clock-limited share of a kernel's time (csrc/ops.cpp, ron_conv2d_bench)
     sys.argv.remove('--zeros')
     os.environ['RON_BENCH_ZERO'] = '1'
-for flag, so in (('--exp', 'libron_hip_exp.so'), ('--diag', 'libron_hip_diag.so')):
-    if flag in sys.argv:
-        sys.argv.remove(flag)
-        os.environ['RON_HIP_LIB'] = os.path.join(ROOT, 'tools', 'experiments', so)
 from ron_tensorflow_amd import _lib
 
 # name, h, w, cin, cout, k, stride, rate, transpose
