@@ -184,15 +184,19 @@ struct TraitsF32S : TraitsF32 {
 // 16 x 16 x 32 block into one fp32 accumulator.  hi*hi is exact in the matrix core (11 x 11 bits), the dropped lo*lo term is
 // 2^-22 of the product.  Element index i of a tensor -> f16 index (i / 32) * 64 + i % 32 (+ 32 for the lo plane): pixel
 // strides and channel slices are multiples of 32 elements everywhere.
-// One value -> its two f16 planes.  Both conversions SATURATE at the largest finite f16 (65504) instead of overflowing to inf:
-// hi = +inf, lo = -inf would read back as NaN and poison every later layer; saturated, |v| up to 131008 is still representable
-// (hi = 65504, lo = the rest, with the f16 spacing of 32 up there) and larger values clip.  NaN stays NaN.  Accuracy contract
+// One value -> its two f16 planes.  Kernels that store split values run with MODE.FP16_OVFL set (split_mode_on() at their start):
+// an fp32 -> f16 conversion that overflows then SATURATES at the largest finite f16 (65504) instead of producing inf, at no cost per
+// value (clamping in VALU instructions made the store-bound conv1_x epilogues 11-19 % slower).  Without it hi = +inf, lo = -inf
+// would read back as NaN and poison every later layer; saturated, |v| up to 131008 is still representable (hi = 65504, lo = the
+// rest, with the f16 spacing of 32 up there) and larger values clip.  True infinities and NaN stay what they are.  Accuracy contract
 // (include/ron_hip.h, RON_DTYPE_F16X3): 22 mantissa bits for 2^-3 <= |v| < 65504; below, lo is an f16 subnormal (not flushed by
 // the matrix core), i.e. an ABSOLUTE error floor of 2^-25 per stored value.
-static __device__ __forceinline__ float sat_f16(float v) { return v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v); }
+static __device__ __forceinline__ void split_mode_on() {
+  __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);      // hwreg(HW_REG_MODE, offset 23, size 1) = FP16_OVFL
+}
 static __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)sat_f16(v);
-  lo = (_Float16)sat_f16(v - (float)hi);
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
 }
 struct TraitsF16X3S {
   typedef f32x4 acc_t;

@@ -94,10 +94,15 @@ int conv_num_cfgs();
 int conv_pick_cfg(const ConvLaunch& c);
 int conv_pick_splitk(int tiles, int KT, int slots);
 int64_t conv_scratch_bytes(const ConvLaunch& c);   // fp32 split-K slabs this launch can ask for (0: none)
-// Several mutually independent convolutions as ONE launch of the row-gather kernel (tile kCfgIgemm128x64 or kCfgIgemm128)
-int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64_t scratch_bytes, hipStream_t stream);
+// Several mutually independent convolutions as ONE launch of the row-gather kernel (tile kCfgIgemm128x64, kCfgIgemm128 or kGroupMixed)
+// sk_plan: the members' split-K factors from conv_group_plan (depends on the members' geometry and the batch only: callers cache it;
+// the mixed-width form models the launch's schedule, ~1 ms of host time), or null to compute them here
+int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64_t scratch_bytes, hipStream_t stream, const int* sk_plan = nullptr);
+void conv_group_plan(const ConvLaunch* ls, int n, int cfg, int* sk);
 int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg);
 constexpr int kMaxConvGroup = 8;
+// launch_conv_group only: every member on the 128-row tile of its own width (128 x 128 when Npad % 128 == 0, else 128 x 64)
+constexpr int kGroupMixed = 64;
 size_t dtype_size(int dtype);
 inline bool dtype_is_half(int dtype) { return dtype == RON_DTYPE_BF16 || dtype == RON_DTYPE_F16; }   // 2-byte elements
 

@@ -87,6 +87,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
+  if constexpr (IsSplit<Tr>::value) split_mode_on();      // the epilogue's fp32 -> f16 conversions saturate (conv_device.h)
 
   // XCD-aware tile order: workgroups that share an XCD (blockIdx % 8) take consecutive tiles,
   // so the N-tiles that re-read one A tile hit the same L2.
@@ -209,11 +210,14 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   // coming back to them a whole sweep of the channels later: the re-reads hit L2 without another workgroup's help.  Worth
   // 1-6 % on layers with one or two column tiles (nobody else on the XCD stages the same input rows at the same time), nothing
   // or -1 % on the wide ones (profiles/r02/sweep_conv_exp_v4_tapsinner.txt); conv_pick_igemm_cfg selects it accordingly.
+  // A column tile that runs the centre tap only (ConvArgs::center_from_n) walks that tap's chunks in the tap-major numbering whatever
+  // the launch's order: its [kt0, kt1) is a contiguous range there.
+  const bool ti = TI && !center_only;
   const int n_taps = p.KT / chunks_per_tap;
-  const int tap0 = TI ? kt0 % n_taps : kt0 / chunks_per_tap;
+  const int tap0 = ti ? kt0 % n_taps : kt0 / chunks_per_tap;
   int ky = tap0 / p.kw, kx = tap0 - (tap0 / p.kw) * p.kw;
-  int cc = (TI ? kt0 / n_taps : kt0 - tap0 * chunks_per_tap) * kChunkElems;
-  int tb = TI ? kt0 % n_taps : 0, cb = TI ? kt0 / n_taps : 0;          // weight ring: tap / chunk of its next tile
+  int cc = (ti ? kt0 / n_taps : kt0 - tap0 * chunks_per_tap) * kChunkElems;
+  int tb = ti ? kt0 % n_taps : 0, cb = ti ? kt0 / n_taps : 0;          // weight ring: tap / chunk of its next tile
   // One K step issues LPT LDS-DMA pieces per thread: the B_IT weight pieces of tile kt+S-1 first, then its A_IT
   // activation pieces.  RON_STAGE_BEGIN computes the wave-uniform part once per step, RON_STAGE_PIECE issues piece j
   // (compile-time), RON_STAGE_END advances the tap of the activation ring.
@@ -225,7 +229,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
     const __amdgpu_buffer_rsrc_t rs_b =                                                                              \
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, ktb_ < kt1 ? p.wgt_bytes : 0u, 0x00020000);   \
     const int a_soff = ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz;                         \
-    const int b_soff = (TI ? tb * chunks_per_tap + cb : ktb_) * kWeightBlockBytes;                                   \
+    const int b_soff = (ti ? tb * chunks_per_tap + cb : ktb_) * kWeightBlockBytes;                                   \
     char* dst_a = s_a + ((ktb_ - kt0) % S) * kABytes + wave * 1024;                                                  \
     char* dst_b = s_b + ((ktb_ - kt0) % S) * kBBytes + wave * 1024;
 #define RON_STAGE_PIECE_B(i_)                                                                                        \
@@ -239,7 +243,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
     } while (0)
 #define RON_STAGE_END()                                                                                              \
     do {                                                                                                             \
-      if (TI) {                                                                                                      \
+      if (ti) {                                                                                                      \
         if (++kx == p.kw) { kx = 0; if (++ky * p.kw >= n_taps) { ky = 0; cc += kChunkElems; } }                       \
         if (++tb == n_taps) { tb = 0; ++cb; }                                                                        \
         break;                                                                                                       \
@@ -367,6 +371,7 @@ struct ConvGroupArgs {
   ConvArgs op[kMaxGroup];
   int first[kMaxGroup + 1];
   int n;
+  unsigned narrow;            // kGroupMixed: bit k set = member k runs on 128 x 64 tiles, else on 128 x 128
 };
 // op[k] of the ConvGroupArgs this kernel was launched with (its only argument), read from the kernel-argument segment
 __device__ __forceinline__ ConvArgs load_group_op(int k) {
@@ -381,7 +386,7 @@ __device__ __forceinline__ ConvArgs load_group_op(int k) {
 }
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_group_kernel(ConvGroupArgs g) {
+__global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S) > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_group_kernel(ConvGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = (int)blockIdx.x;
   int k = 0;
@@ -392,12 +397,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_group_kernel(ConvG
   conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD>(p, (unsigned)(b - g.first[k]), (unsigned)(g.first[k + 1] - g.first[k]), smem);
 }
 
+// The same with the tile WIDTH chosen per member (kGroupMixed): both 128-row tiles run on 4 waves and fit two workgroups per CU, so
+// skinny members (Npad = 64) and wide ones share a launch - a dependency level of the heads is then ONE launch whatever its mix.
+template <class Tr>
+__global__ __launch_bounds__(256, 2) void conv_igemm_group_mixed_kernel(ConvGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = (int)blockIdx.x;
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < kMaxGroup; ++j)
+    if (j < g.n && b >= g.first[j]) k = j;
+  const ConvArgs p = load_group_op(k);
+  const unsigned bid = (unsigned)(b - g.first[k]), nwg = (unsigned)(g.first[k + 1] - g.first[k]);
+  if ((g.narrow >> k) & 1u) conv_igemm_tile<Tr, 128, 64, 2, 2, 2, 2>(p, bid, nwg, smem);
+  else conv_igemm_tile<Tr, 128, 128, 2, 2, 2, 2>(p, bid, nwg, smem);
+}
+
 template <class Tr>
 __global__ void splitk_finalize_group_kernel(ConvGroupArgs g);
 
 // Adds the split-K slabs and applies the conv epilogue (bias, ReLU, relu(x + residual), dtype / fp32 store).
 template <class Tr>
 __device__ __forceinline__ void splitk_finalize_body(const ConvArgs& p) {
+  if constexpr (IsSplit<Tr>::value) split_mode_on();
   const int groups = p.Npad / 4;
   const long long total = (long long)p.M * groups;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -587,10 +609,10 @@ int conv_pick_cfg(const ConvLaunch& c) {
   const bool may_split = c.center_from == 0 && !c.pool && c.up == 0 && c.splitk < 0;      // (the same answer when the scratch is being sized)
   const int KT = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
   const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, c.kh * c.kw * c.in.C, may_split);
-  // taps innermost: not where a tap must be a contiguous K range (centre-tap-only columns), and only for the stride-1 convolutions
-  // it has been measured and tested on (the stride-2 3x3 convolutions of SSD-512's extra blocks keep the tap-major order)
-  if (cfg == kCfgIgemm256TapsInner && (c.center_from > 0 || c.stride != 1)) return kCfgIgemm256;
-  if (cfg == kCfgIgemm128Early && c.kh * c.kw > 1 && c.up == 0 && c.center_from == 0 && c.stride == 1) {
+  // taps innermost: only for the stride-1 convolutions it has been measured and tested on (the stride-2 3x3 convolutions of SSD-512's
+  // extra blocks keep the tap-major order).  Centre-tap-only column tiles of such a launch keep the tap-major walk of their one tap.
+  if (cfg == kCfgIgemm256TapsInner && c.stride != 1) return kCfgIgemm256;
+  if (cfg == kCfgIgemm128Early && c.kh * c.kw > 1 && c.up == 0 && c.stride == 1) {
     // taps innermost for the 128 x 128 tile too (consecutive steps re-read almost the same input lines): 3-6 % on launches that do
     // not split K (with split-K it loses: conv5_1 at batch 4 +10 %), and where no filter rows can be skipped instead
     const int tiles = ((M + 127) / 128) * (c.Npad / 128);
@@ -643,8 +665,8 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
   a.pos_major = pick_pos_major(c, cfg, BM);
   if (c.center_from > 0)
-    RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1) && !conv_cfg_taps_inner(cfg) && c.up == 0,
-                "conv: centre-tap-only columns need an odd filter, the tap-major K order and a boundary on the N tile (%d)", BN);
+    RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1) && c.up == 0,
+                "conv: centre-tap-only columns need an odd filter and a boundary on the N tile (%d)", BN);
   RON_REQUIRE((int64_t)c.Npad * K * esz == c.wgt_bytes, "conv: packed weight size mismatch");
   int rc;
   if (c.dtype == RON_DTYPE_BF16) rc = launch_cfg<TraitsBF16S>(cfg, a, stream);
@@ -662,27 +684,44 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
 // ---- grouped launches ---------------------------------------------------------------------------------------------
 namespace detail {
 
+template <class Tr>
+int launch_group_finalize(const ConvGroupArgs& g, hipStream_t s) {
+  long long most = 0;
+  for (int k = 0; k < g.n; ++k)
+    if (g.op[k].splitk > 1) most = std::max(most, (long long)g.op[k].M * (g.op[k].Npad / 4));
+  const int grid = (int)std::min<long long>((most + 255) / 256, 512);
+  hipLaunchKernelGGL(splitk_finalize_group_kernel<Tr>, dim3(grid, g.n), dim3(256), 0, s, g);
+  return RON_OK;
+}
+
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 int launch_group_t(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
   const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S);
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), (int)lds));
   hipLaunchKernelGGL((conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(g.first[g.n]), dim3(WM * WN * 64), lds, s, g);
-  if (any_split) {
-    long long most = 0;
-    for (int k = 0; k < g.n; ++k)
-      if (g.op[k].splitk > 1) most = std::max(most, (long long)g.op[k].M * (g.op[k].Npad / 4));
-    const int grid = (int)std::min<long long>((most + 255) / 256, 512);
-    hipLaunchKernelGGL(splitk_finalize_group_kernel<Tr>, dim3(grid, g.n), dim3(256), 0, s, g);
-  }
+  if (any_split) launch_group_finalize<Tr>(g, s);
+  RON_HIP_CHECK(hipGetLastError());
+  return RON_OK;
+}
+
+template <class Tr>
+int launch_group_mixed(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
+  const size_t lds = (size_t)igemm_lds_bytes(128, 128, 2);
+  static PerDeviceOnce once;
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_group_mixed_kernel<Tr>), (int)lds));
+  hipLaunchKernelGGL((conv_igemm_group_mixed_kernel<Tr>), dim3(g.first[g.n]), dim3(256), lds, s, g);
+  if (any_split) launch_group_finalize<Tr>(g, s);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
 
 template <class Tr>
 int launch_group_cfg(int cfg, const ConvGroupArgs& g, bool any_split, hipStream_t s) {
+  if (cfg == kGroupMixed) return launch_group_mixed<Tr>(g, any_split, s);
   if (cfg == kCfgIgemm128x64) return launch_group_t<Tr, 128, 64, 2, 2, 2, 2>(g, any_split, s);
   if (cfg == kCfgIgemm128) return launch_group_t<Tr, 128, 128, 2, 2, 2, 2>(g, any_split, s);      // pieces issued early, as kCfgIgemm128Early
+  if (cfg == kCfgIgemm256) return launch_group_t<Tr, 256, 256, 4, 2, 2, 1>(g, any_split, s);      // two launches of < 1 round each as one
   ron::set_error("conv group: tile config %d has no grouped form", cfg);
   return RON_ERR_INVALID;
 }
@@ -703,14 +742,107 @@ int group_pick_splitk(int KT, int tiles) {
 // Split-K factors of the members of a group.  A member's own bound (group_pick_splitk) assumes the group fills the chip; when
 // the whole group is short of that (small batches: every member is a few tiles), K is cut further so that the group's
 // workgroups come to about the chip's slots, each with >= 8 K steps - what conv_pick_splitk does for a launch of its own.
+// tile configuration member `c` of a group launched as `group_cfg` runs on
+static int group_member_cfg(int group_cfg, const ConvLaunch& c) {
+  return group_cfg == kGroupMixed ? (c.Npad % 128 == 0 ? kCfgIgemm128 : kCfgIgemm128x64) : group_cfg;
+}
+
+// Split-K factors of a mixed-width group (one dependency level of the heads: a large "carrier" member and latency-bound small
+// ones) from a model of how the launch runs: workgroups are dispatched in blockIdx order onto 512 slots (two per CU for both
+// 128-row tiles), a workgroup takes as long as its K steps.  For a common chunk length T (K steps per workgroup) every member
+// is cut into ceil(KT / T) slices (>= 8 steps each; transposed convs, fused pools and forced factors stay as they are); the
+// makespan of the resulting list schedule plus what the fp32 slabs cost (written and read once, in K-step units) is evaluated for
+// a ladder of T, the cheapest wins.  What the fixed "<= 24 steps per workgroup" rule missed: {block7_conv_left, block6_conv_left}
+// came to 808 workgroups of 116 / 24 steps = 1.6 rounds of the long ones; four slices of 144 steps are one round.
+static long long group_makespan(const int* len, const int* cnt, int n, int slots) {
+  // list scheduling in dispatch order (members as given, longest first is the caller's job); slot finish times in a min-heap
+  std::vector<long long> heap(slots, 0);
+  auto sift = [&](size_t i) {
+    const size_t N = heap.size();
+    for (;;) {
+      size_t l = 2 * i + 1, r = l + 1, m = i;
+      if (l < N && heap[l] < heap[m]) m = l;
+      if (r < N && heap[r] < heap[m]) m = r;
+      if (m == i) return;
+      std::swap(heap[i], heap[m]);
+      i = m;
+    }
+  };
+  long long end = 0;
+  for (int k = 0; k < n; ++k)
+    for (int w = 0; w < cnt[k]; ++w) {
+      heap[0] += len[k];
+      end = std::max(end, heap[0]);
+      sift(0);
+    }
+  return end;
+}
+
+static void group_splitks_scheduled(const ConvLaunch* ls, int n, int cfg, int* sk) {
+  // workgroup slots of the chip and what a K step of a workgroup costs with the slots full (measured, tools/_tune in HISTORY.md:
+  // 256 x 256: one per CU, 1.4 us; 128 x 128: two per CU, 1.15 us each; 128 x 64: 0.75 us); slab bytes the memory side moves per us
+  const int slots = cfg == kCfgIgemm256 ? 256 : 512;
+  const double kSlabBytesPerUs = 2.0e6;
+  int tiles[kMaxConvGroup], KT[kMaxConvGroup];
+  double step_us[kMaxConvGroup];
+  bool fixed[kMaxConvGroup];
+  for (int k = 0; k < n; ++k) {
+    const ConvLaunch& c = ls[k];
+    const int M = c.in.N * c.Ho * c.Wo;
+    const int mcfg = group_member_cfg(cfg, c), BM = igemm_bm(mcfg);
+    step_us[k] = mcfg == kCfgIgemm256 ? 1.4 : (mcfg == kCfgIgemm128 ? 1.15 : 0.75);
+    KT[k] = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
+    // centre-tap-only column tiles are a ninth of a tile: count them as that
+    const int cols = c.Npad / igemm_bn(mcfg), cols_long = c.center_from > 0 ? c.center_from / igemm_bn(mcfg) : cols;
+    tiles[k] = ((M + BM - 1) / BM) * cols_long + ((M + BM - 1) / BM) * (cols - cols_long) / (c.kh * c.kw);
+    fixed[k] = c.up > 0 || c.pool || c.splitk >= 0 || KT[k] < 16;
+    sk[k] = c.splitk >= 0 ? std::max(c.splitk, 1) : 1;
+  }
+  static const int ladder[] = {8, 12, 16, 24, 32, 36, 48, 64, 72, 96, 128, 144, 192, 256, 288, 384, 576, 1 << 20};
+  double best = 1e30;
+  int best_sk[kMaxConvGroup];
+  for (int T : ladder) {
+    int cand[kMaxConvGroup], len[kMaxConvGroup], cnt[kMaxConvGroup], order[kMaxConvGroup];
+    double slab_us = 0;
+    bool any = false;
+    for (int k = 0; k < n; ++k) {
+      cand[k] = fixed[k] ? sk[k] : std::max(1, std::min((KT[k] + T - 1) / T, KT[k] / 8));
+      len[k] = (int)(((KT[k] + cand[k] - 1) / cand[k]) * step_us[k] * 20.0 + 0.5);      // workgroup duration in ticks of 0.05 us
+      cnt[k] = tiles[k] * cand[k];
+      order[k] = k;
+      if (cand[k] > 1) {
+        slab_us += 2.0 * cand[k] * (double)ls[k].in.N * ls[k].Ho * ls[k].Wo * ls[k].Npad * 4 / kSlabBytesPerUs;
+        any = true;
+      }
+    }
+    std::sort(order, order + n, [&](int a, int b) { return len[a] > len[b]; });
+    int l2[kMaxConvGroup], c2[kMaxConvGroup];
+    for (int k = 0; k < n; ++k) { l2[k] = len[order[k]]; c2[k] = cnt[order[k]]; }
+    const double us = group_makespan(l2, c2, n, slots) * 0.05 + slab_us + (any ? 6.0 : 0.0);      // + the finalize launch
+    if (us < best) { best = us; for (int k = 0; k < n; ++k) best_sk[k] = cand[k]; }
+  }
+  for (int k = 0; k < n; ++k) sk[k] = best_sk[k];
+}
+
 static void group_splitks(const ConvLaunch* ls, int n, int cfg, int* sk) {
-  const int BM = igemm_bm(cfg), BN = igemm_bn(cfg), slots = igemm_slots(cfg);
+  if (cfg == kGroupMixed || cfg == kCfgIgemm256) {
+    // the schedule model assumes a launch that can fill the chip; below that (small batches: every member is a few tiles) the
+    // per-member rule that follows measured better (batch 1, six levels: 271 vs 291 us)
+    long long wg1 = 0;
+    for (int k = 0; k < n; ++k) {
+      const int mcfg = group_member_cfg(cfg, ls[k]);
+      wg1 += (long long)((ls[k].in.N * ls[k].Ho * ls[k].Wo + igemm_bm(mcfg) - 1) / igemm_bm(mcfg)) * (ls[k].Npad / igemm_bn(mcfg));
+    }
+    if (wg1 * 2 >= (cfg == kCfgIgemm256 ? 256 : 512)) return group_splitks_scheduled(ls, n, cfg, sk);
+  }
+  const int slots = cfg == kCfgIgemm256 ? 256 : 512;     // workgroups the chip holds (256 x 256: one per CU, the 128-row tiles: two)
   int tiles[kMaxConvGroup], KT[kMaxConvGroup];
   long long steps = 0, wgs = 0;
   for (int k = 0; k < n; ++k) {
     const ConvLaunch& c = ls[k];
     const int M = c.in.N * c.Ho * c.Wo;
     KT[k] = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
+    const int BM = igemm_bm(group_member_cfg(cfg, c)), BN = igemm_bn(group_member_cfg(cfg, c));
     tiles[k] = ((M + BM - 1) / BM) * (c.Npad / BN);
     sk[k] = (c.up > 0 || c.pool) ? 1 : (c.splitk >= 0 ? std::max(c.splitk, 1) : group_pick_splitk(KT[k], tiles[k]));
     steps += (long long)tiles[k] * KT[k];
@@ -743,32 +875,54 @@ int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg) {
   return total;
 }
 
-// `n` mutually independent convolutions as one launch of tile configuration `cfg` (kCfgIgemm128x64 or kCfgIgemm128);
+// `n` mutually independent convolutions as one launch of tile configuration `cfg` (kCfgIgemm128x64, kCfgIgemm128, or kGroupMixed:
+// each member on the 128-row tile of its own width);
 // `scratch`: conv_group_scratch_bytes() for the split-K slabs (each conv gets its own part).
-int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64_t scratch_bytes, hipStream_t stream) {
+void conv_group_plan(const ConvLaunch* ls, int n, int cfg, int* sk) {
+  if (cfg == kCfgPatch64 || n < 1 || n > kMaxConvGroup) { for (int k = 0; k < n && k < kMaxConvGroup; ++k) sk[k] = 1; return; }
+  group_splitks(ls, n, cfg, sk);
+}
+
+int launch_conv_group(const ConvLaunch* ls_in, int n, int cfg, void* scratch, int64_t scratch_bytes, hipStream_t stream, const int* sk_plan) {
   RON_REQUIRE(n >= 1 && n <= kMaxGroup, "conv group: %d launches (1..%d)", n, kMaxGroup);
   if (cfg == kCfgPatch64) {
     // the two skinny heads of a scale: one launch of the patch kernel where it is the choice for both (dtype, map, batch),
     // otherwise each as the launch it would be on its own
     RON_REQUIRE(n == 2, "conv group: the patch-kernel form takes a pair");
-    if (conv_patch_pair_applicable(ls[0], ls[1])) return launch_conv_patch_pair(ls[0], ls[1], stream);
+    if (conv_patch_pair_applicable(ls_in[0], ls_in[1])) return launch_conv_patch_pair(ls_in[0], ls_in[1], stream);
     for (int k = 0; k < n; ++k) {
-      const int rc = launch_conv(ls[k], stream);
+      const int rc = launch_conv(ls_in[k], stream);
       if (rc) return rc;
     }
     return RON_OK;
   }
-  RON_REQUIRE(cfg == kCfgIgemm128x64 || cfg == kCfgIgemm128, "conv group: tile config %d has no grouped form", cfg);
-  const int BM = igemm_bm(cfg), BN = igemm_bn(cfg);
+  RON_REQUIRE(cfg == kCfgIgemm128x64 || cfg == kCfgIgemm128 || cfg == kGroupMixed || cfg == kCfgIgemm256,
+              "conv group: tile config %d has no grouped form", cfg);
   ConvGroupArgs g = ConvGroupArgs();
   g.n = n;
   int64_t used = 0;
   bool any_split = false;
-  int sks[kMaxConvGroup];
-  group_splitks(ls, n, cfg, sks);
+  int sks_in[kMaxConvGroup], sks[kMaxConvGroup], order[kMaxConvGroup];
+  if (sk_plan != nullptr) for (int k = 0; k < n; ++k) sks_in[k] = sk_plan[k];
+  else group_splitks(ls_in, n, cfg, sks_in);
+  // workgroups are dispatched in blockIdx order: the members with the longest K chains per workgroup go first, the short ones fill
+  // the slots the long ones leave (members are independent: their order is free)
+  for (int k = 0; k < n; ++k) order[k] = k;
+  if (cfg == kGroupMixed || cfg == kCfgIgemm256) {
+    auto chain = [&](int k) {
+      const ConvLaunch& c = ls_in[k];
+      const int KT = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
+      return (KT + sks_in[k] - 1) / sks_in[k];
+    };
+    std::stable_sort(order, order + n, [&](int a, int b) { return chain(a) > chain(b); });
+  }
+  ConvLaunch ls[kMaxConvGroup];
+  for (int k = 0; k < n; ++k) { ls[k] = ls_in[order[k]]; sks[k] = sks_in[order[k]]; }
   for (int k = 0; k < n; ++k) {
     const ConvLaunch& c = ls[k];
     const int esz = (int)dtype_size(c.dtype), chunk = conv_k_chunk(c.dtype);
+    const int mcfg = group_member_cfg(cfg, c), BM = igemm_bm(mcfg), BN = igemm_bn(mcfg);
+    if (mcfg == kCfgIgemm128x64) g.narrow |= 1u << k;
     RON_REQUIRE(c.dtype == ls[0].dtype, "conv group: mixed dtypes");
     RON_REQUIRE(c.in.C % chunk == 0 && c.in.pad >= c.cpad, "conv group: bad input (Cin %d, halo %d < %d)", c.in.C, c.in.pad, c.cpad);
     RON_REQUIRE(c.in.bytes > 0 && c.in.bytes < (int64_t)1 << 32 && c.wgt_bytes > 0 && c.wgt_bytes < (int64_t)1 << 32,
@@ -791,7 +945,7 @@ int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64
       else { used += need; any_split = true; }
     }
     a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
-    a.pos_major = pick_pos_major(c, cfg, BM);
+    a.pos_major = pick_pos_major(c, mcfg, BM);
     if (c.center_from > 0) RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1), "conv group: bad centre-tap-only columns");
     g.first[k + 1] = g.first[k] + a.tiles_total * a.splitk;
   }

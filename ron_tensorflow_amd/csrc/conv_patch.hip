@@ -29,6 +29,29 @@ constexpr int kPatchRows = 344;                  // rows a patch buffer holds (4
 
 __device__ __forceinline__ int patch_key(int i) { return ((i >> 1) & 3) << 1; }
 
+// Issue order of the NQ k-steps between two barriers, everything a compile-time constant (the builtin wants immediates): per k-step
+// its MFMAs (split precision: one per fragment pair in a hi step, two in a lo step), the next k-step's RD fragment reads one per MFMA
+// gap, and - in k-step 0 only - the step's PS0 LDS-DMA instructions spaced evenly between the MFMAs.
+template <class Tr, int MR, int NR, int NQ, int PS0, int q = 0>
+__device__ __forceinline__ void pin_patch_ksteps() {
+  if constexpr (q < NQ) {
+    constexpr int RD = q < NQ - 1 ? MR + NR : 0;
+    constexpr int MM = MR * NR * (IsSplit<Tr>::value ? 1 + (q & 1) : Tr::kMfmaPerMma);
+    constexpr int PS = q == 0 ? PS0 : 0;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (m < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (((m + 1) * PS) / MM > (m * PS) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    if constexpr (RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+      if (x < PS - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    pin_patch_ksteps<Tr, MR, NR, NQ, PS0, q + 1>();
+  }
+}
+
 struct PatchArgs {
   ConvArgs c;
   int flat;                   // 1: runs of 256 positions; 0: TH x TW pixel tiles
@@ -72,6 +95,7 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
   // `wave` is wave-uniform; said explicitly, or hipcc wraps every LDS-DMA whose descriptor / LDS address depends on it (the
   // "piece lies inside the patch buffer" tests below) in a waterfall loop
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if constexpr (IsSplit<Tr>::value) split_mode_on();      // the epilogue's fp32 -> f16 conversions saturate (conv_device.h)
   const int wm = wave / WN, wn = wave % WN;
 
   const unsigned xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
@@ -235,7 +259,12 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
           const int row = pp[i] + ky * pa.PW + kx;
           a_off[kx][i] = row * kRowBytes + ((fh ^ patch_key(row)) << 4);
         }
-      u32x4 fa[2][MR], fb[2][NR];
+      // Split precision (TraitsF16X3S): k-step 0 of a tap reads the hi planes (16-byte slots 0..3 of the row chunk), k-step 1 the lo
+      // planes (slots 4..7: the same address ^ 64), and the products are hi*hi in k-step 0, lo*hi + hi*lo in k-step 1 - so the lo
+      // step needs the hi fragments too while the next tap's are already being read: three register sets instead of two.
+      constexpr bool kSplit = IsSplit<Tr>::value;
+      constexpr int NS = kSplit ? 3 : 2;
+      u32x4 fa[NS][MR], fb[NS][NR];
       // fragments of k-step q_ (= 2 kx + k-step of the tap) into register set set_
 #define READ_FRAGS(set_, q_)                                                                                                       \
       do {                                                                                                                         \
@@ -270,32 +299,27 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
       }
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
-        if (q < 5) READ_FRAGS((q + 1) & 1, q + 1);
+        if (q < 5) READ_FRAGS((q + 1) % NS, q + 1);
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-          for (int j = 0; j < NR; ++j) Tr::mma(fa[q & 1][i], fb[q & 1][j], acc[i][j]);
+          for (int j = 0; j < NR; ++j) {
+            if constexpr (kSplit) {
+              if (q & 1) {
+                Tr::mma(fa[q % NS][i], fb[(q + NS - 1) % NS][j], acc[i][j]);       // lo * hi
+                Tr::mma(fa[(q + NS - 1) % NS][i], fb[q % NS][j], acc[i][j]);       // hi * lo
+              } else {
+                Tr::mma(fa[q % NS][i], fb[q % NS][j], acc[i][j]);                  // hi * hi
+              }
+            } else {
+              Tr::mma(fa[q % NS][i], fb[q % NS][j], acc[i][j]);
+            }
+          }
       }
       // issue order: first fragments | k-step 0: MFMAs with the next reads and the GR DMA instructions between them | k-steps 1..4:
       // MFMAs with the next reads | last k-step
-      {
-        constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma;
-        __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          const int ps = q == 0 ? GR : 0;
-#pragma unroll
-          for (int m = 0; m < MM; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (q < 5 && m < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (((m + 1) * ps) / MM > (m * ps) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          }
-          if (q < 5 && RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
-#pragma unroll
-          for (int x = 0; x < 16; ++x)
-            if (x < ps - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-      }
+      __builtin_amdgcn_sched_group_barrier(0x100, MR + NR, 0);
+      pin_patch_ksteps<Tr, MR, NR, 6, GR>();
       if (++ky == 3) { ky = 0; ++cc; }
     }
 #undef READ_FRAGS
@@ -362,28 +386,12 @@ __device__ __forceinline__ void conv3x3_patch_tile(const PatchArgs& pa, const Co
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
-        for (int j = 0; j < NR; ++j) Tr::mma(fa[s2 & 1][i], fb[s2 & 1][j], acc[i][j]);
+        for (int j = 0; j < NR; ++j) mma_step<Tr, MR, NR>(s2, fa, fb, i, j, acc[i][j]);      // split precision: hi*hi | lo*hi + hi*lo
     }
     // issue order: first fragments | k-step 0: MFMAs with the next reads and the G DMA instructions spaced between them |
     // MFMAs of the last k-step
-    {
-      constexpr int RD = MR + NR, MM = MR * NR * Tr::kMfmaPerMma;
-      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-#pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) {
-        const int ps = s2 == 0 ? G : 0;
-#pragma unroll
-        for (int q = 0; q < MM; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (s2 < KS - 1 && q < RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (((q + 1) * ps) / MM > (q * ps) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        if (s2 < KS - 1 && RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
-#pragma unroll
-        for (int x = 0; x < 8; ++x)
-          if (x < ps - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-    }
+    __builtin_amdgcn_sched_group_barrier(0x100, MR + NR, 0);
+    pin_patch_ksteps<Tr, MR, NR, KS, G>();
     if (++tap == 9) { tap = 0; ++cc; ky = 0; kx = 0; }
     else if (++kx == 3) { kx = 0; ++ky; }
   }
@@ -456,7 +464,7 @@ using namespace detail;
 
 bool conv_patch_applicable(const ConvLaunch& c) {
   PatchGeom g;
-  return c.dtype != RON_DTYPE_F16X3 && c.center_from == 0 &&     // split precision / centre-tap-only columns: the row-gather kernel only
+  return c.center_from == 0 &&     // centre-tap-only columns: the row-gather kernel only
          c.kh == 3 && c.kw == 3 && c.stride == 1 && c.dil == 1 && c.cpad == 1 && c.up == 0 && c.in.H == c.Ho && c.in.W == c.Wo &&
          c.in.pad >= 1 && c.Npad % 64 == 0 && c.in.C % conv_k_chunk(c.dtype) == 0 &&
          patch_geom(c.in.N, c.in.H, c.in.W, c.in.pad, c.pool != 0, &g);
@@ -474,6 +482,9 @@ int conv_patch_pick(const ConvLaunch& c) {
   PatchGeom g;
   if (!patch_geom(c.in.N, c.in.H, c.in.W, c.in.pad, c.pool != 0, &g)) return -1;
   if (c.Npad != 64) return -1;
+  // split precision: the skinny heads (Cin = 512) only - on conv1_2 (Cin = 64: two chunks of 32 elements per tap) the row-gather
+  // kernel measured 7-9 % ahead (tools/sweep_conv.py --dtype f16x3, profiles/r04/sweep_f16x3_patch.txt)
+  if (c.dtype == RON_DTYPE_F16X3 && c.in.C < 256) return -1;
   return g.tiles_sp >= 192 ? kCfgPatch64 : -1;
 }
 
@@ -533,6 +544,7 @@ int launch_conv_patch_pair(const ConvLaunch& ca, const ConvLaunch& cb, hipStream
   } while (0)
   if (ca.dtype == RON_DTYPE_BF16) RON_PATCH_PAIR(TraitsBF16S);
   if (ca.dtype == RON_DTYPE_F16) RON_PATCH_PAIR(TraitsF16S);
+  if (ca.dtype == RON_DTYPE_F16X3) RON_PATCH_PAIR(TraitsF16X3S);
   RON_PATCH_PAIR(TraitsF32S);
 #undef RON_PATCH_PAIR
 }
@@ -551,6 +563,7 @@ int launch_conv_patch(const ConvLaunch& c, int cfg, hipStream_t stream) {
   } while (0)
   if (c.dtype == RON_DTYPE_BF16) RON_PATCH_DISPATCH(TraitsBF16S);
   if (c.dtype == RON_DTYPE_F16) RON_PATCH_DISPATCH(TraitsF16S);
+  if (c.dtype == RON_DTYPE_F16X3) RON_PATCH_DISPATCH(TraitsF16X3S);
   RON_PATCH_DISPATCH(TraitsF32S);
 #undef RON_PATCH_DISPATCH
 }

@@ -29,6 +29,7 @@ template <class T, int V> struct alignas(sizeof(T) * V) Vec { T v[V]; };
 template <class T> struct IO {
   static constexpr int V = 16 / sizeof(T);
   static constexpr int kEsz = sizeof(T);
+  static __device__ __forceinline__ void mode_on() {}          // see IO<SplitF16>
   static __device__ __forceinline__ void load(const void* base, long long off, float* f) {
     const Vec<T, V> a = *reinterpret_cast<const Vec<T, V>*>(reinterpret_cast<const T*>(base) + off);
 #pragma unroll
@@ -49,11 +50,12 @@ template <> struct IO<SplitF16> {
   static constexpr int V = 8;
   static constexpr int kEsz = 4;
   static __device__ __forceinline__ long long hidx(long long off) { return ((off >> 5) << 6) + (off & 31); }
-  // saturating split, the same rule as conv_device.h::split_f16 (values beyond the f16 range clip instead of turning into inf - inf)
-  static __device__ __forceinline__ float sat(float v) { return v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v); }
+  // kernels that store this format set MODE.FP16_OVFL first (mode_on): an overflowing conversion saturates at 65504 instead of
+  // producing inf - inf = NaN on the way back (conv_device.h, split_mode_on)
+  static __device__ __forceinline__ void mode_on() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }
   static __device__ __forceinline__ void split(float v, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)sat(v);
-    lo = (_Float16)sat(v - (float)hi);
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
   }
   static __device__ __forceinline__ void load(const void* base, long long off, float* f) {
     const _Float16* h = reinterpret_cast<const _Float16*>(base) + hidx(off);
@@ -88,6 +90,7 @@ template <> struct IO<SplitF16> {
 // (zero outside the image, zero for k >= 27).  The 3x3 conv then runs as a 1x1 conv on the MFMA path.
 template <class T>
 __global__ void im2col_c3_kernel(const float* __restrict__ x, int n, int h, int w, int kc, void* __restrict__ out) {
+  IO<T>::mode_on();
   constexpr int V = IO<T>::V;
   const int groups = kc / V;
   const long long total = (long long)n * h * w * groups;
@@ -127,6 +130,7 @@ __device__ __forceinline__ long long view_off(const ViewDev& v, long long img, i
 // slim.max_pool2d [2,2] stride 2 (nets/ron_vgg_320.py:456..475); all RON maps are even so SAME == VALID.
 template <class T>
 __global__ void maxpool2x2_kernel(ViewDev in, ViewDev out) {
+  IO<T>::mode_on();
   constexpr int V = IO<T>::V;
   const int groups = out.C / V;
   const long long total = (long long)out.N * out.H * out.W * groups;
@@ -153,6 +157,7 @@ __global__ void maxpool2x2_kernel(ViewDev in, ViewDev out) {
 // zero halo is equivalent to TF's "ignore the padding" for a max.
 template <class T>
 __global__ void maxpool3x3s1_kernel(ViewDev in, ViewDev out) {
+  IO<T>::mode_on();
   constexpr int V = IO<T>::V;
   const int groups = out.C / V;
   const long long total = (long long)out.N * out.H * out.W * groups;
@@ -182,6 +187,7 @@ __global__ void maxpool3x3s1_kernel(ViewDev in, ViewDev out) {
 // y = x * rsqrt(max(sum_c x^2, 1e-12)) * gamma[c].  One wave per pixel, 16 B per lane (and plane) per pass.
 template <class T>
 __global__ void l2norm_kernel(ViewDev in, ViewDev out, const float* __restrict__ gamma) {
+  IO<T>::mode_on();
   constexpr int V = IO<T>::V;
   const int lane = threadIdx.x & 63;
   const long long n_pix = (long long)in.N * in.H * in.W;
@@ -214,6 +220,7 @@ __global__ void l2norm_kernel(ViewDev in, ViewDev out, const float* __restrict__
 
 template <class T>
 __global__ void pack_kernel(const float* __restrict__ x, ViewDev out) {
+  IO<T>::mode_on();
   const long long total = (long long)out.N * out.H * out.W * out.C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % out.C);
@@ -240,6 +247,7 @@ __global__ void unpack_kernel(ViewDev in, float* __restrict__ y) {
 
 template <class T>
 __global__ void fill_random_kernel(ViewDev out, unsigned seed) {
+  IO<T>::mode_on();
   const long long total = (long long)out.N * out.H * out.W * out.C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % out.C);

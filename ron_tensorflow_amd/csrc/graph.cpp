@@ -5,18 +5,19 @@
 // :406-415) with the slim layer semantics of ron_arg_scope (:595-629), re-planned for the
 // MFMA implicit-GEMM kernel:
 //   * inference BatchNorm (eps 1e-5) is folded into the preceding conv at load time;
-//   * per scale, the three 3x3 convs that read the reference map (objectness hidden layer,
-//     box hidden layer, inception-1 3x3 branch) run as ONE conv with 1536 output channels;
-//     the 1x1 branches run as their own 1x1 GEMMs (embedding them in the centre tap of a 3x3
-//     would execute 9x their MACs) and write their half of the concatenated tensor; the
+//   * per scale, everything that reads the reference map (objectness hidden layer, box hidden layer,
+//     both inception-1 branches) runs as ONE conv with 2048 output channels, the 1x1 branch in the centre
+//     tap of its rows (those column tiles run that tap's K steps only); inception-2 likewise; the
 //     BatchNorm after each concat is split per branch and folded; consumers read channel slices;
-//   * the 2x2 stride-2 transposed conv is a GEMM with a pixel-shuffle epilogue, and the
-//     reverse-connection sum relu(left + up) is the epilogue of the left conv;
+//   * the 2x2 stride-2 transposed conv is a GEMM with a pixel-shuffle epilogue; the left conv of a
+//     reverse connection writes its half of relu(left + up) first and the transposed conv adds its
+//     half in place, so only the (small) transposed convs sit on the coarse -> fine chain;
 //   * head logits are written as fp32 straight into the caller's buffers.
 // Every activation lives in HBM as NHWC with a zero halo (conv_mfma.h); all buffers are
 // allocated once for max_batch images (activations of the full variant: ~150 MB / image).
 #include <math.h>
 
+#include <array>
 #include <map>
 #include <memory>
 #include <string>
@@ -129,6 +130,9 @@ struct ron_ctx {
   std::vector<OpTiming> timing;                       // ops.size() + 1 (last = post-processing)
   std::vector<std::string> labels;                    // ron_profile_get names, one per op, built once (stable until ron_destroy)
   int grouped_launches = 0;                           // grouped launches in the plan (0: one launch per convolution)
+  // split-K factors of the grouped launches, planned once per (first op of the group, batch) - conv_group_plan models the launch's
+  // schedule, which is far too slow for the enqueue path: [op index] -> [batch] -> factors (first = 0: not planned yet)
+  std::map<int, std::vector<std::array<int, kMaxConvGroup>>> group_sk;
   std::vector<std::vector<hipEvent_t>> pending;       // per recorded call: one event per stamp ...
   std::vector<std::vector<int>> pending_ops;          // ... and what it marks: op index (its start), -1 = end of a lane,
                                                       //     -2 / -3 = start / end of the post-processing stage
@@ -435,19 +439,14 @@ int make_anchors_ssd(ron_ctx* c) {
   return RON_OK;
 }
 
-// Launch order of the RON heads with the small convolutions grouped (launch_conv_group).  The reference builds the scales one
-// after the other (nets/ron_vgg_320.py:495-506); the only true dependencies are  ref(i) -> trio3(i) (the 1x1 inception branch rides in its centre tap) ->
-// {objectness_score, inception2_*, loc_pred}(i) -> cls_pred(i)  inside a scale and  ref(i) -> deconv_right(i+1) -> conv_left(i+1)
-// -> ref(i+1)  across scales.  At batch 32 the 5x5 and 10x10 scales (M = 800 / 3 200 rows) and the 1x1 / Cout <= 40 layers of
-// the 20x20 scale each fill a fraction of the chip and run 20-35 us apiece, mostly launch + pipeline fill; interleaving the
-// scales by dependency level gives launches of 3-6 independent convolutions each (measured, batch 32, one launch at a
-// time: 68 -> 47 us, 126 -> 50 us, 91 -> 38 us, 98 -> 78 us for the four T64 sets; the T128 sets of medium convolutions
-// are time-neutral and only save launches).  Every braced set below only reads what earlier entries wrote, and its
-// members write disjoint tensors / channel slices.
+// Launch order of the heads with the small convolutions grouped (launch_conv_group).  The reference builds the scales one after the
+// other (nets/ron_vgg_320.py:495-506); the true dependencies are listed at the RON tables below.  Every braced set only reads what
+// earlier entries wrote, and its members write disjoint tensors / channel slices.  History of the measurements behind the plans:
+// HISTORY.md (rounds 2-3: T64 / T128 groups by dependency level) and DESIGN.md 3.2 (round 4: mixed-width groups with carriers).
 void plan_groups(ron_ctx* c) {
   if (c->cfg.flags & (RON_CFG_MULTI_STREAM | RON_CFG_NO_GROUPS)) return;
   struct Slot { int cfg; std::vector<const char*> names; };     // cfg < 0: launches of their own
-  const int T64 = kCfgIgemm128x64, T128 = kCfgIgemm128;     // tiny convolutions / medium ones (Npad % 128 == 0)
+  const int T64 = kCfgIgemm128x64;     // tiny convolutions (Npad = 64)
   // SSD-512 (nets/ssd_vgg_512.py:395-458): blocks 8-12 are a chain of 1x1 -> 3x3 stride-2 convolutions on 16x16 ... 1x1 maps,
   // each a 13-20 us launch at batch 16; the two box convolutions of a block only need that block's output, so they share a
   // launch with the next block's 1x1 (20 small launches -> 11).  The block4 / block7 heads are real work and stay alone.
@@ -462,18 +461,28 @@ void plan_groups(ron_ctx* c) {
       {-1, {"block4_l2norm"}}, {-1, {"block4_box_conv_loc"}}, {-1, {"block4_box_conv_cls"}},
       {-1, {"block7_box_conv_loc"}}, {-1, {"block7_box_conv_cls"}},
   };
+  // RON heads.  Dependencies after the round-4 re-formulation of the reverse connection (the LEFT conv of a scale reads a backbone
+  // map only; the transposed conv adds its half in place, ron_finalize_weights):
+  //   conv_left(i)                       <- backbone (fc7 / fc6 / conv5_3 / conv4_3)        i = block7, 6, 5, 4
+  //   deconv_right(i) -> ref(i)          <- ref(i-1), conv_left(i)
+  //   trio3(i) -> hcat(i)                <- ref(i)
+  //   {objectness_score, inception2, loc_pred}(i) <- hcat(i);   cls_pred(i) <- inception2(i)
+  // so the coarse -> fine chain is ref7 -> deconv6 -> deconv5 -> deconv4 (three small GEMMs), and a dependency LEVEL is
+  // {cls_pred(i-2), obj / inc2 / loc(i-1), trio3(i), deconv_right(i+1)}.  MIX = one launch of the row-gather kernel with the tile width
+  // chosen per member (kGroupMixed): the latency-bound launches of the 5x5 / 10x10 scales (M = 800 / 3200 rows at batch 32: 18-50 us
+  // apiece, mostly pipeline fill and split-K hand-off) ride in the partial rounds of the level's large member.  The members that are
+  // several full rounds of 256 x 256 tiles on their own (block4: conv_left, trio3, inception2, cls_pred) keep launches of their own.
+  const int MIX = kGroupMixed;
   const std::vector<Slot> ron_order = {
-      {-1, {"block7_conv_left"}},
-      {T64, {"block7_trio3", "block6_deconv_right"}},
-      {-1, {"block6_conv_left"}},
-      {T64, {"block7_objectness_score", "block7_inception2", "block7_loc_pred", "block5_deconv_right"}},
-      {T128, {"block6_trio3", "block5_conv_left"}},
-      {T128, {"block6_inception2", "block4_deconv_right"}},
-      {T64, {"block7_cls_pred", "block6_objectness_score", "block6_loc_pred"}},
-      {-1, {"block5_trio3"}},
+      // fc7 (208 tiles of 256 x 256) and the left conv of block6 (26 tiles x 576 K steps: split-K) both read fc6 and are each short
+      // of one round of the chip: one launch of 256 x 256 tiles
+      {kCfgIgemm256, {"fc7", "block6_conv_left"}},
+      {MIX, {"block7_conv_left", "block5_conv_left"}},
+      {MIX, {"block7_trio3", "block6_deconv_right"}},
+      {MIX, {"block7_objectness_score", "block7_inception2", "block7_loc_pred", "block6_trio3", "block5_deconv_right"}},
       {-1, {"block4_conv_left"}},
-      {T64, {"block6_cls_pred", "block5_objectness_score", "block5_loc_pred"}},
-      {-1, {"block5_inception2"}},
+      {MIX, {"block7_cls_pred", "block6_objectness_score", "block6_inception2", "block6_loc_pred", "block5_trio3", "block4_deconv_right"}},
+      {MIX, {"block6_cls_pred", "block5_objectness_score", "block5_loc_pred", "block5_inception2"}},
       {-1, {"block4_trio3"}},
       {-1, {"block5_cls_pred"}},
       // Cout = 20 / 40 over channel slices of the same tensor: one launch of the halo-patch kernel (400 workgroups; 200 each alone)
@@ -483,18 +492,15 @@ void plan_groups(ron_ctx* c) {
   };
   // Small batches (RON_CFG_LEVEL_GROUPS, the default when max_batch <= kLevelPlanMaxBatch): every head convolution is a
   // latency-bound launch of a few hundred workgroups (25-40 us each with its split-K finalize, whatever its size), so
-  // the heads go out one launch per dependency level, the large convolutions included: 16 head launches -> 10.
+  // the heads go out one launch per dependency level, the large convolutions included: 16 head launches -> 7.
   const std::vector<Slot> ron_levels = {
-      {-1, {"block7_conv_left"}},
-      {T64, {"block7_trio3", "block6_deconv_right"}},
-      {T64, {"block6_conv_left", "block7_objectness_score", "block7_inception2", "block7_loc_pred"}},
-      {T128, {"block6_trio3", "block5_deconv_right", "block7_cls_pred"}},
-      {T64, {"block5_conv_left", "block6_objectness_score", "block6_inception2", "block6_loc_pred"}},
-      {T128, {"block5_trio3", "block4_deconv_right", "block6_cls_pred"}},
-      {T64, {"block4_conv_left", "block5_objectness_score", "block5_inception2", "block5_loc_pred"}},
-      {T128, {"block4_trio3", "block5_cls_pred"}},
-      {-1, {"block4_inception2"}},
-      {T64, {"block4_cls_pred", "block4_objectness_score", "block4_loc_pred"}},
+      {MIX, {"block7_conv_left", "block6_conv_left", "block5_conv_left", "block4_conv_left"}},
+      {MIX, {"block7_trio3", "block6_deconv_right"}},
+      {MIX, {"block7_objectness_score", "block7_inception2", "block7_loc_pred", "block6_trio3", "block5_deconv_right"}},
+      {MIX, {"block7_cls_pred", "block6_objectness_score", "block6_inception2", "block6_loc_pred", "block5_trio3", "block4_deconv_right"}},
+      {MIX, {"block6_cls_pred", "block5_objectness_score", "block5_inception2", "block5_loc_pred", "block4_trio3"}},
+      {MIX, {"block5_cls_pred", "block4_objectness_score", "block4_inception2", "block4_loc_pred"}},
+      {-1, {"block4_cls_pred"}},
   };
   const bool levels = !(c->cfg.flags & RON_CFG_BATCH_GROUPS) &&
                       ((c->cfg.flags & RON_CFG_LEVEL_GROUPS) || c->cfg.max_batch <= kLevelPlanMaxBatch);
@@ -585,7 +591,6 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
     c->feat[i] = s_h;
     c->feat_h[i] = s_h; c->feat_w[i] = s_w; c->feat_A[i] = c->num_anchors;
     const std::string L = kFeatLayers[i];
-    if (i > 0) c->add_tensor(L + "_up", s_h, s_w, 512, 1);
     c->add_tensor(L + "_ref", s_h, s_w, 512, 1);
     c->add_tensor(L + "_hcat", s_h, s_w, 2048, 1);
     c->add_tensor(L + "_inc2", s_h, s_w, 1024, 1);
@@ -834,18 +839,22 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       Op o = conv_op(Ln + "_conv_left", T(left_src[i]), T(Ln + "_ref"), rc, 2, 0, 1, sh, sw);
       o.stride = 2;
       c->ops.push_back(o);
+      flops += conv_flops(c->var(L + "_conv_left/weights"), sh * sw); ATTR();
     } else {
+      // relu(relu(BN(conv_left(backbone map))) + relu(deconv_right(coarser reference map) + b))  (nets/ron_vgg_320.py:420-425).
+      // The LEFT conv writes its half into the reference map's tensor first - it reads a backbone map only, so it is OFF the
+      // coarse -> fine chain and free to be launched early / beside anything - and the transposed conv, the cheap one that IS on the
+      // chain, adds its half in place (pixel-shuffle epilogue with the residual at the same address).
+      PACK(pack_plain(c, L + "_conv_left", true));
+      c->ops.push_back(conv_op(Ln + "_conv_left", T(left_src[i]), T(Ln + "_ref"), rc, 3, 1, 1, sh, sw));
+      flops += conv_flops(c->var(L + "_conv_left/weights"), sh * sw); ATTR();
       PACK(pack_deconv(c, L + "_deconv_right"));
-      Op d = conv_op(Ln + "_deconv_right", T(std::string(kFeatLayers[i - 1]) + "_ref"), T(Ln + "_up"), rc, 1, 0, 1, sh / 2, sw / 2);
+      Op d = conv_op(Ln + "_deconv_right", T(std::string(kFeatLayers[i - 1]) + "_ref"), T(Ln + "_ref"), rc, 1, 0, 1, sh / 2, sw / 2);
       d.up = 2; d.up_cout = 512;
+      d.res = T(Ln + "_ref");                 // in place: ref = relu(left + up)
       c->ops.push_back(d);
       flops += conv_flops(c->var(L + "_deconv_right/weights"), (sh / 2) * (sw / 2)); ATTR();
-      PACK(pack_plain(c, L + "_conv_left", true));
-      Op o = conv_op(Ln + "_conv_left", T(left_src[i]), T(Ln + "_ref"), rc, 3, 1, 1, sh, sw);
-      o.res = T(Ln + "_up");
-      c->ops.push_back(o);
     }
-    flops += conv_flops(c->var(L + "_conv_left/weights"), sh * sw); ATTR();
     // hcat channels: [0,512) objectness hidden | [512,1024) box hidden | [1024,1536) inception-1 3x3 | [1536,2048) inception-1 1x1
     PACK(pack_trio3(c, L));
     {
@@ -1102,7 +1111,10 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
         RON_REQUIRE(j - oi < (size_t)kMaxConvGroup, "conv group %d has more than %d members", o.group, kMaxConvGroup);
         if ((rc = describe_conv(c, c->ops[j], n, out, &L[j - oi]))) return rc;
       }
-      if ((rc = launch_conv_group(L, (int)(j - oi), o.group_cfg, c->d_splitk[o.lane], c->splitk_bytes[o.lane], s))) {
+      std::vector<std::array<int, kMaxConvGroup>>& plans = c->group_sk[(int)oi];
+      if (plans.empty()) plans.assign(c->cfg.max_batch + 1, std::array<int, kMaxConvGroup>{});
+      if (plans[n][0] == 0) conv_group_plan(L, (int)(j - oi), o.group_cfg, plans[n].data());
+      if ((rc = launch_conv_group(L, (int)(j - oi), o.group_cfg, c->d_splitk[o.lane], c->splitk_bytes[o.lane], s, plans[n].data()))) {
         std::string msg = ron_last_error();
         ron::set_error("group of %s: %s", o.name.c_str(), msg.c_str());
         return rc;

@@ -37,12 +37,9 @@ def test_the_checker_sees_a_dropped_placeholder():
     """The check itself: a K loop with one LDS-DMA fewer than its wait counts, and a prologue short of one, are reported."""
     name = '_ZN3ron6detail17conv_igemm_kernelINS0_11TraitsBF16SELi128ELi128ELi2ELi2ELi3ELi1ELb0EEEvNS0_8ConvArgsE'   # S = 3: LPT = 8
     dma = '\tbuffer_load_dwordx4 v1, s[0:3], s4 offen lds'
-    good = [dma] * 16 + ['.LBB0_1:', '\ts_waitcnt vmcnt(8) lgkmcnt(0)', '\ts_barrier'] + [dma] * 8 + ['\ts_cbranch_scc1 .LBB0_1', '\ts_endpgm']
+    good = [dma] * 16 + ['.LBB0_1:', '\t;;#ASMSTART', '\ts_waitcnt vmcnt(8) lgkmcnt(0)', '\t;;#ASMEND', '\ts_barrier'] + [dma] * 8 + ['\ts_cbranch_scc1 .LBB0_1', '\ts_endpgm']
     assert cdc.check_igemm(name, good) == []
-    short_loop = [l for l in good]
-    short_loop.remove(dma)
-    short_loop.insert(16 + 3, '\tv_nop')          # prologue intact (16), one of the loop's eight gone
-    short_loop = [dma] * 16 + good[16:19] + [dma] * 7 + good[-2:]
+    short_loop = [dma] * 16 + good[16:21] + [dma] * 7 + good[-2:]          # prologue intact (16), one of the loop's eight gone
     assert any('per K step' in p for p in cdc.check_igemm(name, short_loop))
     short_prologue = [dma] * 15 + good[16:]
     assert any('prologue' in p for p in cdc.check_igemm(name, short_prologue))

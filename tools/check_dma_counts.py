@@ -47,9 +47,10 @@ def kernels(asm):
             name = m.group(1)
             out[name] = []
         elif name is not None:
-            out[name].append(line)
-            if 's_endpgm' in line:
+            if line.startswith('.Lfunc_end'):       # not the first s_endpgm: a kernel may hold early exits
                 name = None
+            else:
+                out[name].append(line)
     return out
 
 
@@ -58,8 +59,10 @@ def loops(lines):
     the previous loop (or the kernel's start) and this wait)]: a K loop = `s_waitcnt vmcnt(N) lgkmcnt(0)` directly followed by
     s_barrier, up to the branch back to a label at or above it."""
     labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r'^(\.LBB\d+_\d+):', l)] if m}
+    # the kernels' own counted wait is inline assembly (;;#ASMSTART in front of it): a compiler-generated `s_waitcnt vmcnt(0) lgkmcnt(0)`
+    # before the s_barrier of a __syncthreads() is not a K-loop top
     tops = [i for i, l in enumerate(lines) if re.search(r's_waitcnt vmcnt\(\d+\) lgkmcnt\(0\)', l)
-            and any('s_barrier' in x for x in lines[i + 1:i + 3])]
+            and i > 0 and '#ASMSTART' in lines[i - 1] and any('s_barrier' in x for x in lines[i + 1:i + 4])]
     out, prev_end = [], 0
     for top in tops:
         n = int(re.search(r'vmcnt\((\d+)\)', lines[top]).group(1))
@@ -102,24 +105,35 @@ def check_patch(name, lines):
 
 
 def check_igemm(name, lines):
-    bm, bn, wm, wn, s, spread = template_ints(name)[:6]
-    lpt = (bm + bn) // (wm * wn * 8)
-    problems = []
+    if 'group_mixed_kernel' in name:
+        # conv_igemm_group_mixed_kernel<Tr>: the 128 x 64 and the 128 x 128 tile function (4 waves, S = 2, early issue), one branch each
+        forms = [(128, 64, 2, 2, 2), (128, 128, 2, 2, 2)]
+    else:
+        bm, bn, wm, wn, s, spread = template_ints(name)[:6]
+        forms = [(bm, bn, wm, wn, s)]
     found = loops(lines)
-    if len(found) != 1:
-        return ['%d K loops found, expected 1' % len(found)]
-    top, n, count, before = found[0]
-    if count is None:
-        return ['loop end not found after line %d' % top]
-    if count != lpt:
-        problems.append('%d LDS-DMA instructions per K step, the protocol counts LPT = %d' % (count, lpt))
-    if n != (s - 2) * lpt:
-        problems.append('vmcnt(%d), expected (S - 2) * LPT = %d' % (n, (s - 2) * lpt))
-    if before != (s - 1) * lpt:
-        problems.append('%d LDS-DMA instructions in the prologue, the first wait assumes (S - 1) * LPT = %d' % (before, (s - 1) * lpt))
+    if len(found) != len(forms):
+        return ['%d K loops found, expected %d' % (len(found), len(forms))]
+    problems, accounted = [], 0
+    want = sorted((bm + bn) // (wm * wn * 8) for bm, bn, wm, wn, s in forms)
+    got = sorted(c for _, _, c, _ in found if c is not None)
+    if len(forms) > 1 and got != want:
+        return ['K loops with %s LDS-DMA instructions per step, expected %s' % (got, want)]
+    for top, n, count, before in found:
+        if count is None:
+            return ['loop end not found after line %d' % top]
+        s = forms[0][4]
+        lpt = count if len(forms) > 1 else want[0]         # mixed kernel: which tile this loop belongs to is read off its own count
+        if count != lpt:
+            problems.append('%d LDS-DMA instructions per K step, the protocol counts LPT = %d' % (count, lpt))
+        if n != (s - 2) * lpt:
+            problems.append('vmcnt(%d), expected (S - 2) * LPT = %d' % (n, (s - 2) * lpt))
+        if before != (s - 1) * lpt:
+            problems.append('%d LDS-DMA instructions in the prologue, the first wait assumes (S - 1) * LPT = %d' % (before, (s - 1) * lpt))
+        accounted += before + count
     total = sum(1 for l in lines if DMA.search(l))
-    if total != before + count:
-        problems.append('%d LDS-DMA instructions outside the prologue and the K loop' % (total - before - count))
+    if total != accounted:
+        problems.append('%d LDS-DMA instructions outside the prologues and the K loops' % (total - accounted))
     return problems
 
 
@@ -141,7 +155,7 @@ def check_file(source):
 
 
 # instantiations the Makefile's build holds (dtypes x tile forms); a different count means the check no longer sees all of them
-EXPECTED = {'conv_patch.hip': 3 * (3 + 3), 'conv_mfma.hip': 4 * (6 + 2)}
+EXPECTED = {'conv_patch.hip': 4 * (3 + 3), 'conv_mfma.hip': 4 * (6 + 3 + 1)}
 
 
 def main():

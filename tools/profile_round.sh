@@ -18,13 +18,14 @@ python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode > $O/bench_cfg2_under_rocprof_inflight2.json 2>> $O/err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --in-flight 1 > $O/bench_cfg2_under_rocprof_inflight1.json 2>> $O/err.txt
 for d in if1 if2; do f=$(ls $O/prof_$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$d.csv; done
-bash tools/pmc_bench.sh $O/pmc --in-flight 1 > $O/pmc.log 2>&1
-cp $O/pmc/traffic_*.json $O/ 2>/dev/null
-bash tools/pmc_mfma.sh $O/pmc > $O/pmc_mfma.log 2>&1
-bash tools/pmc_bench.sh $O/pmc --in-flight 1 --dtype f16x3 > $O/pmc_f16x3.log 2>&1
-bash tools/pmc_mfma.sh $O/pmc --dtype f16x3 > $O/pmc_mfma_f16x3.log 2>&1
-cp $O/pmc/traffic_*.json $O/ 2>/dev/null
-cp $O/pmc/mfma_busy_*.json $O/ 2>/dev/null
+# PMC passes: ONE output directory per dtype (round 3's f16x3 files summed both dtypes' dispatches: same directory, globbed twice);
+# the scripts also remove their counter directories before each pass
+bash tools/pmc_bench.sh $O/pmc_bf16 --in-flight 1 > $O/pmc.log 2>&1
+bash tools/pmc_mfma.sh $O/pmc_bf16 > $O/pmc_mfma.log 2>&1
+bash tools/pmc_bench.sh $O/pmc_f16x3 --in-flight 1 --dtype f16x3 > $O/pmc_f16x3.log 2>&1
+bash tools/pmc_mfma.sh $O/pmc_f16x3 --dtype f16x3 > $O/pmc_mfma_f16x3.log 2>&1
+cp $O/pmc_bf16/traffic_*.json $O/pmc_bf16/traffic_layers_*.txt $O/pmc_bf16/mfma_busy_*.json $O/ 2>/dev/null
+cp $O/pmc_f16x3/traffic_*.json $O/pmc_f16x3/traffic_layers_*.txt $O/pmc_f16x3/mfma_busy_*.json $O/ 2>/dev/null
 python3 tools/post_regimes.py > $O/post_regimes.txt 2>> $O/err.txt
 BATCHES="1 2 4 8 16 32" bash tools/batch_sweep.sh > $O/batch_sweep.txt 2>> $O/err.txt
 # small batches: the two grouped plans of the heads side by side (contexts with max_batch <= 4 take the level plan by default)
@@ -36,7 +37,7 @@ python3 bench.py --no-cpu-baseline --no-parity-mode --batch 1 --in-flight 1 --st
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity-mode --in-flight 1 --batch 1 > $O/bench_cfg2_batch1_under_rocprof.json 2>> $O/err.txt
 f=$(ls $O/prof_b1/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_batch1.csv
 rm -rf $O/prof_b1
-rm -rf $O/prof_if1 $O/prof_if2 $O/pmc/pmc_fetch $O/pmc/pmc_write $O/pmc/pmc_mfma
+rm -rf $O/prof_if1 $O/prof_if2 $O/pmc_*/pmc_fetch $O/pmc_*/pmc_write $O/pmc_*/pmc_mfma
 ls -la $O
 tail -3 $O/pmc.log; tail -30 $O/pmc_mfma.log
 for f in bench_cfg2_default bench_cfg2_inflight1 bench_cfg2_f16x3 bench_cfg2_f16x3_inflight1 bench_cfg2_fp32 bench_cfg4 bench_cfg5 bench_cfg2_torchrun_1rank; do python3 - "$O/$f.json" <<'PY'

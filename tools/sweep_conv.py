@@ -59,6 +59,11 @@ LAYERS = [
     ('b5_left', 20, 20, 512, 512, 3, 1, 1, 0),
     ('b5_cls420', 20, 20, 1024, 420, 3, 1, 1, 0),     # cls_pred with the real 2 x 10 x 21 outputs
     ('b4_cls420', 40, 40, 1024, 420, 3, 1, 1, 0),
+    # Winograd F(2x2, 3x3) upper bound: its 16 transform-domain GEMMs of a 40 x 40 layer at batch 32 are each
+    # M = 32 * 20 * 20 tiles, K = Cin, N = Cout; as ONE launch they have the GEMM shape of this 1x1 conv at --batch 128
+    # (M = 16 * 12 800 rows), transforms free.  `--batch 128 --only wino_`
+    ('wino_conv4_2', 40, 40, 512, 512, 1, 1, 1, 0),
+    ('wino_b4_trio', 40, 40, 512, 1536, 1, 1, 1, 0),
 ]
 
 
