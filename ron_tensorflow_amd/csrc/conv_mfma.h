@@ -106,10 +106,11 @@ constexpr int kGroupMixed = 64;
 size_t dtype_size(int dtype);
 inline bool dtype_is_half(int dtype) { return dtype == RON_DTYPE_BF16 || dtype == RON_DTYPE_F16; }   // 2-byte elements
 
-// conv1_1 (stem.hip): 3 -> 64 channels straight from the fp32 image, bf16 / f16 only
+// conv1_1 (stem.hip): 3 -> 64 channels straight from the fp32 image (bf16 / f16; f16x3: the split-precision form)
 void stem_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* frags);
+float stem_pack_weights_split(const float* hwio, std::vector<uint16_t>* frags);     // RON_DTYPE_F16X3: returns the epilogue's 2^-k
 int launch_stem_conv(const float* x, int n, int h, int w, int dtype, const void* d_wfrag, const float* d_bias,
-                     const TensorView& out, hipStream_t s);
+                     const TensorView& out, hipStream_t s, float oscale = 1.f);
 
 // conv1_1 + conv1_2 + pool1 fused (stem.hip): image -> pool1, bf16 / f16 only
 void stem2_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* lds_image);

@@ -117,6 +117,7 @@ struct ron_ctx {
   int64_t post_ws_bytes = 0;
   void* d_stem_w = nullptr;             // conv1_1 fragments + bias for the dedicated stem kernel (bf16 / f16)
   float* d_stem_b = nullptr;
+  float stem_oscale = 1.f;              // split precision: 2^-k of the stem weights' scale
   void* d_stem2_w = nullptr;            // conv1_2 weights as the LDS image of stem2_kernel (conv1_1 + conv1_2 + pool1 fused)
   void* d_stem2_w1 = nullptr;           // conv1_1 weights as 16x16x32 fragments for stem2_kernel
   float* d_stem2_b = nullptr;
@@ -597,7 +598,7 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
   }
   }
   for (auto& t : c->tensors) {
-    if (t.name == "im2col" && dtype_is_half(cfg->dtype)) continue;      // bf16 / f16 use the stem kernel
+    if (t.name == "im2col" && cfg->dtype != RON_DTYPE_F32) continue;      // bf16 / f16 / f16x3 use the stem kernel
     if ((cfg->flags & RON_CFG_FUSE_POOLS) && (t.name == "conv1_2" || t.name == "conv2_2" || t.name == "conv3_3")) continue;
     if ((cfg->flags & RON_CFG_FUSE_POOLS) && !(cfg->flags & RON_CFG_NO_STEM2) && dtype_is_half(cfg->dtype) && H % 8 == 0 &&
         W % 32 == 0 && t.name == "conv1_1") continue;         // conv1_1 + conv1_2 + pool1 run fused (stem2_kernel)
@@ -707,7 +708,7 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
 #define ATTR() do { c->ops.back().flops += flops - mark; mark = flops; } while (0)
 #define PACK(expr) do { rc = (expr); if (rc < 0) return rc; } while (0)
   // ---- VGG-16 body ----
-  const bool use_stem = dtype_is_half(c->cfg.dtype);      // fp32 / split precision: conv1_1 as im2col + GEMM
+  const bool use_stem = dtype_is_half(c->cfg.dtype) || c->cfg.dtype == RON_DTYPE_F16X3;      // fp32: conv1_1 as im2col + GEMM
   if (!use_stem) {
     Op o; o.kind = OP_IM2COL; o.name = "im2col"; o.out = T("im2col");
     c->ops.push_back(o);
@@ -721,7 +722,8 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       const bool stem = b == 0 && r == 0;
       if (stem && use_stem) {
         std::vector<uint16_t> frags;
-        stem_pack_weights(c->var(scope + "/weights").data.data(), c->cfg.dtype, &frags);
+        if (c->cfg.dtype == RON_DTYPE_F16X3) c->stem_oscale = stem_pack_weights_split(c->var(scope + "/weights").data.data(), &frags);
+        else stem_pack_weights(c->var(scope + "/weights").data.data(), c->cfg.dtype, &frags);
         RON_HIP_CHECK(hipMalloc(&c->d_stem_w, frags.size() * 2));
         RON_HIP_CHECK(hipMemcpy(c->d_stem_w, frags.data(), frags.size() * 2, hipMemcpyHostToDevice));
         RON_HIP_CHECK(hipMalloc((void**)&c->d_stem_b, 64 * sizeof(float)));
@@ -747,7 +749,7 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
       c->ops.back().out = T(pname);
       c->ops.back().name += "+" + pname;
       const size_t n_ops = c->ops.size();
-      if (b == 0 && use_stem && n_ops >= 2 && c->ops[n_ops - 2].kind == OP_STEM && H % 8 == 0 && W % 32 == 0 &&
+      if (b == 0 && dtype_is_half(c->cfg.dtype) && n_ops >= 2 && c->ops[n_ops - 2].kind == OP_STEM && H % 8 == 0 && W % 32 == 0 &&
           !(c->cfg.flags & RON_CFG_NO_STEM2)) {
         // conv1_1 + conv1_2 + pool1 as one kernel (stem.hip): neither full-resolution 64-channel map touches HBM
         std::vector<uint16_t> img;
@@ -1018,6 +1020,7 @@ extern "C" int ron_clone(ron_ctx* src, ron_ctx** out) {
   c->ops = owner->ops;
   c->d_l2_gamma = owner->d_l2_gamma; c->d_stem_w = owner->d_stem_w; c->d_stem_b = owner->d_stem_b;
   c->d_stem2_w = owner->d_stem2_w; c->d_stem2_b = owner->d_stem2_b; c->d_stem2_w1 = owner->d_stem2_w1;
+  c->stem_oscale = owner->stem_oscale;
   c->flops_per_image = owner->flops_per_image;
   c->grouped_launches = owner->grouped_launches;
   c->weights_owner = owner;
@@ -1092,7 +1095,7 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
       if ((rc = launch_im2col_c3(d_images, n, t.H, t.W, c->cfg.dtype, t.d, t.C, s))) return rc;
     } else if (o.kind == OP_STEM) {
       const Tensor& t = c->tensors[o.out];
-      if ((rc = launch_stem_conv(d_images, n, t.H, t.W, c->cfg.dtype, c->d_stem_w, c->d_stem_b, c->view(o.out, n), s))) return rc;
+      if ((rc = launch_stem_conv(d_images, n, t.H, t.W, c->cfg.dtype, c->d_stem_w, c->d_stem_b, c->view(o.out, n), s, c->stem_oscale))) return rc;
     } else if (o.kind == OP_STEM2) {
       const Tensor& t = c->tensors[o.out];
       if ((rc = launch_stem2(d_images, n, 2 * t.H, 2 * t.W, c->cfg.dtype, c->d_stem2_w1, c->d_stem_b, c->d_stem2_w, c->d_stem2_b,

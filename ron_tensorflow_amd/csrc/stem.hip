@@ -132,6 +132,98 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 }
 
 
+// conv1_1 in split precision (RON_DTYPE_F16X3, conv_device.h): the same tiling; A and B are two f16 planes each (hi = rnd(v),
+// lo = rnd(v - hi); the weights times 2^k so that their lo plane is a normal f16, undone by `oscale`), a product is three MFMAs
+// hi*hi + lo*hi + hi*lo into the fp32 accumulator, and a pixel's 64 outputs are stored as two 128-byte chunks [32 x hi][32 x lo].
+// Replaces im2col (173 us at batch 32) + a K = 32 GEMM through the row-gather kernel (276 us): HBM-bound on its 838 MB of output.
+__global__ __launch_bounds__(256) void stem_conv_split_kernel(const float* __restrict__ x, int n_img, int H, int W,
+                                                              const u32x4* __restrict__ wfrag, const float* __restrict__ bias2, float oscale,
+                                                              unsigned* __restrict__ out, int out_Hp, int out_Wp, int out_pad) {
+  __shared__ float s_in[4][kPatch + 14];
+  __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);      // MODE.FP16_OVFL: overflowing f16 conversions saturate (conv_device.h)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  u32x4 wb[2][2][2];                    // [plane: hi, lo][t][s]
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) wb[pl][t][s] = wfrag[((pl * 2 + t) * 2 + s) * 64 + lane];
+  const float b0 = bias2[2 * r], b1 = bias2[2 * r + 1];
+  int a_off[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * s + 8 * h + j;
+      const int ty = k / 9, rem = k - ty * 9;
+      a_off[s][j] = k < 27 ? ty * kPatchW + r * 3 + rem : -1;
+    }
+  float* patch = s_in[wave];
+  const int tiles_per_row = W / 32;
+  const long long n_tiles = (long long)n_img * H * tiles_per_row;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+    const int tx = (int)(tile % tiles_per_row);
+    const long long row = tile / tiles_per_row;
+    const int y = (int)(row % H);
+    const long long img = row / H;
+    const int x0 = tx * 32;
+    for (int i = lane; i < kPatch; i += 64) {
+      const int ty = i / kPatchW, rem = i - ty * kPatchW;
+      const int px = rem / 3, c = rem - px * 3;
+      const int yy = y + ty - 1, xx = x0 + px - 1;
+      float v = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[((img * H + yy) * (long long)W + xx) * 3 + c];
+      patch[i] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    u32x4 fa[2][2];                     // [plane][s]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned short eh[8], el[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = a_off[s][j] >= 0 ? patch[a_off[s][j]] : 0.f;
+        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+        eh[j] = __builtin_bit_cast(unsigned short, hi);
+        el[j] = __builtin_bit_cast(unsigned short, lo);
+      }
+      fa[0][s] = u32x4{(unsigned)eh[0] | ((unsigned)eh[1] << 16), (unsigned)eh[2] | ((unsigned)eh[3] << 16),
+                       (unsigned)eh[4] | ((unsigned)eh[5] << 16), (unsigned)eh[6] | ((unsigned)eh[7] << 16)};
+      fa[1][s] = u32x4{(unsigned)el[0] | ((unsigned)el[1] << 16), (unsigned)el[2] | ((unsigned)el[3] << 16),
+                       (unsigned)el[4] | ((unsigned)el[5] << 16), (unsigned)el[6] | ((unsigned)el[7] << 16)};
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        StemF16::mma(fa[0][s], wb[0][t][s], acc[t]);      // hi * hi
+        StemF16::mma(fa[1][s], wb[0][t][s], acc[t]);      // lo * hi
+        StemF16::mma(fa[0][s], wb[1][t][s], acc[t]);      // hi * lo
+      }
+    }
+    // a pixel = 64 dwords: channel pair r (channels 2r, 2r + 1) -> chunk r / 16: hi dword at chunk * 32 + r % 16, lo dword 16 further
+    const long long obase = ((img * out_Hp + y + out_pad) * (long long)out_Wp + x0 + out_pad) * 64;
+    const int od = (r >> 4) * 32 + (r & 15);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int p = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const float v0 = fmaxf(fmaf(acc[0][e], oscale, b0), 0.f), v1 = fmaxf(fmaf(acc[1][e], oscale, b1), 0.f);
+      const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+      const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+      out[obase + (long long)p * 64 + od] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+      out[obase + (long long)p * 64 + od + 16] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // conv1_1 + conv1_2 + pool1 in one kernel (RON_CFG_FUSE_POOLS, bf16 / f16).
 //
@@ -366,13 +458,34 @@ void stem_pack_weights(const float* hwio, int dtype, std::vector<uint16_t>* frag
         }
 }
 
+// split precision: [plane hi / lo][t][s][lane] fragments of w * 2^k; returns 2^-k for the epilogue
+float stem_pack_weights_split(const float* hwio, std::vector<uint16_t>* frags) {
+  const int k = split_weight_exponent(std::vector<float>(hwio, hwio + 27 * 64));
+  frags->assign(2 * 4 * 64 * 8, 0);
+  for (int t = 0; t < 2; ++t)
+    for (int s = 0; s < 2; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int r = lane & 31, h = lane >> 5;
+          const int kk = 16 * s + 8 * h + j, ch = 2 * r + t;
+          const float v = kk < 27 ? ldexpf(hwio[(size_t)kk * 64 + ch], k) : 0.f;
+          const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+          (*frags)[((size_t)((0 * 2 + t) * 2 + s) * 64 + lane) * 8 + j] = f32_to_f16_rne((float)hi);
+          (*frags)[((size_t)((1 * 2 + t) * 2 + s) * 64 + lane) * 8 + j] = f32_to_f16_rne((float)lo);
+        }
+  return ldexpf(1.f, -k);
+}
+
 int launch_stem_conv(const float* x, int n, int h, int w, int dtype, const void* d_wfrag, const float* d_bias,
-                     const TensorView& out, hipStream_t s) {
-  RON_REQUIRE(dtype == RON_DTYPE_BF16 || dtype == RON_DTYPE_F16, "stem kernel: bf16 / f16 only");
+                     const TensorView& out, hipStream_t s, float oscale) {
+  RON_REQUIRE(dtype == RON_DTYPE_BF16 || dtype == RON_DTYPE_F16 || dtype == RON_DTYPE_F16X3, "stem kernel: bf16 / f16 / f16x3 only");
   RON_REQUIRE(w % 32 == 0 && out.C == 64 && out.cstride == 64 && out.coff == 0 && out.H == h && out.W == w, "stem kernel: bad shape");
   const long long tiles = (long long)n * h * (w / 32);
   const int grid = (int)std::min<long long>((tiles + 3) / 4, 256 * 8);
-  if (dtype == RON_DTYPE_BF16)
+  if (dtype == RON_DTYPE_F16X3)
+    hipLaunchKernelGGL(stem_conv_split_kernel, dim3(grid), dim3(256), 0, s, x, n, h, w, (const u32x4*)d_wfrag, d_bias, oscale,
+                       (unsigned*)out.base, out.Hp(), out.Wp(), out.pad);
+  else if (dtype == RON_DTYPE_BF16)
     hipLaunchKernelGGL(stem_conv_kernel<StemBF16>, dim3(grid), dim3(256), 0, s, x, n, h, w, (const u32x4*)d_wfrag, d_bias,
                        (unsigned*)out.base, out.Hp(), out.Wp(), out.pad);
   else

@@ -117,6 +117,45 @@ def test_conv2d_transpose_2x2(ops, dev, dtype):
     _check(got, ref, dtype)
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'f16x3'])
+def test_conv2d_transpose_2x2_with_residual(ops, dev, dtype):
+    """The reverse connection as the graph runs it since round 4 (nets/ron_vgg_320.py:420-425): the 2x2 stride-2 transposed conv adds
+    its half to the left conv's half in the pixel-shuffle epilogue, relu(relu(deconv + b) + left)."""
+    rs = np.random.RandomState(41)
+    x = rs.randn(3, 5, 5, 128).astype(np.float32)
+    wt = (rs.randn(2, 2, 128, 128) * 0.08).astype(np.float32)        # [kh, kw, Cout, Cin]
+    b = (rs.randn(128) * 0.1).astype(np.float32)
+    left = np.maximum(rs.randn(3, 10, 10, 128), 0).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(np.maximum(orf.conv2d_transpose_np(rnd(x), rnd(wt), 2) + b, 0) + rnd(left), 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, residual=torch.from_numpy(left).to(dev), stride=2, relu=True,
+                          transpose=True, dtype=dtype).cpu().numpy()
+    assert got.shape == (3, 10, 10, 128)
+    _check(got, ref, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'f16x3'])
+@pytest.mark.parametrize('cfg', [0, 7, 2, 9])
+def test_centre_tap_only_columns_in_both_k_orders(ops, dev, cfg, dtype):
+    """A 1x1 branch packed beside 3x3 ones (ConvLaunch::center_from; nets/ron_vgg_320.py:378-397): output channels >= center_from have
+    weights in the centre tap only and their column tiles run that tap's K steps alone.  Round 4: also in the taps-innermost K order
+    (tile configurations 7 and 9), where those tiles keep the tap-major walk of their one tap."""
+    rs = np.random.RandomState(70 + cfg)
+    n, h, w, cin, cout, cf = 5, 20, 20, 128, 512, 256
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(3, 3, cin, cout) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    centre = wt[1, 1, :, cf:].copy()
+    wt[:, :, :, cf:] = 0
+    wt[1, 1, :, cf:] = centre * 3                      # a 1x1 filter in the centre tap of its rows
+    b = (rs.randn(cout) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=cfg, splitk=1, center_from=cf).cpu().numpy()
+    _check(got, ref, dtype)
+    full = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=cfg, splitk=1).cpu().numpy()
+    _check(got, full, dtype)          # the short tiles drop products with exact zeros only
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16', 'f16x3'])
 @pytest.mark.parametrize('hw', [(16, 20), (12, 64), (7, 96)])
 def test_conv_stem_3_channels(ops, dev, dtype, hw):
