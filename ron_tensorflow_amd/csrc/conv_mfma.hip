@@ -367,12 +367,29 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S) > 80 * 10
 // alone leaves most of the chip idle): workgroups [first[k], first[k+1]) run conv k exactly as its own launch would.
 // The descriptions travel in the kernel-argument segment; a workgroup copies its own with scalar loads.
 constexpr int kMaxGroup = kMaxConvGroup;
+// The launch is a list of ENTRIES: entry e = workgroups [first[e], first[e+1]) of the grid = workgroups [ebid0[e], ...) of member
+// eop[e].  A member is one entry, or two when it has centre-tap-only column tiles: its long tiles and its short ones (a ninth of the K
+// steps) are separate entries, so that the host can order ALL long work of the launch before ANY short work - workgroups are
+// dispatched in blockIdx order, and 400 short tiles in front of another member's long ones delayed those by a third of the launch.
+constexpr int kMaxEntries = 2 * kMaxGroup;
 struct ConvGroupArgs {
   ConvArgs op[kMaxGroup];
-  int first[kMaxGroup + 1];
-  int n;
+  int first[kMaxEntries + 1];
+  int eop[kMaxEntries];       // entry -> member
+  int ebid0[kMaxEntries];     // the entry's first workgroup, counted inside the member
+  int enwg[kMaxEntries];      // workgroups of the member as a whole (the tile order is computed from it)
+  int n;                      // members
+  int ne;                     // entries
   unsigned narrow;            // kGroupMixed: bit k set = member k runs on 128 x 64 tiles, else on 128 x 128
 };
+struct GroupPick { int k; unsigned bid, nwg; };
+__device__ __forceinline__ GroupPick pick_group_entry(const ConvGroupArgs& g, int b) {
+  int k = g.eop[0], f = 0, bid0 = g.ebid0[0], nwg = g.enwg[0];
+#pragma unroll
+  for (int j = 1; j < kMaxEntries; ++j)
+    if (j < g.ne && b >= g.first[j]) { k = g.eop[j]; f = g.first[j]; bid0 = g.ebid0[j]; nwg = g.enwg[j]; }
+  return GroupPick{k, (unsigned)(b - f + bid0), (unsigned)nwg};
+}
 // op[k] of the ConvGroupArgs this kernel was launched with (its only argument), read from the kernel-argument segment
 __device__ __forceinline__ ConvArgs load_group_op(int k) {
   static_assert(sizeof(ConvArgs) % 4 == 0, "dword copy");
@@ -388,13 +405,9 @@ __device__ __forceinline__ ConvArgs load_group_op(int k) {
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 __global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S) > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_group_kernel(ConvGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = (int)blockIdx.x;
-  int k = 0;
-#pragma unroll
-  for (int j = 1; j < kMaxGroup; ++j)
-    if (j < g.n && b >= g.first[j]) k = j;
-  const ConvArgs p = load_group_op(k);
-  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD>(p, (unsigned)(b - g.first[k]), (unsigned)(g.first[k + 1] - g.first[k]), smem);
+  const GroupPick e = pick_group_entry(g, (int)blockIdx.x);
+  const ConvArgs p = load_group_op(e.k);
+  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD>(p, e.bid, e.nwg, smem);
 }
 
 // The same with the tile WIDTH chosen per member (kGroupMixed): both 128-row tiles run on 4 waves and fit two workgroups per CU, so
@@ -402,15 +415,10 @@ __global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S) > 80 * 10
 template <class Tr>
 __global__ __launch_bounds__(256, 2) void conv_igemm_group_mixed_kernel(ConvGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = (int)blockIdx.x;
-  int k = 0;
-#pragma unroll
-  for (int j = 1; j < kMaxGroup; ++j)
-    if (j < g.n && b >= g.first[j]) k = j;
-  const ConvArgs p = load_group_op(k);
-  const unsigned bid = (unsigned)(b - g.first[k]), nwg = (unsigned)(g.first[k + 1] - g.first[k]);
-  if ((g.narrow >> k) & 1u) conv_igemm_tile<Tr, 128, 64, 2, 2, 2, 2>(p, bid, nwg, smem);
-  else conv_igemm_tile<Tr, 128, 128, 2, 2, 2, 2>(p, bid, nwg, smem);
+  const GroupPick e = pick_group_entry(g, (int)blockIdx.x);
+  const ConvArgs p = load_group_op(e.k);
+  if ((g.narrow >> e.k) & 1u) conv_igemm_tile<Tr, 128, 64, 2, 2, 2, 2>(p, e.bid, e.nwg, smem);
+  else conv_igemm_tile<Tr, 128, 128, 2, 2, 2, 2>(p, e.bid, e.nwg, smem);
 }
 
 template <class Tr>
@@ -699,7 +707,7 @@ int launch_group_t(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
   const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S);
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), (int)lds));
-  hipLaunchKernelGGL((conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(g.first[g.n]), dim3(WM * WN * 64), lds, s, g);
+  hipLaunchKernelGGL((conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(g.first[g.ne]), dim3(WM * WN * 64), lds, s, g);
   if (any_split) launch_group_finalize<Tr>(g, s);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
@@ -710,7 +718,7 @@ int launch_group_mixed(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
   const size_t lds = (size_t)igemm_lds_bytes(128, 128, 2);
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_group_mixed_kernel<Tr>), (int)lds));
-  hipLaunchKernelGGL((conv_igemm_group_mixed_kernel<Tr>), dim3(g.first[g.n]), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((conv_igemm_group_mixed_kernel<Tr>), dim3(g.first[g.ne]), dim3(256), lds, s, g);
   if (any_split) launch_group_finalize<Tr>(g, s);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
@@ -947,7 +955,28 @@ int launch_conv_group(const ConvLaunch* ls_in, int n, int cfg, void* scratch, in
     a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
     a.pos_major = pick_pos_major(c, mcfg, BM);
     if (c.center_from > 0) RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1), "conv group: bad centre-tap-only columns");
-    g.first[k + 1] = g.first[k] + a.tiles_total * a.splitk;
+  }
+  // entries, longest K chain first (see ConvGroupArgs)
+  struct Ent { int op, bid0, cnt, chain; };
+  Ent ents[kMaxEntries];
+  int ne = 0;
+  for (int k = 0; k < n; ++k) {
+    const ConvArgs& a = g.op[k];
+    const int total = a.tiles_total * a.splitk;
+    if (a.center_from_n > 0 && a.splitk == 1) {
+      const int BN = igemm_bn(group_member_cfg(cfg, ls[k]));
+      const int n_long = (a.tiles_total / a.tiles_n) * (a.center_from_n / BN);
+      ents[ne++] = Ent{k, 0, n_long, a.KT};
+      ents[ne++] = Ent{k, n_long, total - n_long, a.Cin / conv_k_chunk(ls[k].dtype)};
+    } else {
+      ents[ne++] = Ent{k, 0, total, a.kt_split};
+    }
+  }
+  std::stable_sort(ents, ents + ne, [](const Ent& x, const Ent& y) { return x.chain > y.chain; });
+  g.ne = ne;
+  for (int e = 0; e < ne; ++e) {
+    g.eop[e] = ents[e].op; g.ebid0[e] = ents[e].bid0; g.enwg[e] = g.op[ents[e].op].tiles_total * g.op[ents[e].op].splitk;
+    g.first[e + 1] = g.first[e] + ents[e].cnt;
   }
   if (ls[0].dtype == RON_DTYPE_BF16) return launch_group_cfg<TraitsBF16S>(cfg, g, any_split, stream);
   if (ls[0].dtype == RON_DTYPE_F16) return launch_group_cfg<TraitsF16S>(cfg, g, any_split, stream);

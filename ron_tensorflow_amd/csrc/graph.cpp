@@ -30,6 +30,7 @@ using namespace ron;
 namespace {
 
 constexpr float kBnEps = 1e-5f;
+constexpr int kCarrierPlanMinBatch = 24;   // contexts from this max_batch on pack the small head convolutions into the partial rounds of 256 x 256 launches
 constexpr int kLevelPlanMaxBatch = 4;      // contexts up to this max_batch run the heads one launch per dependency level (plan_groups)
 const char* kFeatLayers[4] = {"block7", "block6", "block5", "block4"};
 
@@ -474,10 +475,31 @@ void plan_groups(ron_ctx* c) {
   // apiece, mostly pipeline fill and split-K hand-off) ride in the partial rounds of the level's large member.  The members that are
   // several full rounds of 256 x 256 tiles on their own (block4: conv_left, trio3, inception2, cls_pred) keep launches of their own.
   const int MIX = kGroupMixed;
+  // Batch plan.  G256 = one launch of 256 x 256 tiles (launch_conv_group, kCfgIgemm256): a member that is several rounds of the chip
+  // on its own ends with a partial round (400 tiles = 1.56 rounds, 1200 = 4.69), and the members beside it - whose tiles have the same
+  // or twice the K length - are dispatched into it (longest chains first); everything here has Npad % 256 == 0.  The skinny heads
+  // (Npad = 64) cannot ride on 256-wide tiles: the ones of the three coarse scales share one mixed-width launch.
+  const int G256 = kCfgIgemm256;
   const std::vector<Slot> ron_order = {
-      // fc7 (208 tiles of 256 x 256) and the left conv of block6 (26 tiles x 576 K steps: split-K) both read fc6 and are each short
-      // of one round of the chip: one launch of 256 x 256 tiles
-      {kCfgIgemm256, {"fc7", "block6_conv_left"}},
+      // fc7 (208 tiles) and the left conv of block6 (26 tiles x 576 K steps: split-K) both read fc6 and are each short of one round
+      {G256, {"fc7", "block6_conv_left"}},
+      {MIX, {"block7_conv_left", "block5_conv_left"}},
+      {MIX, {"block7_trio3", "block6_deconv_right"}},
+      {G256, {"block4_conv_left", "block6_trio3", "block7_inception2", "block5_deconv_right"}},
+      {G256, {"block5_trio3", "block6_inception2", "block7_cls_pred", "block4_deconv_right"}},
+      {MIX, {"block7_objectness_score", "block7_loc_pred", "block6_objectness_score", "block6_loc_pred", "block5_objectness_score",
+             "block5_loc_pred"}},
+      {G256, {"block4_trio3", "block5_inception2", "block6_cls_pred"}},
+      // Cout = 20 / 40 over channel slices of the same tensor: one launch of the halo-patch kernel (400 workgroups; 200 each alone)
+      {kCfgPatch64, {"block4_objectness_score", "block4_loc_pred"}},
+      {G256, {"block4_inception2", "block5_cls_pred"}},
+      {-1, {"block4_cls_pred"}},
+  };
+  // Medium batches (max_batch 5 .. kCarrierPlanMinBatch - 1): the large members are not several rounds of 256 x 256 tiles there, so a
+  // dependency level is one mixed-width launch (128-row tiles), the free left convs being the carriers of the first levels
+  // (batch 8 / 16, one in flight: 2.02 -> 1.94 ms, 3.18 -> 3.08 ms; the 256 x 256 groups above measured 2.08 / 3.23 there).
+  const std::vector<Slot> ron_mid = {
+      {G256, {"fc7", "block6_conv_left"}},
       {MIX, {"block7_conv_left", "block5_conv_left"}},
       {MIX, {"block7_trio3", "block6_deconv_right"}},
       {MIX, {"block7_objectness_score", "block7_inception2", "block7_loc_pred", "block6_trio3", "block5_deconv_right"}},
@@ -486,7 +508,6 @@ void plan_groups(ron_ctx* c) {
       {MIX, {"block6_cls_pred", "block5_objectness_score", "block5_loc_pred", "block5_inception2"}},
       {-1, {"block4_trio3"}},
       {-1, {"block5_cls_pred"}},
-      // Cout = 20 / 40 over channel slices of the same tensor: one launch of the halo-patch kernel (400 workgroups; 200 each alone)
       {kCfgPatch64, {"block4_objectness_score", "block4_loc_pred"}},
       {-1, {"block4_inception2"}},
       {-1, {"block4_cls_pred"}},
@@ -505,7 +526,7 @@ void plan_groups(ron_ctx* c) {
   };
   const bool levels = !(c->cfg.flags & RON_CFG_BATCH_GROUPS) &&
                       ((c->cfg.flags & RON_CFG_LEVEL_GROUPS) || c->cfg.max_batch <= kLevelPlanMaxBatch);
-  const std::vector<Slot>& order = c->is_ssd() ? ssd_order : (levels ? ron_levels : ron_order);
+  const std::vector<Slot>& order = c->is_ssd() ? ssd_order : (levels ? ron_levels : (c->cfg.max_batch >= kCarrierPlanMinBatch ? ron_order : ron_mid));
   std::map<std::string, int> at;
   for (size_t i = 0; i < c->ops.size(); ++i) at[c->ops[i].name] = (int)i;
   size_t first_head = c->ops.size(), n_named = 0;

@@ -316,19 +316,25 @@ def test_grouped_launch_plan_is_active(pkg, dev, weights_reduced, weights_full, 
     """The grouped head launches are keyed on op names inside libron_hip (plan_groups): a rename in the graph builder would
     silently fall back to one launch per convolution (-7 % of the step) while every equivalence test still passed.  Read the plan."""
     w = weights_reduced if variant == 'reducedfc' else weights_full
-    net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=8, fuse_pools=True).load_weights(w)
+    net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=24, fuse_pools=True).load_weights(w)
     plan = net.launch_plan()
     groups = [n for n in plan if n.startswith('group[')]
-    assert net.grouped_launches() == 7 and len(groups) == 7, plan
-    # one launch per dependency level of the coarse scales, each with a large "carrier" member (round 4: the left conv of a reverse
-    # connection is off the chain, so conv_left(i) rides with the level before its deconv_right(i))
-    assert groups == ['group[fc7+1]', 'group[block7_conv_left+1]', 'group[block7_trio3+1]', 'group[block7_objectness_score+4]',
-                      'group[block7_cls_pred+5]', 'group[block6_cls_pred+3]', 'group[block4_objectness_score+1]'], groups
+    assert net.grouped_launches() == 9 and len(groups) == 9, plan
+    # round 4: the left conv of a reverse connection is off the coarse -> fine chain; the small convolutions of a dependency level
+    # ride in the partial rounds of a large one (256 x 256 groups) or share a mixed-width launch
+    assert groups == ['group[fc7+1]', 'group[block7_conv_left+1]', 'group[block7_trio3+1]', 'group[block4_conv_left+3]',
+                      'group[block5_trio3+3]', 'group[block7_objectness_score+5]', 'group[block4_trio3+2]',
+                      'group[block4_objectness_score+1]', 'group[block4_inception2+1]'], groups
     assert plan[0] == 'conv1_1+conv1_2+pool1' and plan[-1] == 'post_np'
     launches = [n for n in plan[:-1] if not n.startswith('(')]
-    assert len(launches) == 27, (len(launches), launches)       # fused stem + 13 backbone convs / pools + fc6 + {fc7, block6_conv_left} + 11 head launches
+    assert len(launches) == 25, (len(launches), launches)       # fused stem + 13 backbone convs / pools + fc6 + 10 launches from fc7 on
+    mid = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=8, fuse_pools=True).load_weights(w)      # 5 <= max_batch < 24
+    assert [n for n in mid.launch_plan() if n.startswith('group[')] == [
+        'group[fc7+1]', 'group[block7_conv_left+1]', 'group[block7_trio3+1]', 'group[block7_objectness_score+4]',
+        'group[block7_cls_pred+5]', 'group[block6_cls_pred+3]', 'group[block4_objectness_score+1]']
+    mid.close()
     clone = net.clone()
-    assert clone.launch_plan() == plan and clone.grouped_launches() == 7
+    assert clone.launch_plan() == plan and clone.grouped_launches() == 9
     clone.close()
     net.close()
     net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=1, fuse_pools=True, group_heads=False).load_weights(w)
