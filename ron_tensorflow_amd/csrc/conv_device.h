@@ -65,6 +65,9 @@ struct ConvArgs {
   // Column tiles at or beyond output channel center_from_n (0: none) hold a 1x1 branch whose weights sit in the centre tap of the
   // kh x kw filter, zeros elsewhere: they run the K steps of that tap only.
   int center_from_n;
+  // K order: 0 = tap-major (step = tap * chunks + chunk), 1 = chunk-major with the taps innermost (consecutive steps re-read almost the
+  // same input lines one pixel over: the re-reads hit L2).  Centre-tap-only column tiles always walk their one tap tap-major.
+  int taps_inner;
 };
 
 // MFMA shape of a traits class: kMT x kMT output tile per instruction (32: v_mfma_f32_32x32x16, 16 accumulator registers;
@@ -394,6 +397,7 @@ inline void fill_conv_args(const ConvLaunch& c, ConvArgs* out) {
   a.m_fastest = 0;
   a.pos_major = 0; a.n_img = c.in.N; a.in_H = c.in.H; a.cpad = c.cpad; a.kh = c.kh;
   a.center_from_n = c.center_from;
+  a.taps_inner = 0;
   *out = a;
 }
 

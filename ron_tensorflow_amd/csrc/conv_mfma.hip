@@ -53,10 +53,11 @@ __device__ __forceinline__ void pin_ksteps() {
 
 // Tile configuration: BM x BN block tile, WM x WN waves (each wave owns (BM/WM) x (BN/WN)), S LDS stages.
 // SPREAD 1: the LDS-DMA pieces of a tile are shared out over the k-steps of the stage; 2: all go out during k-step 0.
-// TI: K ordered chunk-major with the taps innermost (see below).
+// The K order (tap-major, or chunk-major with the taps innermost: ConvArgs::taps_inner, see below) is a run-time property of the
+// launch: wave-uniform bookkeeping of a few scalar instructions per step.
 // One tile of launch `p`: workgroup `bid` of the `nwg` that launch consists of (a launch of its own, or a range of the
 // workgroups of a grouped launch).
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, bool TI = false>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigned bid, const unsigned nwg, char* smem) {
   constexpr int kLanesPerRow = kRowBytes / 16;       // 16-byte chunks per row
   constexpr int MT = Tr::kMT;                        // MFMA output tile (16)
@@ -212,7 +213,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   // or -1 % on the wide ones (profiles/r02/sweep_conv_exp_v4_tapsinner.txt); conv_pick_igemm_cfg selects it accordingly.
   // A column tile that runs the centre tap only (ConvArgs::center_from_n) walks that tap's chunks in the tap-major numbering whatever
   // the launch's order: its [kt0, kt1) is a contiguous range there.
-  const bool ti = TI && !center_only;
+  const bool ti = p.taps_inner != 0 && !center_only;
   const int n_taps = p.KT / chunks_per_tap;
   const int tap0 = ti ? kt0 % n_taps : kt0 / chunks_per_tap;
   int ky = tap0 / p.kw, kx = tap0 - (tap0 / p.kw) * p.kw;
@@ -357,10 +358,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
 
 constexpr int igemm_lds_bytes(int BM, int BN, int S) { return S * (BM + BN) * kRowBytes + 3 * BM * (int)sizeof(int); }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, bool TI = false>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 __global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S) > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD, TI>(p, blockIdx.x, gridDim.x, smem);
+  conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD>(p, blockIdx.x, gridDim.x, smem);
 }
 
 // Several independent small convolutions in ONE launch (the per-scale head layers of the coarse scales, each of which
@@ -485,12 +486,12 @@ __global__ void splitk_finalize_group_kernel(ConvGroupArgs g) {
   if (p.splitk > 1) splitk_finalize_body<Tr>(p);
 }
 
-template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD, bool TI = false>
+template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 int launch_t(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S);
   static PerDeviceOnce once;
-  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, TI>), (int)lds));
-  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD, TI>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
+  RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), (int)lds));
+  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
   RON_HIP_CHECK(hipGetLastError());
   return RON_OK;
 }
@@ -499,12 +500,10 @@ int launch_t(const ConvArgs& a, hipStream_t s) {
 template <class Tr>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   switch (cfg) {
-    case kCfgIgemm256: return launch_t<Tr, 256, 256, 4, 2, 2, 1>(a, s);
+    case kCfgIgemm256: case kCfgIgemm256TapsInner: return launch_t<Tr, 256, 256, 4, 2, 2, 1>(a, s);      // (the K order: ConvArgs::taps_inner)
     case kCfgIgemm128: return launch_t<Tr, 128, 128, 2, 2, 2, 1>(a, s);
-    case kCfgIgemm128Early: return launch_t<Tr, 128, 128, 2, 2, 2, 2>(a, s);
+    case kCfgIgemm128Early: case kCfgIgemm128EarlyTapsInner: return launch_t<Tr, 128, 128, 2, 2, 2, 2>(a, s);
     case kCfgIgemm128x64: return launch_t<Tr, 128, 64, 2, 2, 2, 2>(a, s);
-    case kCfgIgemm256TapsInner: return launch_t<Tr, 256, 256, 4, 2, 2, 1, true>(a, s);
-    case kCfgIgemm128EarlyTapsInner: return launch_t<Tr, 128, 128, 2, 2, 2, 2, true>(a, s);
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;
@@ -672,6 +671,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   }
   a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
   a.pos_major = pick_pos_major(c, cfg, BM);
+  a.taps_inner = conv_cfg_taps_inner(cfg) ? 1 : 0;
   if (c.center_from > 0)
     RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1) && c.up == 0,
                 "conv: centre-tap-only columns need an odd filter and a boundary on the N tile (%d)", BN);
@@ -954,6 +954,11 @@ int launch_conv_group(const ConvLaunch* ls_in, int n, int cfg, void* scratch, in
     }
     a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
     a.pos_major = pick_pos_major(c, mcfg, BM);
+    // K order of the member, by the rules of a launch of its own (conv_pick_cfg): taps innermost for stride-1 filters that neither
+    // split K nor skip filter rows - on the 256 x 256 tile where the long columns are at most two tiles wide, on 128 x 128 always
+    const int n_long = c.center_from > 0 ? c.center_from : c.Npad;
+    a.taps_inner = (c.kh * c.kw > 1 && c.up == 0 && c.stride == 1 && a.splitk == 1 && !a.pos_major &&
+                    (mcfg == kCfgIgemm128 || (mcfg == kCfgIgemm256 && n_long <= 512))) ? 1 : 0;
     if (c.center_from > 0) RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1), "conv group: bad centre-tap-only columns");
   }
   // entries, longest K chain first (see ConvGroupArgs)
