@@ -38,6 +38,7 @@ PEAK_F16_TFLOPS = 2500.0
 PEAK_F32_TFLOPS = 157.3
 PEAK_F16X3_TFLOPS = 2500.0 / 3   # split precision: three f16 MFMAs per algorithmic product
 PROFILED_STEPS = 3
+PARITY_WARMUP = 10
 
 
 def parse():
@@ -55,7 +56,7 @@ def parse():
     ap.add_argument('--no-parity-mode', action='store_true',
                     help='skip the second, untimed-by-the-headline leg that runs the same workload in the arithmetic that meets '
                          'north_star\'s 1e-4 clause (dtype f16x3) and reports it as "parity_mode"')
-    ap.add_argument('--parity-steps', type=int, default=10)
+    ap.add_argument('--parity-steps', type=int, default=20)
     ap.add_argument('--cpu-images', type=int, default=6, help='images run one by one (batch 1) in the bounded CPU-baseline sample; '
                     'one batch of up to --batch images follows')
     ap.add_argument('--multi-stream', action='store_true',
@@ -189,10 +190,11 @@ def parity_mode_leg(args, ron_class, ron_params, weights, images, dev, detect_ar
     in_flight = max(1, args.in_flight)
     pipe = DetectPipeline(net, slots=in_flight, top_k=top_k)
     steps = max(1, args.parity_steps)
-    res = parallel.bench_loop(pipe, images, steps, 3, in_flight, detect_args, top_k, device=dev)
+    # (the GPU idled through the cpu_baseline leg: enough warm-up steps for the clocks to come back up before the timed ones)
+    res = parallel.bench_loop(pipe, images, steps, PARITY_WARMUP, in_flight, detect_args, top_k, device=dev)
     dt, det = res['dt'], res['det']
     tflops = net.flops_per_image() * args.batch * steps / dt / 1e12
-    out = {'dtype': dtype, 'images_per_s': args.batch * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'warmup': 3,
+    out = {'dtype': dtype, 'images_per_s': args.batch * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'warmup': PARITY_WARMUP,
            'batches_in_flight': in_flight, 'conv_stack_tflops': tflops, 'peak_tflops': PEAK_F16X3_TFLOPS,
            'roofline_frac_of_833': tflops / PEAK_F16X3_TFLOPS,
            'note': 'same weights, images, pipeline and loop as the headline, run after its timed region; three f16 MFMAs per '

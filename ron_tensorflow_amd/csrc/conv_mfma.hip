@@ -545,12 +545,16 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
 // Default tile of the row-gather kernel, from tools/sweep_conv.py on MI355X at batch 32 (profiles/r01/sweep_*.txt).
 // The 256x256 tile wins once it yields >= ~160 workgroups; below that the grid is the problem and the 128x128 /
 // 2-workgroups-per-CU form keeps more CUs busy.
+constexpr int kTapsInnerMaxN = 2048;       // widest run of long columns the taps-innermost K order is chosen for
 int conv_pick_igemm_cfg(int M, int Npad, int taps, int K, bool may_split) {
   const int tm256 = (M + 255) / 256;
   if (Npad % 128 != 0) return kCfgIgemm128x64;
   if (Npad % 256 == 0) {
     const int t256 = tm256 * (Npad / 256);
-    if (t256 >= 160) return (taps > 1 && Npad <= 512) ? kCfgIgemm256TapsInner : kCfgIgemm256;
+    // taps innermost: worth 1-6 % of the run time up to two column tiles, time-neutral on wider layers (trio3: six long column tiles,
+    // 669 vs 660 us) where it still cuts the fabric reads by a fifth (profiles/r04/sweep_taps_inner_all.txt); conv_pick_cfg takes it
+    // back where skipping halo filter rows is worth more (fc6: 514 us tap-major with skipping, 567 us taps-innermost)
+    if (t256 >= 160) return (taps > 1 && Npad <= kTapsInnerMaxN) ? kCfgIgemm256TapsInner : kCfgIgemm256;
     // few fat tiles with a long K (in elements: the split-precision and fp32 forms take twice the steps for the same K): split-K
     // fills the chip with them too, at twice the arithmetic per staged byte of the 128 x 128 tiles (tools/sweep_conv.py, round 3:
     // block6_conv_left 26 tiles x 36 864 132 -> 126 us, fc6 at batch 8 214 -> 191, cls_pred / inception2 shapes of 50-100 tiles x 9 216
@@ -618,7 +622,7 @@ int conv_pick_cfg(const ConvLaunch& c) {
   const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, c.kh * c.kw * c.in.C, may_split);
   // taps innermost: only for the stride-1 convolutions it has been measured and tested on (the stride-2 3x3 convolutions of SSD-512's
   // extra blocks keep the tap-major order).  Centre-tap-only column tiles of such a launch keep the tap-major walk of their one tap.
-  if (cfg == kCfgIgemm256TapsInner && c.stride != 1) return kCfgIgemm256;
+  if (cfg == kCfgIgemm256TapsInner && (c.stride != 1 || pick_pos_major(c, kCfgIgemm256, 256))) return kCfgIgemm256;
   if (cfg == kCfgIgemm128Early && c.kh * c.kw > 1 && c.up == 0 && c.stride == 1) {
     // taps innermost for the 128 x 128 tile too (consecutive steps re-read almost the same input lines): 3-6 % on launches that do
     // not split K (with split-K it loses: conv5_1 at batch 4 +10 %), and where no filter rows can be skipped instead
@@ -958,7 +962,7 @@ int launch_conv_group(const ConvLaunch* ls_in, int n, int cfg, void* scratch, in
     // split K nor skip filter rows - on the 256 x 256 tile where the long columns are at most two tiles wide, on 128 x 128 always
     const int n_long = c.center_from > 0 ? c.center_from : c.Npad;
     a.taps_inner = (c.kh * c.kw > 1 && c.up == 0 && c.stride == 1 && a.splitk == 1 && !a.pos_major &&
-                    (mcfg == kCfgIgemm128 || (mcfg == kCfgIgemm256 && n_long <= 512))) ? 1 : 0;
+                    (mcfg == kCfgIgemm128 || (mcfg == kCfgIgemm256 && n_long <= kTapsInnerMaxN))) ? 1 : 0;
     if (c.center_from > 0) RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1), "conv group: bad centre-tap-only columns");
   }
   // entries, longest K chain first (see ConvGroupArgs)

@@ -31,7 +31,7 @@ namespace {
 
 constexpr float kBnEps = 1e-5f;
 constexpr int kCarrierPlanMinBatch = 24;   // contexts from this max_batch on pack the small head convolutions into the partial rounds of 256 x 256 launches
-constexpr int kLevelPlanMaxBatch = 4;      // contexts up to this max_batch run the heads one launch per dependency level (plan_groups)
+constexpr int kLevelPlanMaxBatch = 12;      // contexts up to this max_batch run the heads one launch per dependency level (plan_groups)
 const char* kFeatLayers[4] = {"block7", "block6", "block5", "block4"};
 
 struct Var {
@@ -495,7 +495,7 @@ void plan_groups(ron_ctx* c) {
       {G256, {"block4_inception2", "block5_cls_pred"}},
       {-1, {"block4_cls_pred"}},
   };
-  // Medium batches (max_batch 5 .. kCarrierPlanMinBatch - 1): the large members are not several rounds of 256 x 256 tiles there, so a
+  // Medium batches (max_batch kLevelPlanMaxBatch + 1 .. kCarrierPlanMinBatch - 1): the large members are not several rounds of 256 x 256 tiles there, so a
   // dependency level is one mixed-width launch (128-row tiles), the free left convs being the carriers of the first levels
   // (batch 8 / 16, one in flight: 2.02 -> 1.94 ms, 3.18 -> 3.08 ms; the 256 x 256 groups above measured 2.08 / 3.23 there).
   const std::vector<Slot> ron_mid = {
@@ -514,7 +514,9 @@ void plan_groups(ron_ctx* c) {
   };
   // Small batches (RON_CFG_LEVEL_GROUPS, the default when max_batch <= kLevelPlanMaxBatch): every head convolution is a
   // latency-bound launch of a few hundred workgroups (25-40 us each with its split-K finalize, whatever its size), so
-  // the heads go out one launch per dependency level, the large convolutions included: 16 head launches -> 7.
+  // the heads go out one launch per dependency level, the large convolutions included: 16 head launches -> 7.  Since the left
+  // convs left the chain (round 4) this wins up to batch 12 with one or two batches in flight (batch 8: 1.76 vs 1.91 ms, batch 12:
+  // 2.44 vs 2.64 ms); from 16 on two batches in flight prefer the plans above (2.47 vs 2.56 ms), one in flight still this one.
   const std::vector<Slot> ron_levels = {
       {MIX, {"block7_conv_left", "block6_conv_left", "block5_conv_left", "block4_conv_left"}},
       {MIX, {"block7_trio3", "block6_deconv_right"}},

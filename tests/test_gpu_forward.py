@@ -328,7 +328,7 @@ def test_grouped_launch_plan_is_active(pkg, dev, weights_reduced, weights_full, 
     assert plan[0] == 'conv1_1+conv1_2+pool1' and plan[-1] == 'post_np'
     launches = [n for n in plan[:-1] if not n.startswith('(')]
     assert len(launches) == 25, (len(launches), launches)       # fused stem + 13 backbone convs / pools + fc6 + 10 launches from fc7 on
-    mid = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=8, fuse_pools=True).load_weights(w)      # 5 <= max_batch < 24
+    mid = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=16, fuse_pools=True).load_weights(w)      # 12 < max_batch < 24
     assert [n for n in mid.launch_plan() if n.startswith('group[')] == [
         'group[fc7+1]', 'group[block7_conv_left+1]', 'group[block7_trio3+1]', 'group[block7_objectness_score+4]',
         'group[block7_cls_pred+5]', 'group[block6_cls_pred+3]', 'group[block4_objectness_score+1]']
@@ -340,7 +340,7 @@ def test_grouped_launch_plan_is_active(pkg, dev, weights_reduced, weights_full, 
     net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=1, fuse_pools=True, group_heads=False).load_weights(w)
     assert net.grouped_launches() == 0 and not any(n.startswith('group[') for n in net.launch_plan())
     net.close()
-    # small contexts (max_batch <= 4): the heads go out one launch per dependency level, the large convolutions grouped too
+    # small contexts (max_batch <= 12): the heads go out one launch per dependency level, the large convolutions grouped too
     net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=4, fuse_pools=True).load_weights(w)
     plan = net.launch_plan()
     groups = [n for n in plan if n.startswith('group[')]
@@ -466,6 +466,31 @@ def test_grouped_head_launches_match_one_launch_per_conv(pkg, dev, weights_reduc
     for name in ('block7_ref', 'block6_ref', 'block5_ref', 'block4_ref'):
         assert _rel_err(a.end_point(name, 2).cpu().numpy(), b.end_point(name, 2).cpu().numpy()) <= tol, name
     # grouped launches are deterministic: same bits on a second run
+    ha2 = a.forward_heads(x)
+    for ta, tb in zip(ha, ha2):
+        for u, v in zip(ta, tb):
+            assert torch.equal(u, v)
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize('max_batch,n', [(24, 24), (16, 13)])
+@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-5), ('f16x3', 2e-5)])
+def test_carrier_and_mid_plans_match_one_launch_per_conv(pkg, dev, weights_reduced, max_batch, n, dtype, tol):
+    """The launch plans of larger contexts (csrc/graph.cpp plan_groups: max_batch >= 24 packs the small head convolutions into the
+    partial rounds of 256 x 256 launches - kCfgIgemm256 groups, entries ordered long tiles first -; 13..23 runs a dependency level as
+    one mixed-width launch) against RON_CFG_NO_GROUPS at a batch that fills them, in the arithmetic where equality is tight; twice, for
+    determinism (split-K factors of a group come from a schedule model and are cached per batch)."""
+    x = torch.from_numpy(pkg['W'].synthetic_images(n, seed=77)).to(dev)
+    a = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=max_batch, fuse_pools=True).load_weights(weights_reduced)
+    b = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=max_batch, fuse_pools=True, group_heads=False).load_weights(weights_reduced)
+    assert a.grouped_launches() == (9 if max_batch >= 24 else 7) and b.grouped_launches() == 0
+    ha, hb = a.forward_heads(x), b.forward_heads(x)
+    for ta, tb in zip(ha, hb):
+        for u, v in zip(ta, tb):
+            assert _rel_err(u.cpu().numpy(), v.cpu().numpy()) <= tol
+    for name in ('block7', 'block7_ref', 'block6_ref', 'block5_ref', 'block4_ref'):
+        assert _rel_err(a.end_point(name, n).cpu().numpy(), b.end_point(name, n).cpu().numpy()) <= tol, name
     ha2 = a.forward_heads(x)
     for ta, tb in zip(ha, ha2):
         for u, v in zip(ta, tb):

@@ -21,7 +21,7 @@ def opt(name, default):
     return args[args.index(name) + 1] if name in args else default
 key = '%s_%s_bs%s' % (opt('--variant', 'full'), opt('--dtype', 'bf16'), opt('--batch', '32'))
 CONV = ('conv_igemm', 'conv3x3_patch', 'conv3x3_c64')             # every conv launch, grouped ones included (the headline set)
-STEM = ('stem2_kernel', 'stem_conv_kernel')                        # the fused stem: a row of the per-launch table, not of the headline
+STEM = ('stem2_kernel', 'stem_conv_kernel', 'stem_conv_split_kernel')                        # the fused stem: a row of the per-launch table, not of the headline
 tot, seq = {}, {}
 for which in ('fetch', 'write'):
     rows = []
