@@ -481,11 +481,16 @@ void plan_groups(ron_ctx* c) {
   // (Npad = 64) cannot ride on 256-wide tiles: the ones of the three coarse scales share one mixed-width launch.
   const int G256 = kCfgIgemm256;
   const std::vector<Slot> ron_order = {
-      // fc7 (208 tiles) and the left conv of block6 (26 tiles x 576 K steps: split-K) both read fc6 and are each short of one round
+      // the left conv of block4 reads conv4_3 only: its 400 tiles (1.56 rounds) carry conv5_1's 100 (0.39 of a round on its own)
+      {G256, {"conv5_1", "block4_conv_left"}},
+      {-1, {"conv5_2"}}, {-1, {"conv5_3"}}, {-1, {"pool5"}}, {-1, {"fc6"}},
+      // fc7 (208 tiles) and the left conv of block6 (26 tiles x 576 K steps: split-K) both read fc6 and are each short of one round.
+      // (The left conv of block5 on the 48 CUs fc6 leaves idle - {fc6, block5_conv_left} - measured 531 us for the pair where fc6 alone
+      // takes 513: -42 us per step with one batch in flight, but -0.85 % images/s with two, where the other batch uses those CUs.)
       {G256, {"fc7", "block6_conv_left"}},
       {MIX, {"block7_conv_left", "block5_conv_left"}},
       {MIX, {"block7_trio3", "block6_deconv_right"}},
-      {G256, {"block4_conv_left", "block6_trio3", "block7_inception2", "block5_deconv_right"}},
+      {MIX, {"block6_trio3", "block7_inception2", "block5_deconv_right"}},
       {G256, {"block5_trio3", "block6_inception2", "block7_cls_pred", "block4_deconv_right"}},
       {MIX, {"block7_objectness_score", "block7_loc_pred", "block6_objectness_score", "block6_loc_pred", "block5_objectness_score",
              "block5_loc_pred"}},

@@ -319,22 +319,23 @@ def test_grouped_launch_plan_is_active(pkg, dev, weights_reduced, weights_full, 
     net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=24, fuse_pools=True).load_weights(w)
     plan = net.launch_plan()
     groups = [n for n in plan if n.startswith('group[')]
-    assert net.grouped_launches() == 9 and len(groups) == 9, plan
-    # round 4: the left conv of a reverse connection is off the coarse -> fine chain; the small convolutions of a dependency level
-    # ride in the partial rounds of a large one (256 x 256 groups) or share a mixed-width launch
-    assert groups == ['group[fc7+1]', 'group[block7_conv_left+1]', 'group[block7_trio3+1]', 'group[block4_conv_left+3]',
+    assert net.grouped_launches() == 10 and len(groups) == 10, plan
+    # round 4: the left conv of a reverse connection reads a backbone map only and is off the coarse -> fine chain: the left convs are
+    # the carriers of conv5_1 and fc7 (256 x 256 groups), and the small convolutions of a dependency level ride in the partial
+    # rounds of a large one or share a mixed-width launch
+    assert groups == ['group[conv5_1+1]', 'group[fc7+1]', 'group[block7_conv_left+1]', 'group[block7_trio3+1]', 'group[block6_trio3+2]',
                       'group[block5_trio3+3]', 'group[block7_objectness_score+5]', 'group[block4_trio3+2]',
                       'group[block4_objectness_score+1]', 'group[block4_inception2+1]'], groups
     assert plan[0] == 'conv1_1+conv1_2+pool1' and plan[-1] == 'post_np'
     launches = [n for n in plan[:-1] if not n.startswith('(')]
-    assert len(launches) == 25, (len(launches), launches)       # fused stem + 13 backbone convs / pools + fc6 + 10 launches from fc7 on
+    assert len(launches) == 25, (len(launches), launches)       # fused stem + 9 launches up to pool4 + 15 from conv5_1 on
     mid = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=16, fuse_pools=True).load_weights(w)      # 12 < max_batch < 24
     assert [n for n in mid.launch_plan() if n.startswith('group[')] == [
         'group[fc7+1]', 'group[block7_conv_left+1]', 'group[block7_trio3+1]', 'group[block7_objectness_score+4]',
         'group[block7_cls_pred+5]', 'group[block6_cls_pred+3]', 'group[block4_objectness_score+1]']
     mid.close()
     clone = net.clone()
-    assert clone.launch_plan() == plan and clone.grouped_launches() == 9
+    assert clone.launch_plan() == plan and clone.grouped_launches() == 10
     clone.close()
     net.close()
     net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=1, fuse_pools=True, group_heads=False).load_weights(w)
@@ -484,7 +485,7 @@ def test_carrier_and_mid_plans_match_one_launch_per_conv(pkg, dev, weights_reduc
     x = torch.from_numpy(pkg['W'].synthetic_images(n, seed=77)).to(dev)
     a = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=max_batch, fuse_pools=True).load_weights(weights_reduced)
     b = pkg['ron'].RONNet(variant='reducedfc', dtype=dtype, max_batch=max_batch, fuse_pools=True, group_heads=False).load_weights(weights_reduced)
-    assert a.grouped_launches() == (9 if max_batch >= 24 else 7) and b.grouped_launches() == 0
+    assert a.grouped_launches() == (10 if max_batch >= 24 else 7) and b.grouped_launches() == 0
     ha, hb = a.forward_heads(x), b.forward_heads(x)
     for ta, tb in zip(ha, hb):
         for u, v in zip(ta, tb):
