@@ -135,6 +135,9 @@ struct ron_ctx {
   // split-K factors of the grouped launches, planned once per (first op of the group, batch) - conv_group_plan models the launch's
   // schedule, which is far too slow for the enqueue path: [op index] -> [batch] -> factors (first = 0: not planned yet)
   std::map<int, std::vector<std::array<int, kMaxConvGroup>>> group_sk;
+  // conv4_3 / conv5_3 with their pool from the same launch (Op::fuse_next_pool): decided once per (op, batch) - the answer is "the
+  // two-output launch would not split K", which takes a tile-configuration pick: [op index] -> [batch] -> -1 unknown / 0 / 1
+  std::map<int, std::vector<signed char>> fuse_pool_ok;
   std::vector<std::vector<hipEvent_t>> pending;       // per recorded call: one event per stamp ...
   std::vector<std::vector<int>> pending_ops;          // ... and what it marks: op index (its start), -1 = end of a lane,
                                                       //     -2 / -3 = start / end of the post-processing stage
@@ -1160,7 +1163,10 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
         // (The pool inside the split-K finalize pass instead was measured at batch 1: conv4_3 30.9 + pool4 8.7 us -> 40.9 us, no gain.)
         ConvLaunch F = L;
         F.out2 = L.out;                           // the kernel choice of a two-output launch (row-gather kernel only) ...
-        if (conv_scratch_bytes(F) == 0) {         // ... would not split K at this batch
+        std::vector<signed char>& ok = c->fuse_pool_ok[(int)oi];
+        if (ok.empty()) ok.assign(c->cfg.max_batch + 1, (signed char)-1);
+        if (ok[n] < 0) ok[n] = conv_scratch_bytes(F) == 0 ? 1 : 0;      // ... would not split K at this batch
+        if (ok[n] == 1) {
           F.out = c->view(c->ops[oi + 1].out, n);
           F.pool = 1;
           L = F;

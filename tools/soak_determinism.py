@@ -17,7 +17,8 @@ def main():
     dev = torch.device('cuda:0')
     bad = 0
     for variant, dtype, batch in (('full', 'bf16', 32), ('full', 'f16x3', 32), ('full', 'fp32', 8), ('reducedfc', 'fp16', 64),
-                                  ('full', 'bf16', 1), ('full', 'bf16', 4), ('full', 'fp32', 2), ('ssd512', 'bf16', 16)):
+                                  ('full', 'bf16', 1), ('full', 'bf16', 4), ('full', 'fp32', 2), ('ssd512', 'bf16', 16),
+                                  ('full', 'bf16', 16), ('full', 'f16x3', 12)):      # the mid (13..23) and level (<= 12) launch plans
         ssd = variant == 'ssd512'
         cls = nets_factory.get_network('ssd_512_vgg' if ssd else 'ron_320_vgg')
         if ssd:
