@@ -454,7 +454,9 @@ void plan_groups(ron_ctx* c) {
   const int T64 = kCfgIgemm128x64;     // tiny convolutions (Npad = 64)
   // SSD-512 (nets/ssd_vgg_512.py:395-458): blocks 8-12 are a chain of 1x1 -> 3x3 stride-2 convolutions on 16x16 ... 1x1 maps,
   // each a 13-20 us launch at batch 16; the two box convolutions of a block only need that block's output, so they share a
-  // launch with the next block's 1x1 (20 small launches -> 11).  The block4 / block7 heads are real work and stay alone.
+  // launch with the next block's 1x1 (20 small launches -> 11).  The block4 / block7 heads are real work and stay alone (round 4:
+  // as carriers of the chain's small launches in mixed-width groups they measured -0.8 % images/s - block4_box_conv_loc then leaves
+  // the halo-patch kernel: 114 us for {block8_conv1x1, block4_box_conv_loc} where the two take 40 + 45 us on their own).
   const std::vector<Slot> ssd_order = {
       {-1, {"conv6"}}, {-1, {"conv7"}},
       {-1, {"block8_conv1x1"}}, {-1, {"block8_conv3x3"}},
