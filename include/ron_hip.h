@@ -113,6 +113,7 @@ typedef struct {
 #define RON_IN_CLS_IS_PROB 1u   /* cls holds softmax probabilities (RONNet.net()[0])          */
 #define RON_IN_OBJ_IS_PROB 2u   /* obj holds P(object) [N,H,W,A,1] (RONNet.net()[2])          */
 #define RON_IN_LOC_DECODED 4u   /* loc already holds decoded boxes (RONNet.bboxes_decode)     */
+/* bits 30 and 31 of input_flags are reserved for the library: callers pass them as 0 */
 
 typedef struct {
   float objectness_thres;   /* eval_ron_network.py:66-67,227-229 (0.03); ignored if obj NULL */
@@ -217,6 +218,8 @@ int ron_post_tfe(const ron_heads* heads, int n, const ron_tfe_cfg* cfg,
  *   objectness > objectness_thres -> tfe.bboxes_clip(bbox_img) -> filter_boxes (sides > min_size, centre inside the image)
  *   -> tf_bboxes_nms: score > select_threshold, all classes together, greedy in score order, at most keep_top_k kept,
  *   overlap 'union' (what main() passes) or 'min' -> tfe.bboxes_resize(bbox_img).
+ *   nms_mode | 2: tf_bboxes_nms_by_class_v1 instead (ron_eval.py:282-366, the variant behind the commented call of :474): a kept
+ *   box suppresses boxes of its own label only; the first keep_top_k kept rows in score order are returned.
  * min_sizes: device [n], filter_boxes' min_size of every image (max(1e-4, 0.03 * sqrt(h * w / (320 * 320)))).
  * Output: ron_detections (classes = labels), capacity >= keep_top_k, kept rows in score order, zero padded.
  * The 1024 highest scores that pass the filters are the NMS candidates (the reference considers all of them; with its
@@ -227,7 +230,7 @@ typedef struct {
   float select_threshold;   /* 0.6  */
   float nms_threshold;      /* 0.4  */
   int32_t keep_top_k;       /* nms_topk = 20 */
-  int32_t nms_mode;         /* 1 = 'union', 0 = 'min' */
+  int32_t nms_mode;         /* 1 = 'union', 0 = 'min'; + 2 = by class (tf_bboxes_nms_by_class_v1) */
   float bbox_img[4];
   float prior_scaling[4];
   uint32_t input_flags;

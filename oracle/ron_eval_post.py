@@ -6,6 +6,8 @@
   filter_boxes     ron_eval.py:369-392   sides > min_size, centre strictly inside (0, 1)
   tf_bboxes_nms    ron_eval.py:146-206   score > select_threshold, sort (tf.nn.top_k: lower index first among equals),
                                          greedy, all classes together, at most keep_top_k kept
+  tf_bboxes_nms_by_class_v1   ron_eval.py:282-366   (the variant behind the commented call of :474) per label: greedy among the rows of
+                                         that label; the union, cut to the first keep_top_k kept rows in score order
   resize           tfe.bboxes_resize     tf_extended/bboxes.py:147-171
 
 TensorFlow graph code: **parity unpinned** (hand case in tests/test_oracle_ron_eval.py).
@@ -66,12 +68,42 @@ def tf_bboxes_nms(scores, labels, bboxes, extra, select_threshold, nms_threshold
     return scores[keep], labels[keep], bboxes[keep], extra[keep]
 
 
+def tf_bboxes_nms_by_class_v1(scores, labels, bboxes, extra, select_threshold, nms_threshold, keep_top_k, mode, num_classes=21):
+    """ron_eval.py:282-366, written like the reference: a while loop over the labels 1 .. num_classes - 1, each a greedy loop of at
+    most keep_top_k picks over the rows of that label; then the cut at the (keep_top_k + 1)-th kept row (:358-361)."""
+    m = scores > F32(select_threshold)
+    scores, labels, bboxes, extra = scores[m], labels[m], bboxes[m], extra[m]
+    if scores.shape[0] < 1:
+        return scores, labels, bboxes, extra
+    order = np.argsort(-scores, kind='stable')
+    scores, labels, bboxes, extra = scores[order], labels[order], bboxes[order], extra[order]
+    n = scores.shape[0]
+    total = np.zeros((n,), bool)
+    for c in range(1, num_classes):
+        alive = labels == c
+        it = 0
+        while alive.any() and it < keep_top_k:
+            i = int(np.flatnonzero(alive)[0])
+            total[i] = True
+            alive[i] = False
+            ov = tfe_post.overlap_scores(bboxes[i], bboxes, mode) * alive.astype(F32)
+            alive &= ov < F32(nms_threshold)
+            it += 1
+    kept = np.flatnonzero(total)
+    if kept.shape[0] >= keep_top_k + 1:
+        total &= np.arange(n) < kept[keep_top_k]
+    return scores[total], labels[total], bboxes[total], extra[total]
+
+
 def post_eval_image(predictions, objness_pred, bboxes, image_hw, objectness_thres=0.95, select_threshold=0.6, nms_threshold=0.4,
-                    keep_top_k=20, nms_mode='union', bbox_img=(0., 0., 1., 1.), min_size_ratio=0.03):
+                    keep_top_k=20, nms_mode='union', bbox_img=(0., 0., 1., 1.), min_size_ratio=0.03, nms_by_class=False):
     """ron_eval.py:466-477 for one image (decoded boxes in): dict classes / scores / bboxes / anchor_index."""
     s, l, b, idx = flaten_predict(predictions, objness_pred, bboxes, objectness_thres)
     b = tfe_post.clip_with_repair(bbox_img, b)
     s, l, b, idx = filter_boxes(s, l, b, idx, filter_min_size(image_hw, min_size_ratio=min_size_ratio))
-    s, l, b, idx = tf_bboxes_nms(s, l, b, idx, select_threshold, nms_threshold, keep_top_k, nms_mode)
+    if nms_by_class:
+        s, l, b, idx = tf_bboxes_nms_by_class_v1(s, l, b, idx, select_threshold, nms_threshold, keep_top_k, nms_mode, predictions[0].shape[-1])
+    else:
+        s, l, b, idx = tf_bboxes_nms(s, l, b, idx, select_threshold, nms_threshold, keep_top_k, nms_mode)
     b = np_post.bboxes_resize(bbox_img, b)
     return dict(classes=l.astype(np.int64), scores=s, bboxes=b, anchor_index=idx.astype(np.int64))

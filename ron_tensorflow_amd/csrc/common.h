@@ -54,6 +54,10 @@ struct PerDeviceOnce {
   }
 };
 
+// ron_post_cfg::input_flags, internal bit (not in include/ron_hip.h; reserved there): the workspace's counters are zero on entry and
+// ron_post_np leaves them zero (topk_nms_kernel cleans up after itself) - set by ron_detect for its context-owned workspace only
+constexpr unsigned kPostWsClean = 0x40000000u;
+
 // Makes `device` current for the lifetime of the guard and restores the caller's device afterwards.
 struct DeviceGuard {
   int prev = -1;

@@ -1320,9 +1320,10 @@ extern "C" int ron_detect(ron_ctx* c, const float* d_images, int n, const ron_po
   if (c->d_post_ws == nullptr) {
     c->post_ws_bytes = ron_post_np_workspace_bytes(&hd, mb);
     RON_HIP_CHECK(hipMalloc(&c->d_post_ws, (size_t)c->post_ws_bytes));
+    RON_HIP_CHECK(hipMemsetAsync(c->d_post_ws, 0, (size_t)c->post_ws_bytes, (hipStream_t)stream));      // once: the kernels keep the counters clean
   }
   ron_post_cfg pc = *cfg;
-  pc.input_flags = 0;      // logits + raw offsets straight from the conv stack
+  pc.input_flags = ron::kPostWsClean;      // logits + raw offsets straight from the conv stack; self-cleaning workspace (common.h)
   const bool prof = !c->pending.empty() && !c->pending_ops.back().empty() && c->pending_ops.back().back() <= -1 &&
                     c->pending_ops.back().back() != -3 && c->pending_ops.back().back() != -2;   // this call was recorded
   auto post_stamp = [&](int what) -> int {

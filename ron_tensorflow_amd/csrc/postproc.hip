@@ -703,6 +703,12 @@ __global__ __launch_bounds__(kTopkThreads) void topk_nms_kernel(HeadsDev hd, Pos
     lds.anchor[r] = anchor;
   }
   __syncthreads();
+  // self-cleaning workspace (ron_detect's own): this workgroup is the last reader of its image's counters - every thread took them
+  // at the top and has passed barriers since - so it leaves them zero for the next call and the 5 us memset in front of every call goes
+  if ((pc.flags & ron::kPostWsClean) && tid == 0) {
+    const_cast<int*>(counts)[img * kCountStride] = 0;
+    const_cast<int*>(part_total)[img * kCountStride] = 0;
+  }
   if (sorted_out.classes != nullptr) store_sorted(lds, n, sorted_out, img);
   nms_and_store(lds, n, pc.nms_thr, pc.ref, true, out, img, hd.num_classes);
 }
@@ -845,13 +851,22 @@ extern "C" int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cf
   pc.top_k = cfg->top_k; pc.flags = cfg->input_flags;
   for (int i = 0; i < 4; ++i) { pc.ref[i] = cfg->bbox_img[i]; pc.ps[i] = cfg->prior_scaling[i]; }
   hipStream_t s = (hipStream_t)stream;
-  const int64_t cnt_bytes = ron::align_up((int64_t)n * kCountStride * 4, 256);
+  // Layout: [counts][part_total][keys of n images][partial keys].  A self-cleaning workspace (kPostWsClean) is reused by calls of
+  // different n and must keep its counters where they are: they are laid out for the largest batch the workspace holds, not for n
+  // (laid out for n, a batch of 1 wrote its keys over the counters of a later batch of 32)
   const int cap = hd.anchor_base[RON_MAX_LAYERS] * (hd.num_classes - 1);
+  auto bytes_for = [&](int64_t k) {           // = ron_post_np_workspace_bytes(heads, k)
+    return 2 * ron::align_up(k * kCountStride * 4, 256) + k * cap * 8 + k * kPartChunks * kMaxTopK * 8;
+  };
+  int n_layout = n;
+  if (cfg->input_flags & ron::kPostWsClean)
+    while (bytes_for(n_layout + 1) <= workspace_bytes) ++n_layout;
+  const int64_t cnt_bytes = ron::align_up((int64_t)n_layout * kCountStride * 4, 256);
   int* counts = (int*)workspace;
   int* part_total = (int*)((char*)workspace + cnt_bytes);
   u64* keys = (u64*)((char*)workspace + 2 * cnt_bytes);
-  u64* part_keys = keys + (size_t)n * cap;
-  RON_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * cnt_bytes, s));
+  u64* part_keys = keys + (size_t)n_layout * cap;
+  if (!(cfg->input_flags & ron::kPostWsClean)) RON_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * cnt_bytes, s));
   dim3 grid(hd.block_base[RON_MAX_LAYERS], n);
   const size_t lds = (size_t)kSelectThreads * hd.num_classes * sizeof(float);
   hipLaunchKernelGGL(select_kernel, grid, dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
@@ -1163,13 +1178,19 @@ constexpr int kEvalCand = 1024;     // NMS candidates of the ron_eval.py variant
 // candidates run out.  One pass in practice (the reference's thresholds let a few dozen through), exact for any count.
 __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, EvalDev pc, const u64* keys, const int* counts,
                                                                 int cap, DetDev out) {
-  static_assert(kEvalCand == kTopkThreads && kSortCap >= kEvalCand + kEvalCand * 2, "one thread per candidate; boxes live behind the keys");
+  static_assert(kEvalCand == kTopkThreads && kSortCap >= kEvalCand + kEvalCand * 2 + kEvalCand / 2,
+                "one thread per candidate; boxes and labels live behind the keys");
   __shared__ ImageLds lds;
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = min(counts[img * kCountStride], cap);
   float* box = reinterpret_cast<float*>(&lds.sort[kEvalCand]);              // [kEvalCand][4]
+  int* lab = reinterpret_cast<int*>(&lds.sort[kEvalCand + kEvalCand * 2]);  // [kEvalCand] labels of this pass's candidates
   u64* words = reinterpret_cast<u64*>(lds.hist);                            // alive bits, one word per wave
-  const int mode = pc.nms_mode == 1 ? 2 : 1;
+  const int mode = (pc.nms_mode & 1) ? 2 : 1;
+  // tf_bboxes_nms_by_class_v1 (ron_eval.py:282-366): a kept box only suppresses boxes of ITS label; classes are independent,
+  // so one greedy pass in score order with the label test is the reference's loop over the classes, and "the first keep_top_k of the
+  // kept rows in score order" (its final cut) is where this scan stops anyway
+  const bool by_class = (pc.nms_mode & 2) != 0;
   const int max_keep = min(pc.keep_top_k, out.capacity);
   int n_kept = 0;                                                           // kept records: lds.box / score / cls / anchor
   u64 below = ~0ull;
@@ -1192,9 +1213,11 @@ __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, Eva
     if (n > 0) below = lds.sort[n - 1];                                     // the next pass continues under this key
     __syncthreads();                                                        // every key is read before boxes overwrite the tail
     box[tid * 4 + 0] = my[0]; box[tid * 4 + 1] = my[1]; box[tid * 4 + 2] = my[2]; box[tid * 4 + 3] = my[3];
+    const int my_label = (int)(my_p & 63u);
+    lab[tid] = my_label;
     bool alive = tid < n;
     for (int j = 0; j < n_kept && alive; ++j)                               // boxes kept by earlier passes come first in score order
-      if (tfe_suppresses(lds.box[j], my, pc.nms_thr, mode)) alive = false;
+      if ((!by_class || lds.cls[j] == my_label) && tfe_suppresses(lds.box[j], my, pc.nms_thr, mode)) alive = false;
     // greedy, class agnostic, in score order (ron_eval.py:187-203): pick the first live row, drop every live row it overlaps
     while (n_kept < max_keep) {
       const u64 bal = __ballot(alive);
@@ -1213,7 +1236,7 @@ __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, Eva
         lds.anchor[n_kept] = (int)(my_p >> 6);
       }
       ++n_kept;
-      if (alive && tfe_suppresses(&box[first * 4], my, pc.nms_thr, mode)) alive = false;
+      if (alive && (!by_class || lab[first] == my_label) && tfe_suppresses(&box[first * 4], my, pc.nms_thr, mode)) alive = false;
       __syncthreads();
     }
     __syncthreads();
@@ -1252,7 +1275,7 @@ extern "C" int ron_post_eval(const ron_heads* heads, int n, const float* min_siz
                              int64_t workspace_bytes, ron_detections* out, void* stream) {
   RON_REQUIRE(cfg != nullptr && n > 0 && out != nullptr && min_sizes != nullptr, "bad argument");
   RON_REQUIRE(cfg->keep_top_k >= 1 && cfg->keep_top_k <= kMaxTopK, "keep_top_k %d not in [1, %d]", cfg->keep_top_k, kMaxTopK);
-  RON_REQUIRE(cfg->nms_mode == 0 || cfg->nms_mode == 1, "unknown mode to use for nms.");
+  RON_REQUIRE(cfg->nms_mode >= 0 && cfg->nms_mode <= 3, "unknown mode to use for nms.");
   RON_REQUIRE(heads != nullptr && heads->num_classes <= 64, "num_classes must be <= 64");
   HeadsDev hd;
   int rc = build_heads_dev(heads, &hd, (cfg->input_flags & RON_IN_LOC_DECODED) == 0);

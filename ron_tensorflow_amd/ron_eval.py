@@ -27,16 +27,18 @@ def filter_min_size(image_shapes, net_input_shape=(320., 320.), min_size_ratio=0
 def post_eval(cls, obj, loc, anchors_dev, image_shapes, num_classes=21, objectness_thres=0.95, select_threshold=0.6,
               nms_threshold=0.4, keep_top_k=20, nms_mode='union', bbox_img=(0., 0., 1., 1.), min_size_ratio=0.03,
               net_input_shape=(320., 320.), prior_scaling=(0.1, 0.1, 0.2, 0.2), cls_is_prob=True, obj_is_prob=True,
-              loc_decoded=True):
+              loc_decoded=True, nms_by_class=False):
     """Per-layer lists of GPU tensors in (the outputs of ``RONNet.net`` + ``bboxes_decode`` by default), DetectionBuffers
-    out: ``classes`` = labels, rows in score order, ``count`` <= keep_top_k.  Defaults are ron_eval.py's flags (:82-92)."""
+    out: ``classes`` = labels, rows in score order, ``count`` <= keep_top_k.  Defaults are ron_eval.py's flags (:82-92).
+    ``nms_by_class``: ``tf_bboxes_nms_by_class_v1`` (ron_eval.py:282-366, the variant behind the commented call of :474) instead of
+    ``tf_bboxes_nms``: a kept box only suppresses boxes of its own label."""
     if nms_mode not in NMS_MODES:
         raise ValueError('unknown mode to use for nms.')          # ron_eval.py:188
     n, dev = cls[0].shape[0], cls[0].device
     heads, keep = _fill_heads(cls, obj, loc, None if loc_decoded else anchors_dev, num_classes)
     cfg = EvalCfg()
     cfg.objectness_thres, cfg.select_threshold, cfg.nms_threshold = objectness_thres, select_threshold, nms_threshold
-    cfg.keep_top_k, cfg.nms_mode = keep_top_k, NMS_MODES[nms_mode]
+    cfg.keep_top_k, cfg.nms_mode = keep_top_k, NMS_MODES[nms_mode] | (2 if nms_by_class else 0)
     for i in range(4):
         cfg.bbox_img[i] = bbox_img[i]
         cfg.prior_scaling[i] = prior_scaling[i]

@@ -500,6 +500,22 @@ def test_carrier_and_mid_plans_match_one_launch_per_conv(pkg, dev, weights_reduc
     b.close()
 
 
+def test_detect_workspace_survives_a_smaller_batch(pkg, dev, weights_reduced):
+    """ron_detect's context-owned post-processing workspace is self-cleaning (its kernels leave the candidate counters zero, no memset
+    per call): a call with a smaller batch in between must not disturb the counters of a later full batch.  (Laid out for the batch of
+    the call, a batch of 1 once wrote its candidate keys over the counters of the next batch of 32.)"""
+    x = torch.from_numpy(pkg['W'].synthetic_images(4, seed=9)).to(dev)
+    net = pkg['ron'].RONNet(variant='reducedfc', dtype='bf16', max_batch=4, fuse_pools=True).load_weights(weights_reduced)
+    a = net.detect(x)
+    first = {k: getattr(a, k).clone() for k in ('count', 'classes', 'scores', 'bboxes', 'anchor_index')}
+    net.detect(x[2:3])                       # other launch plan per convolution at batch 1: its own counts, not compared here
+    for _ in range(2):
+        b = net.detect(x)
+        for k, v in first.items():
+            assert torch.equal(getattr(b, k), v), k
+    net.close()
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 def test_fused_stem_vs_oracle_at_full_size(pkg, dev, weights_reduced, images, dtype):
     """conv1_1 + conv1_2 + pool1 as ONE kernel (stem2_kernel, 320 x 320 input) against the ORACLE, not against the other GPU

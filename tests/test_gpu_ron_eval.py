@@ -27,8 +27,10 @@ CASES = [  # seed, batch, bg, ob, obj_thr, sel_thr, nms_thr, keep_top_k, mode
 ]
 
 
+@pytest.mark.parametrize('by_class', [False, True], ids=['agnostic', 'by_class'])
 @pytest.mark.parametrize('case', CASES, ids=lambda c: 'seed%d' % c[0])
-def test_post_eval_matches_oracle(case):
+def test_post_eval_matches_oracle(case, by_class):
+    """by_class: tf_bboxes_nms_by_class_v1 (ron_eval.py:282-366) instead of tf_bboxes_nms (:146-206)."""
     from ron_tensorflow_amd import ops, ron_eval
     seed, batch, bg, ob, obj_thr, sel_thr, nms_thr, keep, mode = case
     dev = torch.device('cuda:0')
@@ -43,13 +45,14 @@ def test_post_eval_matches_oracle(case):
     dec = [ops.bboxes_decode_layer(l, a) for l, a in zip(loc_d, adev)]
     shapes = [(375, 500), (500, 333)][:batch]
     det = ron_eval.post_eval(pred, objp, dec, None, shapes, objectness_thres=obj_thr, select_threshold=sel_thr,
-                             nms_threshold=nms_thr, keep_top_k=keep, nms_mode=mode)
+                             nms_threshold=nms_thr, keep_top_k=keep, nms_mode=mode, nms_by_class=by_class)
     got = det.to_lists()
     n_total = 0
     for i in range(batch):
         ref = rp.post_eval_image([p[i].cpu().numpy() for p in pred], [o[i].cpu().numpy() for o in objp],
                                  [d[i].cpu().numpy() for d in dec], shapes[i], objectness_thres=obj_thr,
-                                 select_threshold=sel_thr, nms_threshold=nms_thr, keep_top_k=keep, nms_mode=mode)
+                                 select_threshold=sel_thr, nms_threshold=nms_thr, keep_top_k=keep, nms_mode=mode,
+                                 nms_by_class=by_class)
         g = got[i]
         assert np.array_equal(g['classes'], ref['classes']), i
         assert np.array_equal(g['anchor_index'], ref['anchor_index']), i
@@ -62,7 +65,7 @@ def test_post_eval_matches_oracle(case):
     # fused entry: logits, objectness logits, raw offsets
     det2 = ron_eval.post_eval(cls_d, obj_d, loc_d, adev, shapes, objectness_thres=obj_thr, select_threshold=sel_thr,
                               nms_threshold=nms_thr, keep_top_k=keep, nms_mode=mode, cls_is_prob=False, obj_is_prob=False,
-                              loc_decoded=False)
+                              loc_decoded=False, nms_by_class=by_class)
     assert torch.equal(det2.count, det.count) and torch.equal(det2.classes, det.classes)
     assert torch.equal(det2.anchor_index, det.anchor_index)
     assert float((det2.bboxes - det.bboxes).abs().max()) <= 1e-6

@@ -27,3 +27,20 @@ def test_hand_case():
     r = rp.post_eval_image([pred], [obj], [box], (640, 640), nms_threshold=0.4)
     assert r['anchor_index'].tolist() == [0] or r['anchor_index'].tolist() == [0, 2]
     assert abs(rp.filter_min_size((640, 640)) - 0.06) < 1e-7 and rp.filter_min_size((1, 1)) == np.float32(0.0001)
+
+
+def test_by_class_variant_hand_case():
+    """tf_bboxes_nms_by_class_v1 (ron_eval.py:282-366): a kept box suppresses boxes of ITS label only; the result is cut to the first
+    keep_top_k kept rows in score order."""
+    pred = np.array([[.1, .8, .1],      # label 1, kept
+                     [.1, .7, .2],      # label 1, overlaps anchor 0 -> suppressed in both variants
+                     [.1, .2, .7],      # label 2, the SAME box as anchor 0: suppressed by the class-agnostic NMS, kept by class
+                     [.2, .1, .7]],     # label 2, far away
+                    np.float32).reshape(1, 1, 4, 3)
+    obj = np.array([.99, .98, .97, .96], np.float32).reshape(1, 1, 4, 1)
+    box = np.array([[.1, .1, .5, .5], [.12, .1, .5, .5], [.1, .1, .5, .5], [.6, .6, .9, .9]], np.float32).reshape(1, 1, 4, 4)
+    agnostic = rp.post_eval_image([pred], [obj], [box], (320, 320))
+    assert agnostic['anchor_index'].tolist() == [0, 3]
+    by_class = rp.post_eval_image([pred], [obj], [box], (320, 320), nms_by_class=True)
+    assert by_class['anchor_index'].tolist() == [0, 2, 3] and by_class['classes'].tolist() == [1, 2, 2]
+    assert rp.post_eval_image([pred], [obj], [box], (320, 320), nms_by_class=True, keep_top_k=2)['anchor_index'].tolist() == [0, 2]
