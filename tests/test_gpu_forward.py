@@ -516,6 +516,32 @@ def test_detect_workspace_survives_a_smaller_batch(pkg, dev, weights_reduced):
     net.close()
 
 
+@pytest.mark.parametrize('variant', ['reducedfc', 'full'])
+@pytest.mark.parametrize('max_batch,head_plan', [(1, None), (4, 'batch'), (12, None), (16, None), (16, 'level'), (24, None), (32, None)])
+def test_launch_plans_respect_dependencies(pkg, dev, weights_reduced, weights_full, variant, max_batch, head_plan):
+    """Every launch plan plan_groups can produce, read back from the library and checked against the graph's true dependencies: a launch
+    only reads what EARLIER launches wrote, and the members of a grouped launch neither read nor write what another member writes
+    (they run concurrently).  A plan-table edit that breaks this would still pass every numerical test most of the time."""
+    w = weights_reduced if variant == 'reducedfc' else weights_full
+    net = pkg['ron'].RONNet(variant=variant, dtype='bf16', max_batch=max_batch, fuse_pools=True, head_plan=head_plan).load_weights(w)
+    plan = [n for n in net.launch_plan()[:-1]]
+    net.close()
+    from plan_util import check_launches, head_dependencies
+    dep = head_dependencies()
+    start = plan.index('conv5_1') if 'conv5_1' in plan else next(i for i, n in enumerate(plan) if 'conv5_1' in n)
+    launches = []
+    for n in plan[start:]:
+        if n.startswith('('):
+            launches[-1].append(n[1:-1])
+        elif n.startswith('group['):
+            launches.append([n[len('group['):n.rindex('+')]])
+        else:
+            launches.append([n])
+    seen_ops = [m for l in launches for m in l]
+    assert sorted(seen_ops) == sorted(dep), sorted(set(dep) ^ set(seen_ops))          # every op exactly once
+    check_launches(launches, dep)
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 def test_fused_stem_vs_oracle_at_full_size(pkg, dev, weights_reduced, images, dtype):
     """conv1_1 + conv1_2 + pool1 as ONE kernel (stem2_kernel, 320 x 320 input) against the ORACLE, not against the other GPU
