@@ -303,10 +303,11 @@ typedef struct {
  * skips the filter rows that fall outside the image for all of its rows (bit-identical results: only products with zeros go).
  * This flag keeps the image-major order and the full K loop (tests compare the two). */
 #define RON_CFG_NO_HALO_SKIP 16u
-/* Which grouped plan the RON heads run: by default contexts with max_batch <= 4 launch the heads one launch per dependency
- * level (10 launches, the large convolutions grouped too: at such batches every launch is latency-bound), larger ones the
- * plan above (16 launches).  RON_CFG_LEVEL_GROUPS / RON_CFG_BATCH_GROUPS force one or the other (A/B tests; same results up to
- * the order of the fp32 partial sums). */
+/* Which grouped plan the RON heads run: by default contexts with max_batch <= 12 launch the heads one launch per dependency
+ * level (7 launches, the large convolutions grouped too: at such batches every launch is latency-bound); 13..23: mixed-width
+ * level groups with the large layers on their own; >= 24: small convolutions packed into the partial rounds of 256 x 256-tile
+ * launches (csrc/graph.cpp, plan_groups).  RON_CFG_LEVEL_GROUPS forces the level plan, RON_CFG_BATCH_GROUPS the plan max_batch
+ * would select without the level rule (A/B tests; same results up to the order of the fp32 partial sums). */
 #define RON_CFG_LEVEL_GROUPS 32u
 #define RON_CFG_BATCH_GROUPS 64u
 
@@ -354,8 +355,8 @@ double ron_flops_per_image(const ron_ctx* ctx);
  * no work of their own.  *name points into the context and stays valid until ron_destroy. */
 int ron_profile_enable(ron_ctx* ctx, int enable);
 int ron_profile_num_ops(const ron_ctx* ctx);
-/* Grouped launches in the plan of this context: 7 (RON-320; 8 in the level plan of small contexts, RON_CFG_LEVEL_GROUPS), 5 (SSD-512);
- * 0 with RON_CFG_NO_GROUPS / RON_CFG_MULTI_STREAM. */
+/* Grouped launches in the plan of this context: RON-320 10 (max_batch >= 24), 7 (13..23), 6 (the level plan, <= 12 or
+ * RON_CFG_LEVEL_GROUPS); SSD-512 5; 0 with RON_CFG_NO_GROUPS / RON_CFG_MULTI_STREAM. */
 int ron_num_grouped_launches(const ron_ctx* ctx);
 int ron_profile_get(ron_ctx* ctx, int i, const char** name, int* is_conv, double* flops_per_image,
                     double* total_ms, int* launches, double* act_bytes_per_image, double* weight_bytes);
