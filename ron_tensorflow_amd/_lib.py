@@ -146,6 +146,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RonError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                            '(or `make -C ron_tensorflow_amd/csrc`). There is no CPU fallback.' % LIB_PATH)
+        # torch wheels bundle their own libamdhip64 (same soname as the system's): whichever is loaded first serves both.  Loaded
+        # after libron_hip.so, torch would bring a second HIP runtime into the process and this library's calls would land in the one
+        # that sees no device ("no ROCm-capable device is detected").  torch tensors are the device containers of every call, so
+        # torch comes first.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the symbol is missing: fail loudly
