@@ -34,8 +34,10 @@ Pinning status
 * ``eval_metrics``: the AP integrals and ``voc_eval_class`` are pinned against the reference's own numpy
   ``voc_ap`` / ``DetectorEvalPascal.voc_eval`` (fixtures g6, g7); the TF matching is **parity unpinned**.
 * ``preprocess`` (TF1 bilinear resize restated from its published algorithm) and ``ron_eval_post``: **parity unpinned**.
-* ``ron_forward`` and ``tfe_post`` restate TensorFlow-1.x graph code.  TensorFlow
-  is not installable here and the reference ships no tests, golden vectors or
-  checkpoints for it, so for these two: **parity unpinned** (cross-checked only
+* ``ron_forward`` / ``ssd_forward``: the VGG-16 backbone (conv1_1 .. conv5_3 with pool1..4; SSD: .. conv7 with pool5 3x3 s1 and the
+  rate-6 conv6) and the conv -> inference BatchNorm -> ReLU layer ARE pinned: golden G8 = the reference's only executable conv
+  arithmetic, the torch ``VGG16`` / ``vgg()`` of ``convert_pytorch_vgg.py:13-58`` (tests/test_oracle_g8.py).  The rest of the two
+  forwards (fc6 / fc7, transposed conv, reverse-connection sum, inception concat + BN, heads, SSD blocks 8-12, L2-norm) and
+  ``tfe_post`` restate TensorFlow-1.x graph code with no executable form in the reference: **parity unpinned** (cross-checked
   against the independent torch-CPU operators and hand-derived cases).
 """

@@ -1,11 +1,11 @@
 """Oracle: fp32 NHWC restatement of the RON-320 conv stack (test infrastructure).
 
-Follows the reference graph code, which is TensorFlow-1.x / tf.contrib.slim and cannot be
-executed here (TensorFlow is not installable; the reference ships no tests or checkpoints
-for it): **parity unpinned** -- the layer semantics below are restated from the reference
-source and cross-checked against the independent torch-CPU operators
-(tests/test_oracle_forward.py: every layer shape of RON-320 and SSD-512, both back-ends), not against
-outputs of the reference itself.
+Follows the reference graph code, which is TensorFlow-1.x / tf.contrib.slim and cannot be executed here.  PINNED against the
+reference's own executable torch VGG (convert_pytorch_vgg.py:13-58, golden G8, tests/test_oracle_g8.py): conv1_1 .. conv5_3 with
+pool1..4, and the conv -> inference BatchNorm -> ReLU layer.  Everything else below (fc6 / fc7, transposed conv, reverse-connection
+sum, inception concat + BN, heads) has no executable form in the reference: **parity unpinned** -- restated from the reference
+source and cross-checked against the independent torch-CPU operators (tests/test_oracle_forward.py: every layer shape of RON-320
+and SSD-512, both back-ends).
 
   VGG-16 body, fc6/fc7 (both variants)   nets/ron_vgg_320.py:454-483, :530-556
   reverse connection + objectness        nets/ron_vgg_320.py:418-432

@@ -105,3 +105,24 @@ def g8_sample_index(n):
         return np.arange(n)
     inner = np.linspace(2, n - 3, 5).round().astype(np.int64)[1:4]
     return np.unique(np.concatenate([[0, 1], inner, [n - 2, n - 1]]))
+
+
+# golden G8 (second part): the reference's vgg(cfg, i, batch_norm=True) - conv -> BatchNorm2d (inference) -> ReLU
+VGG_BN_CFG = [32, 'M', 64]            # two conv + BN + ReLU layers with a pool between them
+
+
+def vgg_bn_params(seed):
+    """Seeded parameters for vgg(VGG_BN_CFG, 3, batch_norm=True): per conv layer (W [O,I,3,3], gamma, beta, running_mean, running_var),
+    conv biases zero (slim.conv2d with a normalizer_fn has none, nets/ron_vgg_320.py:595-629)."""
+    rs = np.random.RandomState(seed)
+    out, cin = [], 3
+    for v in VGG_BN_CFG:
+        if isinstance(v, int):
+            w = (rs.randn(v, cin, 3, 3) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+            gamma = rs.uniform(0.5, 1.5, v).astype(np.float32)
+            beta = (rs.randn(v) * 0.1).astype(np.float32)
+            mean = (rs.randn(v) * 0.5).astype(np.float32)
+            var = rs.uniform(0.5, 1.5, v).astype(np.float32)
+            out.append((w, gamma, beta, mean, var))
+            cin = v
+    return out

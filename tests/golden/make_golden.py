@@ -405,6 +405,32 @@ def g8_vgg_backbone():
             out['%d/%s/sum' % (size, name)] = np.array([a.sum(dtype=np.float64), (a.astype(np.float64) ** 2).sum()])
     for h in hooks:
         h.remove()
+    # ---- second part: the same reference function with batch_norm=True (convert_pytorch_vgg.py:47-48: Conv2d -> BatchNorm2d ->
+    # ReLU), in eval mode on seeded running statistics: the only executable "conv + inference BatchNorm + ReLU" of the reference
+    # (eps 1e-5 = torch's default = ron_arg_scope's batch_norm_epsilon, nets/ron_vgg_320.py:601).  Small: stored in full.
+    layers = ref.vgg(list(synth.VGG_BN_CFG), 3, batch_norm=True)[:-5]          # drop the pool5 / conv6 / conv7 tail vgg() appends
+    seed_bn = 83
+    params = synth.vgg_bn_params(seed_bn)
+    convs = [m for m in layers if isinstance(m, torch.nn.Conv2d)]
+    bns = [m for m in layers if isinstance(m, torch.nn.BatchNorm2d)]
+    assert len(convs) == len(bns) == len(params) == 2
+    with torch.no_grad():
+        for cv, bn, (w, gamma, beta, mean, var) in zip(convs, bns, params):
+            cv.weight.copy_(torch.from_numpy(w)); cv.bias.zero_()
+            bn.weight.copy_(torch.from_numpy(gamma)); bn.bias.copy_(torch.from_numpy(beta))
+            bn.running_mean.copy_(torch.from_numpy(mean)); bn.running_var.copy_(torch.from_numpy(var))
+            assert bn.eps == 1e-5
+    net = torch.nn.Sequential(*layers).eval()
+    img = synth.vgg_backbone_image(84, 24)
+    acts, x = [], torch.from_numpy(img).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        for m in net:
+            x = m(x)
+            if isinstance(m, (torch.nn.ReLU, torch.nn.MaxPool2d)):
+                acts.append(x.clone().permute(0, 2, 3, 1).contiguous().numpy())
+    assert len(acts) == 3
+    out['bn/seed_params'], out['bn/seed_image'] = np.int64(seed_bn), np.int64(84)
+    out['bn/conv_bn_relu_1'], out['bn/pool'], out['bn/conv_bn_relu_2'] = acts
     np.savez_compressed(os.path.join(HERE, 'g8_vgg_backbone.npz'), **out)
 
 

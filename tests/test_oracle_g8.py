@@ -6,7 +6,8 @@
 ``tests/golden/make_golden.py::g8_vgg_backbone`` ran it in the build container on seeded weights (converted OIHW -> HWIO like
 ``nets/caffe_scope.py:57-60``) and seeded 320^2 / 512^2 images and stored every module's output (samples + whole-tensor sums).
 Here the two restated oracles, on both of their back-ends, must reproduce those tensors.  What G8 cannot pin (no such layer in
-the reference's torch model): fc6 7x7 / rate 3, pool5 2x2, the reverse-connection module, the heads, BatchNorm, the transposed conv."""
+the reference's torch model): fc6 7x7 / rate 3, pool5 2x2, the reverse-connection module, the heads, the transposed conv.  BatchNorm IS
+pinned (second part of G8: the same reference function with batch_norm=True, conv -> BatchNorm2d -> ReLU in eval mode)."""
 import numpy as np
 import pytest
 
@@ -59,3 +60,26 @@ def test_g8_check_catches_a_wrong_border():
     b[0, 5, 0, :] = 0          # row 5 is not sampled
     with pytest.raises(AssertionError):
         check_tensor(320, 'conv1_1', b)
+
+
+@pytest.mark.parametrize('backend', ['numpy', 'torch'])
+def test_oracle_conv_batchnorm_relu_reproduces_the_reference(backend):
+    """slim.conv2d with normalizer_fn=slim.batch_norm at inference (no bias, BN eps 1e-5, ReLU: nets/ron_vgg_320.py:595-629) as the oracle
+    computes it (oracle/ron_forward.py::_Net.conv_bn_relu) == the reference's own conv -> BatchNorm2d -> ReLU (vgg(cfg, i,
+    batch_norm=True), convert_pytorch_vgg.py:47-48, eval mode, eps 1e-5), layer by layer, with the 2x2 pool between them."""
+    params = synth.vgg_bn_params(int(G8['bn/seed_params']))
+    weights = {}
+    for i, (w, gamma, beta, mean, var) in enumerate(params):
+        sc = '%s/bn_layer%d' % (orf.SCOPE, i)
+        weights[sc + '/weights'] = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)))          # OIHW -> HWIO, nets/caffe_scope.py:57-60
+        weights[sc + '/BatchNorm/gamma'], weights[sc + '/BatchNorm/beta'] = gamma, beta
+        weights[sc + '/BatchNorm/moving_mean'], weights[sc + '/BatchNorm/moving_variance'] = mean, var
+    net = orf._Net(weights, backend)
+    x = synth.vgg_backbone_image(int(G8['bn/seed_image']), 24)
+    a1 = net.conv_bn_relu(x, 'bn_layer0')
+    p1 = net.pool(a1)
+    a2 = net.conv_bn_relu(p1, 'bn_layer1')
+    for got, key in ((a1, 'bn/conv_bn_relu_1'), (p1, 'bn/pool'), (a2, 'bn/conv_bn_relu_2')):
+        want = G8[key]
+        assert got.shape == want.shape
+        assert float(np.abs(got - want).max()) <= 1e-5 * float(np.abs(want).max()), key
