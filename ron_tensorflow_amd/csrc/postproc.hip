@@ -203,7 +203,9 @@ struct ImageLds {
   int keep[kMaxTopK];              // sorted row -> kept?
   int cstart[66];                  // first class-grouped position of every class
   float gbox[kMaxTopK][4];         // boxes in class-grouped order (class-wise NMS: no double indirection in the pair loop)
-  int rend[kMaxTopK];              // class-grouped position -> one past the last position of its class
+  int rbeg[kMaxTopK];              // class-grouped position -> first position of its class
+  float gvol[kMaxTopK];            // area of gbox[pos], as bboxes_jaccard computes it
+  u64 keptw[kTopkThreads / 64][kMaskWords];  // class-wise NMS: the scanning wave's kept rows, one word per 64 grouped positions
 };
 
 __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int j) {
@@ -360,6 +362,22 @@ __device__ __forceinline__ bool nms_suppresses(const float* bi, const float* bj,
   // 87.6 vs 88 us per batch in the 1 k-candidate regime: the pass is not bound by the division)
 }
 
+// The same decision as nms_suppresses with the two areas given, for the pair loop of the class-wise scan, which is bound by the
+// vector ALU of its one CU: the quotient is first estimated with v_rcp_f32 (1 ulp) and only a pair whose estimate lies within
+// 1e-6 of the threshold - or whose denominator is not a normal positive number - takes the IEEE division; every other pair is
+// decided by the estimate, whose error (< 3e-7 relative) cannot move it across the threshold.
+__device__ __forceinline__ bool nms_suppresses_vol(const float* bi, float vol1, const float* bj, float vol2, float thr) {
+  const float ih = fmaxf(fminf(bi[2], bj[2]) - fmaxf(bi[0], bj[0]), 0.f);
+  const float iw = fmaxf(fminf(bi[3], bj[3]) - fmaxf(bi[1], bj[1]), 0.f);
+  const float inter = ih * iw;
+  const float den = vol1 + vol2 - inter;
+  const float est = inter * __builtin_amdgcn_rcpf(den);
+  const bool sure_below = est < thr * (1.f - 1e-6f), sure_above = est > thr * (1.f + 1e-6f);
+  if ((sure_below || sure_above) && den > 1e-30f && den < 1e30f) return sure_above;
+  const float iou = inter / den;
+  return !(iou < thr);
+}
+
 // tf_extended/bboxes.py:195-211 + :226: kept box i against a later box j; mode 1 = 'min', 2 = 'union'
 __device__ __forceinline__ bool tfe_suppresses(const float* bi, const float* bj, float thr, int mode) {
   const float ih = fmaxf(fminf(bj[2], bi[2]) - fmaxf(bj[0], bi[0]), 0.f);
@@ -434,9 +452,14 @@ __device__ void nms_scan(ImageLds& lds, int n, float nms_thr, int mode, int max_
 }
 
 // Class-wise form of the np_methods NMS (np_methods.py:229-242 suppresses only boxes of the SAME class): rows are
-// grouped by class (stable, so score order is kept inside a class), the suppression bits are built per class segment
-// (one wave per row, lanes = the later rows of the segment, __ballot -> word) and every class is scanned greedily by its
-// own wave in parallel.  Pairs examined: sum_c n_c^2 / 2 instead of n^2 / 2, serial depth max_c n_c instead of n.
+// grouped by class (stable, so score order is kept inside a class) and every class is scanned by its own wave in parallel.
+// Pairs examined: sum_c n_c^2 / 2 instead of n^2 / 2.
+//   The bit matrix is held by COLUMNS: row b of `mask` says which EARLIER rows of its class overlap b beyond the threshold (the
+// test is symmetric in the two boxes, bit for bit: min / max / + commute).  A row is kept iff no kept earlier row is in its
+// column.  64 rows at a time, lane = row: the kept rows of the earlier blocks are final (wave-uniform words), so "removed by an
+// earlier block" is an AND per lane; inside the block kept = alive & ((column & kept) == 0) is iterated from kept = alive until
+// it stops changing - row i is final after i + 1 rounds whatever the start, so the fixed point is the greedy answer, and the
+// rounds needed are the longest suppression chain in the block (a handful), not the 64 serial steps of the row-major scan.
 // Same outputs in lds.hist / lds.scalars[4] as nms_scan.
 __device__ void nms_scan_classwise(ImageLds& lds, int n, float nms_thr, int num_classes) {
   const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
@@ -481,57 +504,70 @@ __device__ void nms_scan_classwise(ImageLds& lds, int n, float nms_thr, int num_
   if (tid < n) {
     const int pos = lds.cstart[c_me] + wcnt[(wave << 6) + c_me] + rank_me;
     lds.order[pos] = tid;
-    lds.rend[pos] = lds.cstart[c_me + 1];       // one past the last grouped position of the row's class
+    lds.rbeg[pos] = lds.cstart[c_me];
     lds.keep[tid] = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) lds.gbox[pos][q] = lds.box[tid][q];     // boxes in grouped order
+    lds.gvol[pos] = (lds.box[tid][2] - lds.box[tid][0]) * (lds.box[tid][3] - lds.box[tid][1]);
   }
   __syncthreads();                             // wcnt (in lds.sort) is dead from here: the mask goes there
-  for (int a = wave; a < n; a += nwaves) {   // suppression bits of grouped row a: only the words that overlap (a, end of its class)
-    const int s1 = lds.rend[a];
-    const int w0 = a >> 6, w1 = (s1 - 1) >> 6;
-    float ba[4];
+  // Column of grouped row b: the earlier rows of its class that overlap it.  A quarter wave (16 lanes) per row - classes are
+  // short (top_k rows over the classes), a whole wave per row left most lanes without a pair - taking the earlier rows 16 at a
+  // time, aligned, so that its 16 ballot bits are one 16-bit slot of the row's words.  Words [s0 >> 6, b >> 6] of row b are
+  // zeroed first; the scan reads no others.  (One CU's vector ALU bounds this loop: ~36 issue slots per 64 pairs.)
+  {
+    typedef unsigned short __attribute__((may_alias)) u16a;
+    u16a* mask16 = reinterpret_cast<u16a*>(mask);
+    const int sub = lane >> 4, sl = lane & 15;
+    for (int r0 = wave * 4; r0 < n; r0 += nwaves * 4) {
+      const int b = r0 + sub;
+      const bool live = b < n;
+      const int s0 = live ? lds.rbeg[b] : 0;
+      float bb[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ba[q] = lds.gbox[a][q];
-    for (int w = w0; w <= w1; ++w) {
-      const int b = (w << 6) + lane;
-      bool sup = false;
-      if (b > a && b < s1) sup = nms_suppresses(ba, lds.gbox[b], nms_thr);
-      const u64 bits = __ballot(sup);
-      if (lane == 0) mask[a * kMaskWords + w] = bits;
+      for (int q = 0; q < 4; ++q) bb[q] = live ? lds.gbox[b][q] : 0.f;
+      const float vb = live ? lds.gvol[b] : 0.f;
+      if (live && sl <= (b >> 6) - (s0 >> 6)) mask[b * kMaskWords + (s0 >> 6) + sl] = 0;
+      const int k0 = s0 >> 4;                                 // 16-row slots [k0, (b - 1) >> 4] hold the rows in [s0, b)
+      const int iters_me = (live && b > s0) ? ((b - 1) >> 4) - k0 + 1 : 0;
+      int iters = max(iters_me, __shfl_xor(iters_me, 16, 64));
+      iters = max(iters, __shfl_xor(iters, 32, 64));
+      // (loads and arithmetic unconditional on a clamped row, validity applied to the result: straight-line code)
+#pragma unroll 2
+      for (int it = 0; it < iters; ++it) {
+        const int a = ((k0 + it) << 4) + sl;
+        const int ac = min(a, kMaxTopK - 1);
+        const bool sup = nms_suppresses_vol(lds.gbox[ac], lds.gvol[ac], bb, vb, nms_thr) && it < iters_me && a >= s0 && a < b;
+        const u64 bal = __ballot(sup);
+        const unsigned half = (sub & 2) ? (unsigned)(bal >> 32) : (unsigned)(bal & 0xFFFFFFFFull);
+        if (sl == 0 && it < iters_me) mask16[(b * kMaskWords << 2) + k0 + it] = (unsigned short)(half >> ((sub & 1) << 4));
+      }
     }
   }
   __syncthreads();
   for (int c = wave; c < 64 && c < num_classes; c += nwaves) {   // one wave per class
-    // (read through readfirstlane: the class bounds are wave-uniform, and the row loop below then runs on scalar registers)
+    // (read through readfirstlane: the class bounds are wave-uniform)
     const int s0 = __builtin_amdgcn_readfirstlane(lds.cstart[c]), s1 = __builtin_amdgcn_readfirstlane(lds.cstart[c + 1]);
     if (s0 >= s1) continue;
     const int wfirst = s0 >> 6, wlast = (s1 - 1) >> 6;
-    u64 removed = 0;                           // lane w: word w of the class's "removed" set (grouped positions)
-    // 64 rows at a time.  Lane i holds the row's bits for its own block (the diagonal word); the greedy pass over the block then
-    // runs on scalar registers -- a bit test per row and, for a kept row, two readlanes -- instead of one LDS round trip per kept
-    // row (a class of 200 rows: ~20 us -> ~5).  The kept rows' bits for the later blocks are OR-reduced across the wave.
+    u64* keptw = lds.keptw[wave];              // kept rows of the blocks done so far, private to this wave
     for (int wb = wfirst; wb <= wlast; ++wb) {
       const int r = (wb << 6) + lane;
       const bool in_cls = r >= s0 && r < s1;
-      const u64 diag = in_cls ? mask[r * kMaskWords + wb] : 0ull;       // words [r >> 6, wlast] of a class row were written above
-      const unsigned dlo = (unsigned)(diag & 0xFFFFFFFFull), dhi = (unsigned)(diag >> 32);
-      // (the builtin returns int: through unsigned, or the low half sign-extends into the high one)
-      u64 rem = ((u64)(unsigned)__builtin_amdgcn_readlane((unsigned)(removed >> 32), wb) << 32) |
-                (u64)(unsigned)__builtin_amdgcn_readlane((unsigned)(removed & 0xFFFFFFFFull), wb);
-      const int i0 = max(s0 - (wb << 6), 0), i1 = min(s1 - (wb << 6), 64);
-      for (int i = i0; i < i1; ++i) {
-        if (((rem >> i) & 1ull) == 0)
-          rem |= ((u64)(unsigned)__builtin_amdgcn_readlane(dhi, i) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane(dlo, i);
+      u64 hit = 0;                             // kept rows of the earlier blocks in this row's column
+      for (int w = wfirst; w < wb; ++w) hit |= (in_cls ? mask[r * kMaskWords + w] : 0ull) & keptw[w];
+      const u64 col = in_cls ? mask[r * kMaskWords + wb] : 0ull;
+      const bool alive = in_cls && hit == 0;
+      u64 kept = __ballot(alive);
+      for (;;) {
+        const u64 next = __ballot(alive && (col & kept) == 0);
+        if (next == kept) break;
+        kept = next;
       }
-      const bool kept = in_cls && ((rem >> lane) & 1ull) == 0;
-      if (kept) lds.keep[lds.order[r]] = 1;
-      for (int w2 = wb + 1; w2 <= wlast; ++w2) {
-        u64 m = kept ? mask[r * kMaskWords + w2] : 0ull;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) m |= shfl_xor_u64(m, d);
-        if (lane == w2) removed |= m;
-      }
+      if ((kept >> lane) & 1ull) lds.keep[lds.order[r]] = 1;
+      if (lane == 0) keptw[wb] = kept;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
   __syncthreads();
