@@ -58,8 +58,9 @@ struct ConvArgs {
   // tile order inside an XCD's run of workgroups: 0 = N fastest (the column tiles that re-read one activation tile share an L2),
   // 1 = M fastest (the row tiles that re-read one weight slice do: fc6's 205 MB of weights are then fetched once, not once per XCD)
   int m_fastest;
-  // Rows ordered position-major (m = (oy * Wo + ox) * n_img + img) instead of image-major: a tile then covers few output rows oy,
-  // and the filter rows ky whose taps fall into the zero halo for ALL of them are skipped (K range [kt0, kt1) of the tile).
+  // Rows ordered by output row first (m = (oy * n_img + img) * Wo + ox) instead of image-major: a tile then covers few output rows
+  // oy, and the filter rows ky whose taps fall into the zero halo for ALL of them are skipped.  (Round 4: the images used to be the
+  // fastest index; consecutive rows were then one image plane apart, a multiple of 16 KB on fc6's input, i.e. on one L2 channel.)
   // fc6 (7x7 on a 10 x 10 map): 31 % of the MACs multiply halo zeros; skipping whole filter rows per tile recovers half of that.
   int pos_major, n_img, in_H, cpad, kh;
   // Column tiles at or beyond output channel center_from_n (0: none) hold a 1x1 branch whose weights sit in the centre tap of the

@@ -123,23 +123,29 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   int kt0 = zsplit * p.kt_split;
   int kt1 = min(p.KT, kt0 + p.kt_split);
   const bool center_only = p.center_from_n > 0 && n0 >= p.center_from_n;
+  // Position-major rows: the tile runs the filter rows [ky_lo, ky_hi] that touch the image for at least one of its output rows, and
+  // its K steps are numbered locally, [0, rows * kw * steps_per_tap).  The rows are walked from the filter's centre row up to ky_hi,
+  // then from ky_lo up to the centre: every tile of a launch starts on the same weights, and tiles whose row sets differ still meet
+  // on the rows they share at about the same time - the workgroups of an XCD stream a weight column through its L2 together
+  // instead of each at its own filter row (fc6, 7x7 rate 3 on 10x10: 13 row tiles with row sets 3..6, 2..5, 1..4, 0..3).
+  const bool pm = p.pos_major && !center_only;
+  int ky_lo = 0, ky_hi = 0x7fffff, ky_first = 0;
   if (p.pos_major || center_only) {
-    // K range of this tile (tap-major K order: a filter row / a tap is a contiguous K range); split-K slices share it evenly (a
-    // slice may be empty: it stores zeros)
+    // split-K slices share the tile's steps evenly (a slice may be empty: it stores zeros)
     const int steps_per_tap = p.Cin / (kRowBytes / Tr::kEsz);
     int lo, hi;
     if (center_only) {
-      // a 1x1 branch in the centre tap of the filter: that tap alone
+      // a 1x1 branch in the centre tap of the filter: that tap alone (tap-major numbering of the launch)
       lo = ((p.kh >> 1) * p.kw + (p.kw >> 1)) * steps_per_tap;
       hi = lo + steps_per_tap;
     } else {
-      // filter rows that touch the image for at least one output row of this tile
-      const int oy_lo = (m0 / p.n_img) / p.Wo, oy_hi = (min(p.M, m0 + BM) - 1) / p.n_img / p.Wo;
-      int ky_lo = 0, ky_hi = p.kh - 1;
+      const int oy_lo = m0 / (p.n_img * p.Wo), oy_hi = (min(p.M, m0 + BM) - 1) / (p.n_img * p.Wo);
+      ky_hi = p.kh - 1;
       while (ky_lo < ky_hi && oy_hi * p.stride - p.cpad + ky_lo * p.dil < 0) ++ky_lo;
       while (ky_hi > ky_lo && oy_lo * p.stride - p.cpad + ky_hi * p.dil > p.in_H - 1) --ky_hi;
-      lo = ky_lo * p.kw * steps_per_tap;
-      hi = (ky_hi + 1) * p.kw * steps_per_tap;
+      ky_first = min(max(p.cpad / p.dil, ky_lo), ky_hi);
+      lo = 0;
+      hi = (ky_hi - ky_lo + 1) * p.kw * steps_per_tap;
     }
     const int per = (hi - lo + p.splitk - 1) / p.splitk;
     kt0 = min(hi, lo + zsplit * per);
@@ -169,10 +175,18 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
       m = valid ? m : p.M - 1;
       const int hw = p.Ho * p.Wo;
       int rem;
-      if (p.pos_major) { rem = m / p.n_img; img = m - rem * p.n_img; }
-      else { img = m / hw; rem = m - img * hw; }
-      oy = rem / p.Wo;
-      ox = rem - oy * p.Wo;
+      if (p.pos_major) {                       // rows ordered (oy, img, ox): ConvArgs::pos_major
+        const int rw = p.n_img * p.Wo;
+        oy = m / rw;
+        rem = m - oy * rw;
+        img = rem / p.Wo;
+        ox = rem - img * p.Wo;
+      } else {
+        img = m / hw;
+        rem = m - img * hw;
+        oy = rem / p.Wo;
+        ox = rem - oy * p.Wo;
+      }
       const int os = p.up > 0 ? p.up : 1;
       off = ((img * p.out_Hp + oy * os + p.out_pad) * p.out_Wp + ox * os + p.out_pad) * p.out_cstride + p.out_coff;
     }
@@ -218,6 +232,20 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   const int tap0 = ti ? kt0 % n_taps : kt0 / chunks_per_tap;
   int ky = tap0 / p.kw, kx = tap0 - (tap0 / p.kw) * p.kw;
   int cc = (ti ? kt0 / n_taps : kt0 - tap0 * chunks_per_tap) * kChunkElems;
+  if (pm) {
+    // Inside a filter row the K steps run chunk-major (step = (row, chunk, kx)): the kw taps of a chunk re-read the same 128-byte
+    // pieces of the same pixels, shifted, so an XCD's tiles keep ~0.5 MB of activations live per chunk instead of sweeping every
+    // pixel's whole channel vector once per tap (fc6: 3.3 MB per tap and XCD, which the 4 MB L2 does not hold beside the weights:
+    // 0.7 GB of activation re-reads per launch).  Local step kt0 -> (row in walking order, chunk, kx).
+    const int per_row = p.kw * chunks_per_tap;
+    const int i0 = kt0 / per_row, r0 = kt0 - i0 * per_row;
+    ky = ky_first + i0;
+    if (ky > ky_hi) ky -= ky_hi - ky_lo + 1;
+    kx = r0 % p.kw;
+    cc = (r0 / p.kw) * kChunkElems;
+  }
+  // weight block of the next tile to stage (tap-major orders): the K step itself unless the filter rows are walked from the centre
+  int wblk = pm ? (ky * p.kw + kx) * chunks_per_tap + cc / kChunkElems : kt0;
   int tb = ti ? kt0 % n_taps : 0, cb = ti ? kt0 / n_taps : 0;          // weight ring: tap / chunk of its next tile
   // One K step issues LPT LDS-DMA pieces per thread: the B_IT weight pieces of tile kt+S-1 first, then its A_IT
   // activation pieces.  RON_STAGE_BEGIN computes the wave-uniform part once per step, RON_STAGE_PIECE issues piece j
@@ -230,7 +258,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
     const __amdgpu_buffer_rsrc_t rs_b =                                                                              \
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, ktb_ < kt1 ? p.wgt_bytes : 0u, 0x00020000);   \
     const int a_soff = ((ky * p.dil * p.in_Wp + kx * p.dil) * p.in_cstride + cc) * Tr::kEsz;                         \
-    const int b_soff = (ti ? tb * chunks_per_tap + cb : ktb_) * kWeightBlockBytes;                                   \
+    const int b_soff = (ti ? tb * chunks_per_tap + cb : wblk) * kWeightBlockBytes;                                   \
     char* dst_a = s_a + ((ktb_ - kt0) % S) * kABytes + wave * 1024;                                                  \
     char* dst_b = s_b + ((ktb_ - kt0) % S) * kBBytes + wave * 1024;
 #define RON_STAGE_PIECE_B(i_)                                                                                        \
@@ -249,7 +277,18 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
         if (++tb == n_taps) { tb = 0; ++cb; }                                                                        \
         break;                                                                                                       \
       }                                                                                                              \
+      if (pm) {                                                                                                      \
+        wblk += chunks_per_tap;                                                                                      \
+        if (++kx == p.kw) {                                                                                          \
+          kx = 0;                                                                                                    \
+          cc += kChunkElems;                                                                                         \
+          if (cc >= p.Cin) { cc = 0; if (++ky > ky_hi) ky = ky_lo; }                                                 \
+          wblk = ky * p.kw * chunks_per_tap + cc / kChunkElems;                                                      \
+        }                                                                                                            \
+        break;                                                                                                       \
+      }                                                                                                              \
       cc += kChunkElems;                                                                                             \
+      ++wblk;                                                                                                        \
       if (cc >= p.Cin) {                                                                                             \
         cc = 0;                                                                                                      \
         if (++kx == p.kw) { kx = 0; ++ky; }                                                                          \
@@ -459,10 +498,18 @@ __device__ __forceinline__ void splitk_finalize_body(const ConvArgs& p) {
     }
     for (; z < p.splitk; ++z) sum += *reinterpret_cast<const f32x4*>(src + (size_t)z * slab);
     const int hw = p.Ho * p.Wo;
-    int img, rem;
-    if (p.pos_major) { rem = m / p.n_img; img = m - rem * p.n_img; }      // rows are position-major (ConvArgs::pos_major)
-    else { img = m / hw; rem = m - img * hw; }
-    const int oy = rem / p.Wo, ox = rem - (rem / p.Wo) * p.Wo;
+    int img, oy, ox;
+    if (p.pos_major) {                         // rows ordered (oy, img, ox): ConvArgs::pos_major
+      const int rw = p.n_img * p.Wo;
+      oy = m / rw;
+      img = (m - oy * rw) / p.Wo;
+      ox = m - oy * rw - img * p.Wo;
+    } else {
+      img = m / hw;
+      const int rem = m - img * hw;
+      oy = rem / p.Wo;
+      ox = rem - oy * p.Wo;
+    }
     const int o = ((img * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cstride + p.out_coff + n;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

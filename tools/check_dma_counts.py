@@ -56,13 +56,13 @@ def kernels(asm):
 
 def loops(lines):
     """[(index of the K loop's counted wait, its vmcnt immediate, LDS-DMA instructions in the loop body, LDS-DMA instructions between
-    the previous loop (or the kernel's start) and this wait)]: a K loop = `s_waitcnt vmcnt(N) lgkmcnt(0)` directly followed by
-    s_barrier, up to the branch back to a label at or above it."""
+    the previous loop (or the kernel's start) and this wait)]: a K loop = `s_waitcnt vmcnt(N) lgkmcnt(0)` followed by s_barrier
+    within a few (scalar) instructions, up to the branch back to a label at or above it."""
     labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r'^(\.LBB\d+_\d+):', l)] if m}
     # the kernels' own counted wait is inline assembly (;;#ASMSTART in front of it): a compiler-generated `s_waitcnt vmcnt(0) lgkmcnt(0)`
     # before the s_barrier of a __syncthreads() is not a K-loop top
     tops = [i for i, l in enumerate(lines) if re.search(r's_waitcnt vmcnt\(\d+\) lgkmcnt\(0\)', l)
-            and i > 0 and '#ASMSTART' in lines[i - 1] and any('s_barrier' in x for x in lines[i + 1:i + 4])]
+            and i > 0 and '#ASMSTART' in lines[i - 1] and any('s_barrier' in x for x in lines[i + 1:i + 12])]
     out, prev_end = [], 0
     for top in tops:
         n = int(re.search(r'vmcnt\((\d+)\)', lines[top]).group(1))
