@@ -349,23 +349,12 @@ __device__ int topk_keys(const u64* __restrict__ keys, int m, int top_k, ImageLd
   return min(n_sel, top_k);
 }
 
-__device__ __forceinline__ bool nms_suppresses(const float* bi, const float* bj, float thr) {
-  // np_methods.py:186-205 (bboxes_jaccard), float32, one rounding per operation
-  const float ih = fmaxf(fminf(bi[2], bj[2]) - fmaxf(bi[0], bj[0]), 0.f);
-  const float iw = fmaxf(fminf(bi[3], bj[3]) - fmaxf(bi[1], bj[1]), 0.f);
-  const float inter = ih * iw;
-  const float vol1 = (bi[2] - bi[0]) * (bi[3] - bi[1]);
-  const float vol2 = (bj[2] - bj[0]) * (bj[3] - bj[1]);
-  const float iou = inter / (vol1 + vol2 - inter);
-  return !(iou < thr);   // NaN suppresses, as logical_or(overlap < thr, ...) does
-  // (round 4: deciding most pairs with v_rcp_f32 + a multiply and dividing only near the threshold changed nothing measurable -
-  // 87.6 vs 88 us per batch in the 1 k-candidate regime: the pass is not bound by the division)
-}
-
-// The same decision as nms_suppresses with the two areas given, for the pair loop of the class-wise scan, which is bound by the
-// vector ALU of its one CU: the quotient is first estimated with v_rcp_f32 (1 ulp) and only a pair whose estimate lies within
-// 1e-6 of the threshold - or whose denominator is not a normal positive number - takes the IEEE division; every other pair is
-// decided by the estimate, whose error (< 3e-7 relative) cannot move it across the threshold.
+// np_methods.py:186-205 (bboxes_jaccard) + :229-242: does box i remove box j?  float32, one rounding per operation:
+//     iou = inter / (vol1 + vol2 - inter);  suppressed = !(iou < thr)      (NaN suppresses, as logical_or(overlap < thr, ...) does)
+// with the two areas given (they are per-row values).  The pair loop of the class-wise scan is bound by the vector ALU of its one
+// CU: the quotient is first estimated with v_rcp_f32 (1 ulp) and only a pair whose estimate lies within 1e-6 of the threshold - or
+// whose denominator is not a normal positive number - takes the IEEE division; every other pair is decided by the estimate, whose
+// error (< 3e-7 relative) cannot move it across the threshold.
 __device__ __forceinline__ bool nms_suppresses_vol(const float* bi, float vol1, const float* bj, float vol2, float thr) {
   const float ih = fmaxf(fminf(bi[2], bj[2]) - fmaxf(bi[0], bj[0]), 0.f);
   const float iw = fmaxf(fminf(bi[3], bj[3]) - fmaxf(bi[1], bj[1]), 0.f);
@@ -390,63 +379,105 @@ __device__ __forceinline__ bool tfe_suppresses(const float* bi, const float* bj,
   return !(sc < thr);
 }
 
-// Suppression bit matrix of the n sorted boxes in lds (row i: which later rows box i removes), then the
-// greedy scan by one wave.  Leaves in lds.hist: [0..7] low / [16..23] high halves of the keep bits per
-// 64-row word, [32..39] exclusive kept counts per word; lds.scalars[4] = number kept (<= max_keep).
+// The pair test of the three NMS flavours with the two areas given: `be` / `ve` the EARLIER row of the score order (the box that
+// would do the suppressing), `bl` / `vl` the later one.  mode 0 = np_methods IoU (plain division: 0 / 0 = NaN suppresses), 1 = 'min',
+// 2 = 'union' of tf_extended/bboxes.py:195-211 (safe_divide: 0 when the denominator is not positive).  The operand order of the
+// reference's sums is kept ('union': (vol_later - inner) + vol_earlier).  The quotient is estimated with v_rcp_f32 first, as in
+// nms_suppresses_vol: only estimates within 1e-6 of the threshold or unusual denominators take the IEEE division.
+__device__ __forceinline__ bool pair_suppresses(const float* be, float ve, const float* bl, float vl, float thr, int mode) {
+  const float ih = fmaxf(fminf(bl[2], be[2]) - fmaxf(bl[0], be[0]), 0.f);
+  const float iw = fmaxf(fminf(bl[3], be[3]) - fmaxf(bl[1], be[1]), 0.f);
+  const float inner = ih * iw;
+  const float den = mode == 0 ? (ve + vl - inner) : mode == 2 ? (vl - inner + ve) : fminf(vl, ve);
+  const float est = inner * __builtin_amdgcn_rcpf(den);
+  const bool sure_below = est < thr * (1.f - 1e-6f), sure_above = est > thr * (1.f + 1e-6f);
+  if ((sure_below || sure_above) && den > 1e-30f && den < 1e30f) return sure_above;
+  const float q = (mode == 0 || den > 0.f) ? inner / den : 0.f;
+  return !(q < thr);
+}
+
+// Greedy NMS of the n sorted boxes in lds, any flavour, all rows one segment (the TF variant: one workgroup per class; np_methods
+// with class ids beyond the class-wise scan's 64: mode 0 with the label test).  Same scheme as nms_scan_classwise below: the bit
+// matrix by COLUMNS (row b: the earlier rows that overlap it), a quarter wave per row, then per 64-row block the fixed point of
+// kept = alive & ((column & kept) == 0) on wave 0.  Stopping after max_keep kept rows = keeping the first max_keep of them.
+// Leaves in lds.hist: [0..15] low / [16..31] high halves of the keep bits per 64-row word, [32..47] exclusive kept counts per
+// word; lds.scalars[4] = number kept (<= max_keep).
 __device__ void nms_scan(ImageLds& lds, int n, float nms_thr, int mode, int max_keep) {
-  const int tid = threadIdx.x;
-  const int nth = blockDim.x;
+  const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
   const int words = (n + 63) >> 6;
   u64* mask = lds.sort;    // [n][kMaskWords]
-  for (int idx = tid; idx < n * words; idx += nth) {
-    const int i = idx / words, w = idx - i * words;
-    u64 bits = 0;
-    const int j0 = w << 6;
-    const int j1 = min(n, j0 + 64);
-    const int ci = lds.cls[i];
-    for (int j = max(j0, i + 1); j < j1; ++j) {
-      const bool sup = mode == 0 ? (lds.cls[j] == ci && nms_suppresses(lds.box[i], lds.box[j], nms_thr))
-                                 : tfe_suppresses(lds.box[i], lds.box[j], nms_thr, mode);
-      if (sup) bits |= 1ull << (j - j0);
-    }
-    mask[i * kMaskWords + w] = bits;
-  }
+  for (int i = tid; i < n; i += nth) lds.gvol[i] = (lds.box[i][2] - lds.box[i][0]) * (lds.box[i][3] - lds.box[i][1]);
   __syncthreads();
-  // serial part: one wave, lane w owns word w of the "removed" set
-  if (tid < 64) {
-    const int lane = tid;
-    u64 removed = 0;
-    u64 keep_bits = 0;     // lane w: kept rows of word w
-    int n_kept = 0;
-    u64 row = (lane < words && n > 0) ? mask[lane] : 0;         // mask row i, fetched one iteration ahead
-    for (int i = 0; i < n && n_kept < max_keep; ++i) {
-      const u64 cur = row;
-      if (i + 1 < n) row = (lane < words) ? mask[(i + 1) * kMaskWords + lane] : 0;
-      const int wi = i >> 6;
-      const unsigned lo = __builtin_amdgcn_readlane((unsigned)(removed & 0xFFFFFFFFull), wi);
-      const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), wi);
-      const u64 rw = ((u64)hi << 32) | lo;
-      const bool kept = ((rw >> (i & 63)) & 1ull) == 0;
-      if (kept) {
-        removed |= cur;
-        if (lane == wi) keep_bits |= 1ull << (i & 63);
-        ++n_kept;
+  {
+    typedef unsigned short __attribute__((may_alias)) u16a;
+    u16a* mask16 = reinterpret_cast<u16a*>(mask);
+    const int sub = lane >> 4, sl = lane & 15;
+    for (int r0 = wave * 4; r0 < n; r0 += nwaves * 4) {
+      const int b = r0 + sub;
+      const bool live = b < n;
+      float bb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bb[q] = live ? lds.box[b][q] : 0.f;
+      const float vb = live ? lds.gvol[b] : 0.f;
+      const int cb = live ? lds.cls[b] : -1;
+      if (live && sl <= (b >> 6)) mask[b * kMaskWords + sl] = 0;
+      const int iters_me = (live && b > 0) ? ((b - 1) >> 4) + 1 : 0;   // 16-row slots [0, (b - 1) >> 4] hold the rows in [0, b)
+      int iters = max(iters_me, __shfl_xor(iters_me, 16, 64));
+      iters = max(iters, __shfl_xor(iters, 32, 64));
+#pragma unroll 2
+      for (int it = 0; it < iters; ++it) {
+        const int a = (it << 4) + sl;
+        const int ac = min(a, kMaxTopK - 1);
+        const bool sup = pair_suppresses(lds.box[ac], lds.gvol[ac], bb, vb, nms_thr, mode) && (mode != 0 || lds.cls[ac] == cb) &&
+                         it < iters_me && a < b;
+        const u64 bal = __ballot(sup);
+        const unsigned half = (sub & 2) ? (unsigned)(bal >> 32) : (unsigned)(bal & 0xFFFFFFFFull);
+        if (sl == 0 && it < iters_me) mask16[(b * kMaskWords << 2) + it] = (unsigned short)(half >> ((sub & 1) << 4));
       }
     }
-    // exclusive prefix of kept counts per word
-    int cnt = (lane < words) ? __popcll(keep_bits) : 0;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    u64* keptw = lds.keptw[0];
+    for (int wb = 0; wb < words; ++wb) {
+      const int r = (wb << 6) + lane;
+      const bool in = r < n;
+      u64 hit = 0;
+      for (int w = 0; w < wb; ++w) hit |= (in ? mask[r * kMaskWords + w] : 0ull) & keptw[w];
+      const u64 col = in ? mask[r * kMaskWords + wb] : 0ull;
+      const bool alive = in && hit == 0;
+      u64 kept = __ballot(alive);
+      for (;;) {
+        const u64 next = __ballot(alive && (col & kept) == 0);
+        if (next == kept) break;
+        kept = next;
+      }
+      if (lane == 0) keptw[wb] = kept;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // lane w: kept rows of word w, cut after the max_keep-th kept row of the score order
+    u64 kb = lane < words ? keptw[lane] : 0ull;
+    int cnt = __popcll(kb);
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int v = __shfl_up(incl, d, 64);
       if (lane >= d) incl += v;
     }
-    if (lane < kMaskWords) {
-      lds.hist[lane] = (unsigned)(keep_bits & 0xFFFFFFFFull);
-      lds.hist[16 + lane] = (unsigned)(keep_bits >> 32);
-      lds.hist[32 + lane] = (unsigned)(incl - cnt);
+    const int excl = incl - cnt;
+    if (excl >= max_keep) kb = 0;
+    else if (incl > max_keep) {
+      u64 rest = kb;
+      for (int k = 0; k < max_keep - excl; ++k) rest &= rest - 1;      // the set bits beyond the first max_keep - excl
+      kb &= ~rest;
     }
-    if (lane == 63) lds.scalars[4] = incl;
+    if (lane < kMaskWords) {
+      lds.hist[lane] = (unsigned)(kb & 0xFFFFFFFFull);
+      lds.hist[16 + lane] = (unsigned)(kb >> 32);
+      lds.hist[32 + lane] = (unsigned)min(excl, max_keep);
+    }
+    if (lane == 63) lds.scalars[4] = min(incl, max_keep);
   }
   __syncthreads();
 }

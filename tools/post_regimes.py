@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ron_tensorflow_amd import ops
+from ron_tensorflow_amd import ops, tfe
 from ron_tensorflow_amd.nets.ron_vgg_320 import RONNet
 
 
@@ -40,8 +40,22 @@ def main():
             det, _, ncand = ops.post_np(t[0], t[1], t[2], adev)
         e1.record()
         torch.cuda.synchronize()
-        print('bg %+.0f ob %+.0f: %8.0f candidates / image, %6.1f detections / image, %8.1f us per batch of 32'
-              % (bg, ob, float(ncand.float().mean()), float(det.count.float().mean()), e0.elapsed_time(e1) * 100), flush=True)
+        us_np = e0.elapsed_time(e1) * 100
+        # the TF-evaluation variant on the same heads with eval_ron_network.py's flags (:60-71: select 0.01, nms 0.4, top_k 200, keep 100)
+        kw = dict(objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.4, top_k=200, keep_top_k=100,
+                  cls_is_prob=False, obj_is_prob=False, loc_decoded=False)
+        for _ in range(3):
+            sc, bb = tfe.post_tfe(t[0], t[1], t[2], adev, **kw)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            sc, bb = tfe.post_tfe(t[0], t[1], t[2], adev, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        print('bg %+.0f ob %+.0f: %8.0f candidates / image, %6.1f detections / image, %8.1f us per batch of 32 (np_methods);  '
+              'TF variant: %6.1f detections / image, %8.1f us'
+              % (bg, ob, float(ncand.float().mean()), float(det.count.float().mean()), us_np,
+                 float((sc > 0).sum()) / sc.shape[0], e0.elapsed_time(e1) * 100), flush=True)
 
 
 if __name__ == '__main__':
