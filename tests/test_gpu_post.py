@@ -268,3 +268,35 @@ def test_list_sort_handles_negative_zero_and_nan_scores(ops, dev):
         order = np.argsort(-scores, kind='stable')
     assert list(srt['anchor_index']) == list(order)
     assert list(got['anchor_index']) == list(order)
+
+
+def _chain_boxes(n, w=0.002, d=0.0006, jitter=None):
+    """Boxes i and i+1 overlap beyond 0.45 (IoU (w-d)/(w+d) = 0.54), i and i+2 do not (0.25): greedy NMS keeps every other box,
+    and whether box i survives depends on box i-1, which depends on box i-2, ... -- the longest possible dependency chain."""
+    x0 = np.arange(n, dtype=np.float32) * np.float32(d) + np.float32(0.01)
+    if jitter is not None:
+        x0 = x0 + jitter.astype(np.float32)
+    b = np.stack([np.full(n, 0.1, np.float32), x0, np.full(n, 0.9, np.float32), x0 + np.float32(w)], axis=1)
+    return np.ascontiguousarray(b.astype(np.float32))
+
+
+@pytest.mark.parametrize('layout', ['one_class', 'two_classes', 'three_classes_mixed', 'class_id_70', 'jitter'])
+def test_nms_long_suppression_chains(ops, dev, layout):
+    """The class-wise scan decides 64 rows per fixed-point iteration and the generic scan likewise: chains of suppressions as long as
+    a class, across the 64-row blocks, against np_methods' sequential loop (nets/np_methods.py:229-242)."""
+    from oracle import np_post
+    n = 400
+    rs = np.random.RandomState(11)
+    scores = np.linspace(0.99, 0.05, n).astype(np.float32)
+    boxes = _chain_boxes(n, jitter=rs.uniform(-2e-4, 2e-4, n) if layout == 'jitter' else None)
+    classes = {'one_class': np.full(n, 5), 'two_classes': 3 + 4 * (np.arange(n) % 2),
+               'three_classes_mixed': np.array([1, 1, 2, 1, 3, 3, 2])[np.arange(n) % 7], 'class_id_70': np.full(n, 70),
+               'jitter': 1 + (np.arange(n) // 150)}[layout].astype(np.int64)
+    got, _ = _run_list(ops, dev, classes, scores, boxes)
+    sc, ss, sb = np_post.bboxes_sort(classes, scores, boxes, top_k=400)
+    rc, rsc, rb = np_post.bboxes_nms(sc, ss, sb, nms_threshold=0.45)
+    assert np.array_equal(got['classes'], rc) and np.array_equal(got['scores'], rsc) and np.array_equal(got['bboxes'], rb)
+    if layout in ('one_class', 'class_id_70'):
+        assert len(rc) == n // 2                              # every other box
+    if layout == 'two_classes':
+        assert len(rc) == n                                   # same-class neighbours are two steps apart: nothing goes

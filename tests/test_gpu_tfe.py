@@ -72,3 +72,31 @@ def test_unknown_nms_mode_raises(dev):
     with pytest.raises(ValueError):
         tfe.post_tfe([torch.zeros((1, 1, 1, 1, 21), device=dev)], None, [torch.zeros((1, 1, 1, 1, 4), device=dev)], None,
                      nms_mode='iou')
+
+
+@pytest.mark.parametrize('mode,keep', [('min', 200), ('union', 200), ('union', 37)])
+def test_long_suppression_chain_per_class(dev, mode, keep):
+    """One class holds a chain of boxes in which every box overlaps only its neighbours: the kept set alternates along the whole list,
+    across the 64-row blocks of the scan, and keep_top_k cuts it in the middle (tf_extended/bboxes.py:173-234)."""
+    from ron_tensorflow_amd import tfe
+    shapes = [(5, 5), (10, 10), (20, 20), (40, 40)]
+    pred = [np.zeros((1, h, w, 10, 21), np.float32) for h, w in shapes]
+    boxes = [np.zeros((1, h, w, 10, 4), np.float32) for h, w in shapes]
+    n = 200
+    x0 = (np.arange(n) * 0.0006 + 0.01).astype(np.float32)
+    # 'min' overlap of neighbours: (w - d) / w = 0.7, of second neighbours 0.4; 'union': 0.54 / 0.25
+    chain = np.stack([np.full(n, 0.1, np.float32), x0, np.full(n, 0.9, np.float32), x0 + np.float32(0.002)], axis=1)
+    flat_p, flat_b = pred[3].reshape(-1, 21), boxes[3].reshape(-1, 4)
+    flat_p[:n, 7] = np.linspace(0.95, 0.2, n).astype(np.float32)
+    flat_b[:n] = chain
+    flat_p[n:2 * n:3, 2] = 0.5                      # a second class with identical boxes: one survivor
+    flat_b[n:2 * n:3] = np.array([0.2, 0.2, 0.6, 0.6], np.float32)
+    thr = 0.45
+    ds, db = tfe.detected_bboxes(_to_dev(pred, dev), _to_dev(boxes, dev), num_classes=21, select_threshold=0.01, nms_threshold=thr,
+                                 clipping_bbox=[0., 0., 1., 1.], top_k=200, keep_top_k=keep, nms_mode=mode, min_size=None)
+    rs, rb = tfe_post.detected_bboxes(pred, boxes, num_classes=21, select_threshold=0.01, nms_threshold=thr,
+                                      clipping_bbox=[0., 0., 1., 1.], top_k=200, keep_top_k=keep, nms_mode=mode, min_size=None)
+    for c in range(1, 21):
+        assert np.array_equal(ds[c].cpu().numpy(), rs[c]), c
+        assert np.array_equal(db[c].cpu().numpy(), rb[c]), c
+    assert int((rs[7] > 0).sum()) == min(keep, n // 2) and int((rs[2] > 0).sum()) == 1
