@@ -299,8 +299,9 @@ typedef struct {
  * per convolution (same results up to the order of the fp32 partial sums: the split of K differs; tests compare the two). */
 #define RON_CFG_NO_GROUPS 8u
 /* Small maps with large filters spend a good part of their MACs on the zero halo (fc6: 7x7 on 10 x 10, 31 %; conv6 of SSD-512;
- * the 3x3 heads of the 5 x 5 / 10 x 10 scales).  By default such launches order their GEMM rows position-major and every tile
- * skips the filter rows that fall outside the image for all of its rows (bit-identical results: only products with zeros go).
+ * the 3x3 heads of the 5 x 5 / 10 x 10 scales).  By default such launches order their GEMM rows by output row first (output row,
+ * image, column) and every tile skips the filter rows that fall outside the image for all of its rows, walking the others from the
+ * filter's centre row (only products with zeros go; the fp32 sums are taken in another order, so the last bit may differ).
  * This flag keeps the image-major order and the full K loop (tests compare the two). */
 #define RON_CFG_NO_HALO_SKIP 16u
 /* Which grouped plan the RON heads run: by default contexts with max_batch <= 12 launch the heads one launch per dependency
