@@ -14,6 +14,8 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(8))) unsigned u32x8;
+typedef __attribute__((ext_vector_type(32))) float f32x32;
 
 template <int N> struct alignas(4 * N) F32Vec { float v[N]; };
 template <int N> __device__ __forceinline__ void store_f32_vec(float* p, const float* v) {
@@ -76,6 +78,7 @@ struct ConvArgs {
 // row l % kMT, 16-byte K group l / kMT.  Same FLOP per cycle; the 16x16 form holds a higher clock under load
 // (MI355X_MICROARCH.md, DVFS item 7).
 struct TraitsBF16 {
+  static constexpr bool kIsBf16 = true;
   typedef __hip_bfloat16 elem;
   typedef f32x16 acc_t;
   static constexpr int kMT = 32;
@@ -103,6 +106,7 @@ struct TraitsBF16 {
   }
 };
 struct TraitsF16 {
+  static constexpr bool kIsBf16 = false;
   typedef _Float16 elem;
   typedef f32x16 acc_t;
   static constexpr int kMT = 32;
@@ -243,6 +247,10 @@ struct TraitsF16X3S {
   }
 };
 
+// traits whose 256 x 256 tile has the four-wave assembly K loop (kloop4w.inc): bf16 and f16 on v_mfma_f32_16x16x32
+template <class Tr> struct AsmLoop { static constexpr bool value = false; };
+template <> struct AsmLoop<TraitsBF16S> { static constexpr bool value = true; };
+template <> struct AsmLoop<TraitsF16S> { static constexpr bool value = true; };
 template <class Tr, class = void> struct IsSplit { static constexpr bool value = false; };
 template <class Tr> struct IsSplit<Tr, decltype((void)Tr::kSplit)> { static constexpr bool value = Tr::kSplit; };
 // MFMA instructions one (row tile, column tile) pair issues in k-step s of a stage
@@ -278,50 +286,62 @@ typedef __attribute__((address_space(3))) void lds_void;
 // optional relu(x + residual) (reverse-connection sum, nets/ron_vgg_320.py:425), optional fused 2x2 max-pool (tile rows
 // are ordered window-major, so a pool window is four consecutive accumulator registers of one lane), one vector store
 // per row (dtype or fp32).  s_out_off[row] = element offset of the row's output pixel, -1 for rows that store nothing.
-template <class Tr, int MR, int NR, int MT, int EPA>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, typename Tr::acc_t (&acc)[MR][NR], const int* s_out_off, int row0,
-                                              int fh, int n_glob, int n_store, int tap_off, const int* s_out2_off = nullptr) {
+// `rd.row(i, e, v)` delivers v[j] = accumulator register e of the lane's (row tile i, column tile j), j < NR: from a register array
+// (AccArray) or, for the assembly K loop, straight from the accumulation registers (conv_mfma.hip).
+template <class Tr, int MR, int NR>
+struct AccArray {
+  typename Tr::acc_t (&acc)[MR][NR];
+  __device__ __forceinline__ void row(int i, int e, float (&v)[NR]) const {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) v[j] = acc[i][j][e];
+  }
+};
+
+template <class Tr, int MR, int NR, int MT, int EPA, class Reader>
+__device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader& rd, const int* s_out_off, int row0,
+                                                int fh, int n_glob, int n_store, int tap_off, const int* s_out2_off = nullptr) {
   float bias_v[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) bias_v[j] = p.bias[n_glob + j];
   const int n_valid = p.Cout - n_glob;                 // channels of this lane's group that exist (may be <= 0)
   if (n_valid <= 0) return;
   if (p.pool) {
-    if (p.out2 != nullptr && s_out2_off != nullptr) {
-      // the un-pooled map as well (s_out2_off[row] = element offset of the row's pixel in out2, channel slice included)
-#pragma unroll
-      for (int i = 0; i < MR; ++i) {
-#pragma unroll
-        for (int e = 0; e < EPA; ++e) {
-          const int ooff = s_out2_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
-          if (ooff < 0) continue;
-          float v[NR];
-#pragma unroll
-          for (int j = 0; j < NR; ++j) {
-            v[j] = fmaf(acc[i][j][e], p.oscale, bias_v[j]);
-            if (p.relu) v[j] = fmaxf(v[j], 0.f);
-          }
-          const int o = ooff + n_store;
-          if (n_valid >= NR) {
-            Tr::template store_vec<NR>(p.out2, o, v);
-          } else {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) if (j < n_valid) Tr::store(p.out2, o + j, v[j]);
-          }
-        }
-      }
-    }
     // max over the 2x2 window = max over registers 4t..4t+3; relu(max(x) + b) == max(relu(x + b))
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
 #pragma unroll
       for (int t = 0; t < EPA / 4; ++t) {
+        float w[4][NR];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rd.row(i, 4 * t + u, w[u]);
+        if (p.out2 != nullptr && s_out2_off != nullptr) {
+          // the un-pooled map as well (s_out2_off[row] = element offset of the row's pixel in out2, channel slice included)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = 4 * t + u;
+            const int ooff = s_out2_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
+            if (ooff < 0) continue;
+            float v[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+              v[j] = fmaf(w[u][j], p.oscale, bias_v[j]);
+              if (p.relu) v[j] = fmaxf(v[j], 0.f);
+            }
+            const int o = ooff + n_store;
+            if (n_valid >= NR) {
+              Tr::template store_vec<NR>(p.out2, o, v);
+            } else {
+#pragma unroll
+              for (int j = 0; j < NR; ++j) if (j < n_valid) Tr::store(p.out2, o + j, v[j]);
+            }
+          }
+        }
         const int ooff = s_out_off[row0 + i * MT + 8 * t + 4 * fh];
         if (ooff < 0) continue;
         float v[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-          const float mx = fmaxf(fmaxf(acc[i][j][4 * t], acc[i][j][4 * t + 1]), fmaxf(acc[i][j][4 * t + 2], acc[i][j][4 * t + 3]));
+          const float mx = fmaxf(fmaxf(w[0][j], w[1][j]), fmaxf(w[2][j], w[3][j]));
           v[j] = fmaf(mx, p.oscale, bias_v[j]);
           if (p.relu) v[j] = fmaxf(v[j], 0.f);
         }
@@ -340,13 +360,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, typename Tr::ac
   for (int i = 0; i < MR; ++i) {
 #pragma unroll
     for (int e = 0; e < EPA; ++e) {
+      float v[NR];
+      rd.row(i, e, v);
       const int ooff = s_out_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
       if (ooff < 0) continue;
       const int o = ooff + tap_off + n_store;
-      float v[NR];
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        v[j] = fmaf(acc[i][j][e], p.oscale, bias_v[j]);
+        v[j] = fmaf(v[j], p.oscale, bias_v[j]);
         if (p.relu) v[j] = fmaxf(v[j], 0.f);
       }
       if (n_valid >= NR) {
@@ -370,6 +391,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, typename Tr::ac
       }
     }
   }
+}
+
+template <class Tr, int MR, int NR, int MT, int EPA>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, typename Tr::acc_t (&acc)[MR][NR], const int* s_out_off, int row0,
+                                              int fh, int n_glob, int n_store, int tap_off, const int* s_out2_off = nullptr) {
+  conv_epilogue_r<Tr, MR, NR, MT, EPA>(p, AccArray<Tr, MR, NR>{acc}, s_out_off, row0, fh, n_glob, n_store, tap_off, s_out2_off);
 }
 
 // Geometry / pointers of a launch -> kernel arguments (tiling fields are the caller's).

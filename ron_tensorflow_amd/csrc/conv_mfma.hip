@@ -19,6 +19,7 @@
 // This file holds the configurations conv_pick_cfg() can select, nothing else.  The ablation / stamp / experimental forms of
 // this kernel that rounds 1-3 measured (HISTORY.md) are not in the tree: tools/experiments/README.md says where they are.
 #include "conv_device.h"
+#include "kloop4w.inc"
 
 namespace ron {
 namespace detail {
@@ -51,6 +52,47 @@ __device__ __forceinline__ void pin_ksteps() {
   }
 }
 
+// Reads the accumulators of the assembly K loop where it left them (a[0:255], block (i, j) in a[4 * (8 * i + j) : +3]): one
+// v_accvgpr_read per value at the point of use, eight values (one output row of the lane) at a time.  The eight 32-register tuples
+// are the loop's outputs, so the compiler knows they are live; extracting single elements from such a tuple makes hipcc (ROCm 7.2)
+// copy all 256 values into vector registers first (spills), hence the reads by hand.
+struct AccAgpr4w {
+  const f32x32 &c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7;
+  __device__ __forceinline__ void row(int i, int e, float (&v)[8]) const {
+    switch (i * 4 + e) { RON_ACC4W_CASES }
+  }
+};
+
+// Everything after the K loop of conv_igemm_tile: raw fp32 slab store of a split-K slice, or the conv epilogue.
+template <class Tr, int MR, int NR, int MT, int EPA, int TM, int TN, class Reader>
+__device__ __forceinline__ void igemm_finish(const ConvArgs& p, const Reader& rd, const int* s_out_off, const int* s_out2_off, int zsplit,
+                                             int m0, int n0, int wm, int wn, int fr, int fh) {
+  // C/D layout of the 16x16 MFMA: column = lane % 16, row = e + 4 * (lane / 16), e < 4
+  int tap_off = 0, n_base = n0;
+  if (p.up > 0) {
+    const int tap = n0 / p.up_cout;                       // BN divides up_cout: uniform per tile
+    tap_off = ((tap / p.up) * p.out_Wp + (tap % p.up)) * p.out_cstride;
+    n_base = n0 - tap * p.up_cout;
+  }
+  const int nloc = wn * TN + fr * NR;                     // lane -> NR adjacent output channels
+  if (p.splitk > 1) {
+    float* slab = p.partial + (size_t)zsplit * p.M * p.Npad;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+      for (int e = 0; e < EPA; ++e) {
+        float v[NR];
+        rd.row(i, e, v);
+        const int rt = wm * TM + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (s_out_off[rt] < 0) continue;
+        store_f32_vec<NR>(slab + (size_t)(m0 + rt) * p.Npad + n0 + nloc, v);
+      }
+    }
+    return;
+  }
+  conv_epilogue_r<Tr, MR, NR, MT, EPA>(p, rd, s_out_off, wm * TM, fh, n0 + nloc, n_base + nloc, tap_off, s_out2_off);
+}
+
 // Tile configuration: BM x BN block tile, WM x WN waves (each wave owns (BM/WM) x (BN/WN)), S LDS stages.
 // SPREAD 1: the LDS-DMA pieces of a tile are shared out over the k-steps of the stage; 2: all go out during k-step 0.
 // The K order (tap-major, or chunk-major with the taps innermost: ConvArgs::taps_inner, see below) is a run-time property of the
@@ -77,7 +119,11 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   static_assert(TM % 32 == 0 && TN % 32 == 0 && S >= 2 && S <= 5, "bad wave tile / stage count");
   static_assert(NR <= 8, "vector epilogue: at most 8 channels per lane");
   static_assert(SPREAD == 1 || SPREAD == 2, "SPREAD");
-  // layout: [A stage 0 .. S-1][B stage 0 .. S-1][in_off: BM ints][out_off: BM ints][out2_off: BM ints]
+  // The 256 x 256 tile on FOUR waves (128 x 128 per wave, one wave per SIMD, 256 accumulator + 256 vector registers) runs its K loop
+  // as the assembly of kloop4w.inc (tools/gen_kloop4w.py): two tiles of LDS-DMA in flight over two LDS stages, three barriers per
+  // K step.  bf16 / f16 only.
+  constexpr bool kAsmLoop = AsmLoop<Tr>::value && BM == 256 && BN == 256 && WM == 2 && WN == 2 && S == 2;
+  // layout: [A stage 0 .. S-1][B stage 0 .. S-1][in_off: BM ints][out_off: BM ints][out2_off: BM ints][step table (kAsmLoop)]
   char* s_a = smem;
   char* s_b = smem + S * kABytes;
   int* s_in_off = reinterpret_cast<int*>(smem + kRingBytes);
@@ -229,6 +275,75 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   // the launch's order: its [kt0, kt1) is a contiguous range there.
   const bool ti = p.taps_inner != 0 && !center_only;
   const int n_taps = p.KT / chunks_per_tap;
+  typename Tr::acc_t acc[MR][NR];
+  // fragment read offsets: lane -> row r = lane % MT, K group h = lane / MT; step s reads chunk kGroups*s + h
+  const int fr = lane & (MT - 1), fh = lane / MT;
+  int rd_off[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) rd_off[s] = fr * kRowBytes + (((kGroups * s + fh) ^ ((fr >> 1) & 7)) << 4);
+  const int a_base = wm * TM * kRowBytes;
+  const int b_base = wn * TN * kRowBytes;
+  if constexpr (kAsmLoop) {
+    static_assert(KS == 2 && MR == 8 && NR == 8 && A_IT == 8 && B_IT == 8, "kloop4w.inc is written for this tile");
+    // Step table: entry q = {soffset of the A pieces, soffset of the B pieces} of the tile's K step kt0 + q, in the launch's K order
+    // (tap-major / taps innermost / position-major walk, see the loop of the other tiles below); two more entries than steps: the
+    // loop stages two tiles ahead, past the end with zero-record descriptors.
+    int* s_tab = s_out2_off + BM;
+    const int nsteps = max(kt1 - kt0, 0);
+    for (int q = tid; q < nsteps + 2; q += kThreads) {
+      const int g = kt0 + q;
+      int ky_, kx_, cq, wb;
+      if (pm) {
+        const int per_row = p.kw * chunks_per_tap;
+        const int i0 = g / per_row, r0 = g - i0 * per_row;
+        ky_ = ky_first + i0;
+        if (ky_ > ky_hi) ky_ -= ky_hi - ky_lo + 1;
+        cq = r0 / p.kw;
+        kx_ = r0 - cq * p.kw;
+        wb = (ky_ * p.kw + kx_) * chunks_per_tap + cq;
+      } else if (ti) {
+        cq = g / n_taps;
+        const int tap = g - cq * n_taps;
+        ky_ = tap / p.kw;
+        kx_ = tap - ky_ * p.kw;
+        wb = tap * chunks_per_tap + cq;
+      } else {
+        const int tap = g / chunks_per_tap;
+        cq = g - tap * chunks_per_tap;
+        ky_ = tap / p.kw;
+        kx_ = tap - ky_ * p.kw;
+        wb = g;
+      }
+      s_tab[2 * q] = ((ky_ * p.dil * p.in_Wp + kx_ * p.dil) * p.in_cstride + cq * kChunkElems) * Tr::kEsz;
+      s_tab[2 * q + 1] = wb * kWeightBlockBytes;
+    }
+    __syncthreads();
+    u32x8 av, bv;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { av[it] = (unsigned)a_voff[it]; bv[it] = (unsigned)b_voff[it]; }
+    const unsigned lds_a = (unsigned)(uintptr_t)(lds_void*)s_a, lds_b = (unsigned)(uintptr_t)(lds_void*)s_b;
+    const unsigned dst_a = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_a + wave * 1024));
+    const unsigned dst_b = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_b + wave * 1024));
+    const unsigned rd_a0 = lds_a + a_base + rd_off[0], rd_a1 = lds_a + a_base + rd_off[1];
+    const unsigned rd_b0 = lds_b + b_base + rd_off[0], rd_b1 = lds_b + b_base + rd_off[1];
+    const unsigned tab = (unsigned)(uintptr_t)(lds_void*)s_tab;
+    const unsigned long long in_ptr = (unsigned long long)(uintptr_t)p.in, wgt_ptr = (unsigned long long)(uintptr_t)p.wgt;
+    const unsigned in_bytes = p.in_bytes, wgt_bytes = p.wgt_bytes;
+    const unsigned ns = (unsigned)__builtin_amdgcn_readfirstlane(nsteps);
+    f32x32 c0, c1, c2, c3, c4, c5, c6, c7;
+#define RON_KLOOP4W_OPERANDS                                                                                                        \
+        : "={a[0:31]}"(c0), "={a[32:63]}"(c1), "={a[64:95]}"(c2), "={a[96:127]}"(c3), "={a[128:159]}"(c4), "={a[160:191]}"(c5),      \
+          "={a[192:223]}"(c6), "={a[224:255]}"(c7)                                                                                  \
+        : "{s[36:37]}"(in_ptr), "{s[38:39]}"(wgt_ptr), "{s40}"(in_bytes), "{s41}"(wgt_bytes), "{s42}"(ns), "{s43}"(dst_a),          \
+          "{s44}"(dst_b), "{v[100:107]}"(av), "{v[108:115]}"(bv), "{v116}"(rd_a0), "{v117}"(rd_a1), "{v118}"(rd_b0),                \
+          "{v119}"(rd_b1), "{v120}"(tab)                                                                                            \
+        : RON_KLOOP4W_CLOBBERS
+    if constexpr (Tr::kIsBf16) asm volatile(RON_KLOOP4W_BF16 RON_KLOOP4W_OPERANDS);
+    else asm volatile(RON_KLOOP4W_F16 RON_KLOOP4W_OPERANDS);
+#undef RON_KLOOP4W_OPERANDS
+    igemm_finish<Tr, MR, NR, MT, EPA, TM, TN>(p, AccAgpr4w{c0, c1, c2, c3, c4, c5, c6, c7}, s_out_off, s_out2_off, zsplit, m0, n0, wm, wn, fr, fh);
+    return;
+  } else {
   const int tap0 = ti ? kt0 % n_taps : kt0 / chunks_per_tap;
   int ky = tap0 / p.kw, kx = tap0 - (tap0 / p.kw) * p.kw;
   int cc = (ti ? kt0 / n_taps : kt0 - tap0 * chunks_per_tap) * kChunkElems;
@@ -295,21 +410,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
       }                                                                                                              \
     } while (0)
 
-  typename Tr::acc_t acc[MR][NR];
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < NR; ++j)
 #pragma unroll
       for (int e = 0; e < EPA; ++e) acc[i][j][e] = 0.f;
-
-  // fragment read offsets: lane -> row r = lane % MT, K group h = lane / MT; step s reads chunk kGroups*s + h
-  const int fr = lane & (MT - 1), fh = lane / MT;
-  int rd_off[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) rd_off[s] = fr * kRowBytes + (((kGroups * s + fh) ^ ((fr >> 1) & 7)) << 4);
-  const int a_base = wm * TM * kRowBytes;
-  const int b_base = wn * TN * kRowBytes;
 
   // prologue: the steps before the first one, in the order the loop issues them: S-1 tiles in flight
 #pragma unroll
@@ -367,38 +473,19 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
 #undef RON_STAGE_PIECE_A
 #undef RON_STAGE_PIECE_B
 #undef RON_STAGE_END
-  // epilogue.  C/D layout of the 16x16 MFMA: column = lane % 16, row = e + 4 * (lane / 16), e < 4
-  int tap_off = 0, n_base = n0;
-  if (p.up > 0) {
-    const int tap = n0 / p.up_cout;                       // BN divides up_cout: uniform per tile
-    tap_off = ((tap / p.up) * p.out_Wp + (tap % p.up)) * p.out_cstride;
-    n_base = n0 - tap * p.up_cout;
-  }
-  const int nloc = wn * TN + fr * NR;                     // lane -> NR adjacent output channels
-  if (p.splitk > 1) {
-    float* slab = p.partial + (size_t)zsplit * p.M * p.Npad;
-#pragma unroll
-    for (int i = 0; i < MR; ++i) {
-#pragma unroll
-      for (int e = 0; e < EPA; ++e) {
-        const int rt = wm * TM + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (s_out_off[rt] < 0) continue;
-        float v[NR];
-#pragma unroll
-        for (int j = 0; j < NR; ++j) v[j] = acc[i][j][e];
-        store_f32_vec<NR>(slab + (size_t)(m0 + rt) * p.Npad + n0 + nloc, v);
-      }
-    }
-    return;
-  }
-  conv_epilogue<Tr, MR, NR, MT, EPA>(p, acc, s_out_off, wm * TM, fh, n0 + nloc, n_base + nloc, tap_off, s_out2_off);
+  }   // !kAsmLoop
+  igemm_finish<Tr, MR, NR, MT, EPA, TM, TN>(p, AccArray<Tr, MR, NR>{acc}, s_out_off, s_out2_off, zsplit, m0, n0, wm, wn, fr, fh);
 }
 
 
-constexpr int igemm_lds_bytes(int BM, int BN, int S) { return S * (BM + BN) * kRowBytes + 3 * BM * (int)sizeof(int); }
+// K steps one workgroup of the assembly K loop can take (its step table has two more entries): 16 KB of LDS
+constexpr int kAsmLoopMaxSteps = 2046;
+constexpr int igemm_lds_bytes(int BM, int BN, int S, bool asm_loop = false) {
+  return S * (BM + BN) * kRowBytes + 3 * BM * (int)sizeof(int) + (asm_loop ? (kAsmLoopMaxSteps + 2) * 2 * (int)sizeof(int) : 0);
+}
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
-__global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S) > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S) > 80 * 1024) ? (WM * WN + 3) / 4 : 2) void conv_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   conv_igemm_tile<Tr, BM, BN, WM, WN, S, SPREAD>(p, blockIdx.x, gridDim.x, smem);
 }
@@ -443,7 +530,7 @@ __device__ __forceinline__ ConvArgs load_group_op(int k) {
 }
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
-__global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S) > 80 * 1024) ? (WM * WN) / 4 : 2) void conv_igemm_group_kernel(ConvGroupArgs g) {
+__global__ __launch_bounds__(WM * WN * 64, (igemm_lds_bytes(BM, BN, S) > 80 * 1024) ? (WM * WN + 3) / 4 : 2) void conv_igemm_group_kernel(ConvGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GroupPick e = pick_group_entry(g, (int)blockIdx.x);
   const ConvArgs p = load_group_op(e.k);
@@ -535,7 +622,7 @@ __global__ void splitk_finalize_group_kernel(ConvGroupArgs g) {
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 int launch_t(const ConvArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S);
+  const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, AsmLoop<Tr>::value && BM == 256 && WM == 2);
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), (int)lds));
   hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
@@ -544,10 +631,21 @@ int launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 
+// The four-wave assembly K loop takes the 256 x 256 launches of bf16 / f16 whose workgroups' K chains fit its step table
+// (RON_IGEMM256_V1=1: the eight-wave loop instead, for side-by-side timing).
+static bool asm_loop_ok(int steps_per_wg) {
+  static const bool v1 = getenv("RON_IGEMM256_V1") != nullptr;
+  return !v1 && steps_per_wg <= kAsmLoopMaxSteps;
+}
+
 template <class Tr>
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
   switch (cfg) {
-    case kCfgIgemm256: case kCfgIgemm256TapsInner: return launch_t<Tr, 256, 256, 4, 2, 2, 1>(a, s);      // (the K order: ConvArgs::taps_inner)
+    case kCfgIgemm256: case kCfgIgemm256TapsInner:                                                      // (the K order: ConvArgs::taps_inner)
+      if constexpr (AsmLoop<Tr>::value) {
+        if (asm_loop_ok(a.kt_split)) return launch_t<Tr, 256, 256, 2, 2, 2, 1>(a, s);                    // four waves, assembly K loop
+      }
+      return launch_t<Tr, 256, 256, 4, 2, 2, 1>(a, s);
     case kCfgIgemm128: return launch_t<Tr, 128, 128, 2, 2, 2, 1>(a, s);
     case kCfgIgemm128Early: case kCfgIgemm128EarlyTapsInner: return launch_t<Tr, 128, 128, 2, 2, 2, 2>(a, s);
     case kCfgIgemm128x64: return launch_t<Tr, 128, 64, 2, 2, 2, 2>(a, s);
@@ -755,7 +853,7 @@ int launch_group_finalize(const ConvGroupArgs& g, hipStream_t s) {
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 int launch_group_t(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
-  const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S);
+  const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, AsmLoop<Tr>::value && BM == 256 && WM == 2);
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), (int)lds));
   hipLaunchKernelGGL((conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(g.first[g.ne]), dim3(WM * WN * 64), lds, s, g);
@@ -780,7 +878,14 @@ int launch_group_cfg(int cfg, const ConvGroupArgs& g, bool any_split, hipStream_
   if (cfg == kGroupMixed) return launch_group_mixed<Tr>(g, any_split, s);
   if (cfg == kCfgIgemm128x64) return launch_group_t<Tr, 128, 64, 2, 2, 2, 2>(g, any_split, s);
   if (cfg == kCfgIgemm128) return launch_group_t<Tr, 128, 128, 2, 2, 2, 2>(g, any_split, s);      // pieces issued early, as kCfgIgemm128Early
-  if (cfg == kCfgIgemm256) return launch_group_t<Tr, 256, 256, 4, 2, 2, 1>(g, any_split, s);      // two launches of < 1 round each as one
+  if (cfg == kCfgIgemm256) {                                                                       // two launches of < 1 round each as one
+    if constexpr (AsmLoop<Tr>::value) {
+      int longest = 0;
+      for (int k = 0; k < g.n; ++k) longest = std::max(longest, g.op[k].kt_split);
+      if (asm_loop_ok(longest)) return launch_group_t<Tr, 256, 256, 2, 2, 2, 1>(g, any_split, s);
+    }
+    return launch_group_t<Tr, 256, 256, 4, 2, 2, 1>(g, any_split, s);
+  }
   ron::set_error("conv group: tile config %d has no grouped form", cfg);
   return RON_ERR_INVALID;
 }

@@ -104,7 +104,51 @@ def check_patch(name, lines):
     return problems
 
 
+def check_asm4w(name, lines):
+    """The four-wave assembly K loop (kloop4w.inc, tools/gen_kloop4w.py): two whole tiles (2 x 16 pieces) in the prologue and
+    `vmcnt(16)` before the first fragment reads; 16 pieces per K step; the loop's one `vmcnt(N)` has exactly N of them in front of
+    it in the loop body (the previous step's tile has then landed), the rest behind."""
+    top = [i for i, l in enumerate(lines) if re.match(r'^\.Lk4w_loop_\d+:', l)]
+    if len(top) != 1:
+        return ['%d assembly K loops found, expected 1' % len(top)]
+    top = top[0]
+    start = max(i for i in range(top) if '#ASMSTART' in lines[i])
+    end = [i for i in range(top, len(lines)) if re.search(r's_cbranch_scc0 \.Lk4w_loop_\d+', lines[i])]
+    if len(end) != 1:
+        return ['loop end not found']
+    end = end[0]
+    problems = []
+    pro = sum(1 for l in lines[start:top] if DMA.search(l))
+    if pro != 32:
+        problems.append('%d LDS-DMA instructions in the prologue, expected 32' % pro)
+    if not any(re.search(r's_waitcnt vmcnt\(16\)$', l.strip()) for l in lines[start:top]):
+        problems.append('no vmcnt(16) in the prologue')
+    body = lines[top:end]
+    waits = [(i, int(m.group(1))) for i, l in enumerate(body) for m in [re.search(r's_waitcnt vmcnt\((\d+)\)', l)] if m]
+    n_dma = sum(1 for l in body if DMA.search(l))
+    if n_dma != 16:
+        problems.append('%d LDS-DMA instructions per K step, expected 16' % n_dma)
+    if len(waits) != 1:
+        problems.append('%d vmcnt waits in the loop, expected 1' % len(waits))
+    else:
+        before = sum(1 for l in body[:waits[0][0]] if DMA.search(l))
+        if before != waits[0][1]:
+            problems.append('vmcnt(%d) with %d LDS-DMA instructions of the step in front of it' % (waits[0][1], before))
+    if sum(1 for l in body if 's_barrier' in l) != 3:
+        problems.append('%d barriers per K step, expected 3' % sum(1 for l in body if 's_barrier' in l))
+    total = sum(1 for l in lines if DMA.search(l))
+    if total != pro + n_dma:
+        problems.append('%d LDS-DMA instructions outside the assembly loop' % (total - pro - n_dma))
+    return problems
+
+
+def is_asm4w(name):
+    return template_ints(name)[:5] == [256, 256, 2, 2, 2] and ('TraitsBF16S' in name or 'TraitsF16S' in name) and 'mixed' not in name
+
+
 def check_igemm(name, lines):
+    if is_asm4w(name):
+        return check_asm4w(name, lines)
     if 'group_mixed_kernel' in name:
         # conv_igemm_group_mixed_kernel<Tr>: the 128 x 64 and the 128 x 128 tile function (4 waves, S = 2, early issue), one branch each
         forms = [(128, 64, 2, 2, 2), (128, 128, 2, 2, 2)]
@@ -155,7 +199,8 @@ def check_file(source):
 
 
 # instantiations the Makefile's build holds (dtypes x tile forms); a different count means the check no longer sees all of them
-EXPECTED = {'conv_patch.hip': 4 * (3 + 3), 'conv_mfma.hip': 4 * (4 + 3 + 1)}
+# (+ the four-wave assembly form of the 256 x 256 tile and of its grouped kernel, bf16 / f16)
+EXPECTED = {'conv_patch.hip': 4 * (3 + 3), 'conv_mfma.hip': 4 * (4 + 3 + 1) + 2 * 2}
 
 
 def main():
