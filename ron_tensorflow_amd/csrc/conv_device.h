@@ -297,6 +297,92 @@ struct AccArray {
   }
 };
 
+// The rows of a lane whose NR channels all exist, for one combination of the launch's epilogue switches: straight-line code per row
+// (the switches are wave-uniform and decided once, outside), the rows' output offsets read from LDS up front in one batch.  With one
+// wave per SIMD (the four-wave 256 x 256 tile) nothing hides a per-row LDS round trip or a per-value select: the generic row loop took
+// 21.6 k cycles per tile there, an eighth of a 72-step tile.
+template <class Tr, int MR, int NR, int MT, int EPA, bool RELU, bool RES, bool F32, class Reader>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& p, const Reader& rd, const int* s_out_off, int row0, int fh,
+                                                   const float (&bias_v)[NR], int n_store, int tap_off) {
+  int ooff[MR][EPA];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int e = 0; e < EPA; ++e) ooff[i][e] = s_out_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
+  const float oscale = p.oscale;
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+#pragma unroll
+    for (int e = 0; e < EPA; ++e) {
+      float v[NR];
+      rd.row(i, e, v);
+      const int o = ooff[i][e] + tap_off + n_store;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        v[j] = fmaf(v[j], oscale, bias_v[j]);
+        if (RELU) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (ooff[i][e] < 0) continue;
+      if (RES) {
+        float rv[NR];
+        Tr::template load_vec<NR>(p.res, o, rv);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j] + rv[j], 0.f);
+      }
+      if (F32) store_f32_vec<NR>(reinterpret_cast<float*>(p.out) + o, v);
+      else Tr::template store_vec<NR>(p.out, o, v);
+    }
+  }
+}
+
+// The fused 2x2 max-pool form (tile rows are window-major: registers 4t..4t+3 of a lane are one window), optionally with the
+// un-pooled map as a second output; same structure as above.
+template <class Tr, int MR, int NR, int MT, int EPA, bool RELU, bool OUT2, class Reader>
+__device__ __forceinline__ void conv_epilogue_pool_rows(const ConvArgs& p, const Reader& rd, const int* s_out_off, const int* s_out2_off,
+                                                        int row0, int fh, const float (&bias_v)[NR], int n_store) {
+  int ooff[MR][EPA / 4], ooff2[MR][EPA];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+#pragma unroll
+    for (int t = 0; t < EPA / 4; ++t) ooff[i][t] = s_out_off[row0 + i * MT + 8 * t + 4 * fh];
+    if (OUT2) {
+#pragma unroll
+      for (int e = 0; e < EPA; ++e) ooff2[i][e] = s_out2_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
+    }
+  }
+  const float oscale = p.oscale;
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+#pragma unroll
+    for (int t = 0; t < EPA / 4; ++t) {
+      float w[4][NR];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rd.row(i, 4 * t + u, w[u]);
+      if (OUT2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float v[NR];
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            v[j] = fmaf(w[u][j], oscale, bias_v[j]);
+            if (RELU) v[j] = fmaxf(v[j], 0.f);
+          }
+          if (ooff2[i][4 * t + u] >= 0) Tr::template store_vec<NR>(p.out2, ooff2[i][4 * t + u] + n_store, v);
+        }
+      }
+      // max over the 2x2 window = max over registers 4t..4t+3; relu(max(x) + b) == max(relu(x + b))
+      float v[NR];
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const float mx = fmaxf(fmaxf(w[0][j], w[1][j]), fmaxf(w[2][j], w[3][j]));
+        v[j] = fmaf(mx, oscale, bias_v[j]);
+        if (RELU) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (ooff[i][t] >= 0) Tr::template store_vec<NR>(p.out, ooff[i][t] + n_store, v);
+    }
+  }
+}
+
 template <class Tr, int MR, int NR, int MT, int EPA, class Reader>
 __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader& rd, const int* s_out_off, int row0,
                                                 int fh, int n_glob, int n_store, int tap_off, const int* s_out2_off = nullptr) {
@@ -305,8 +391,28 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
   for (int j = 0; j < NR; ++j) bias_v[j] = p.bias[n_glob + j];
   const int n_valid = p.Cout - n_glob;                 // channels of this lane's group that exist (may be <= 0)
   if (n_valid <= 0) return;
+  if (n_valid >= NR) {
+    // every channel of the lane's vector exists (all lanes but the last column tile's tail): the specialised forms
+    if (p.pool) {
+      const bool out2 = p.out2 != nullptr && s_out2_off != nullptr;
+      if (p.relu) {
+        if (out2) conv_epilogue_pool_rows<Tr, MR, NR, MT, EPA, true, true>(p, rd, s_out_off, s_out2_off, row0, fh, bias_v, n_store);
+        else conv_epilogue_pool_rows<Tr, MR, NR, MT, EPA, true, false>(p, rd, s_out_off, s_out2_off, row0, fh, bias_v, n_store);
+      } else {
+        if (out2) conv_epilogue_pool_rows<Tr, MR, NR, MT, EPA, false, true>(p, rd, s_out_off, s_out2_off, row0, fh, bias_v, n_store);
+        else conv_epilogue_pool_rows<Tr, MR, NR, MT, EPA, false, false>(p, rd, s_out_off, s_out2_off, row0, fh, bias_v, n_store);
+      }
+      return;
+    }
+    const int sw = (p.relu ? 1 : 0) | (p.res != nullptr ? 2 : 0) | (p.out_f32 ? 4 : 0);
+#define RON_EPI_CASE(k_) \
+    case k_: conv_epilogue_rows<Tr, MR, NR, MT, EPA, ((k_) & 1) != 0, ((k_) & 2) != 0, ((k_) & 4) != 0>(p, rd, s_out_off, row0, fh, bias_v, n_store, tap_off); break;
+    switch (sw) { RON_EPI_CASE(0) RON_EPI_CASE(1) RON_EPI_CASE(2) RON_EPI_CASE(3) RON_EPI_CASE(4) RON_EPI_CASE(5) RON_EPI_CASE(6) RON_EPI_CASE(7) }
+#undef RON_EPI_CASE
+    return;
+  }
+  // lanes of a partial channel vector: element by element
   if (p.pool) {
-    // max over the 2x2 window = max over registers 4t..4t+3; relu(max(x) + b) == max(relu(x + b))
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
 #pragma unroll
@@ -315,42 +421,29 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
 #pragma unroll
         for (int u = 0; u < 4; ++u) rd.row(i, 4 * t + u, w[u]);
         if (p.out2 != nullptr && s_out2_off != nullptr) {
-          // the un-pooled map as well (s_out2_off[row] = element offset of the row's pixel in out2, channel slice included)
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int e = 4 * t + u;
             const int ooff = s_out2_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
             if (ooff < 0) continue;
-            float v[NR];
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
-              v[j] = fmaf(w[u][j], p.oscale, bias_v[j]);
-              if (p.relu) v[j] = fmaxf(v[j], 0.f);
-            }
-            const int o = ooff + n_store;
-            if (n_valid >= NR) {
-              Tr::template store_vec<NR>(p.out2, o, v);
-            } else {
-#pragma unroll
-              for (int j = 0; j < NR; ++j) if (j < n_valid) Tr::store(p.out2, o + j, v[j]);
+              if (j >= n_valid) break;
+              float x = fmaf(w[u][j], p.oscale, bias_v[j]);
+              if (p.relu) x = fmaxf(x, 0.f);
+              Tr::store(p.out2, ooff + n_store + j, x);
             }
           }
         }
         const int ooff = s_out_off[row0 + i * MT + 8 * t + 4 * fh];
         if (ooff < 0) continue;
-        float v[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
+          if (j >= n_valid) break;
           const float mx = fmaxf(fmaxf(w[0][j], w[1][j]), fmaxf(w[2][j], w[3][j]));
-          v[j] = fmaf(mx, p.oscale, bias_v[j]);
-          if (p.relu) v[j] = fmaxf(v[j], 0.f);
-        }
-        const int o = ooff + n_store;
-        if (n_valid >= NR) {
-          Tr::template store_vec<NR>(p.out, o, v);
-        } else {
-#pragma unroll
-          for (int j = 0; j < NR; ++j) if (j < n_valid) Tr::store(p.out, o + j, v[j]);
+          float x = fmaf(mx, p.oscale, bias_v[j]);
+          if (p.relu) x = fmaxf(x, 0.f);
+          Tr::store(p.out, ooff + n_store + j, x);
         }
       }
     }
@@ -367,27 +460,12 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
       const int o = ooff + tap_off + n_store;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        v[j] = fmaf(v[j], p.oscale, bias_v[j]);
-        if (p.relu) v[j] = fmaxf(v[j], 0.f);
-      }
-      if (n_valid >= NR) {
-        if (p.res != nullptr) {
-          float rv[NR];
-          Tr::template load_vec<NR>(p.res, o, rv);
-#pragma unroll
-          for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j] + rv[j], 0.f);
-        }
-        if (p.out_f32) store_f32_vec<NR>(reinterpret_cast<float*>(p.out) + o, v);
-        else Tr::template store_vec<NR>(p.out, o, v);
-      } else {
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-          if (j >= n_valid) break;
-          float x = v[j];
-          if (p.res != nullptr) x = fmaxf(x + Tr::load(p.res, o + j), 0.f);
-          if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = x;
-          else Tr::store(p.out, o + j, x);
-        }
+        if (j >= n_valid) break;
+        float x = fmaf(v[j], p.oscale, bias_v[j]);
+        if (p.relu) x = fmaxf(x, 0.f);
+        if (p.res != nullptr) x = fmaxf(x + Tr::load(p.res, o + j), 0.f);
+        if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = x;
+        else Tr::store(p.out, o + j, x);
       }
     }
   }
