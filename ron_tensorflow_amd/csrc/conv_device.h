@@ -207,6 +207,7 @@ static __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16
   lo = (_Float16)(v - (float)hi);
 }
 struct TraitsF16X3S {
+  static constexpr bool kIsBf16 = false;
   typedef f32x4 acc_t;
   static constexpr int kMT = 16;
   static constexpr int kEsz = 4;
@@ -247,10 +248,11 @@ struct TraitsF16X3S {
   }
 };
 
-// traits whose 256 x 256 tile has the four-wave assembly K loop (kloop4w.inc): bf16 and f16 on v_mfma_f32_16x16x32
+// traits whose 256 x 256 tile has the four-wave assembly K loop (kloop4w.inc): bf16, f16 and split precision on v_mfma_f32_16x16x32
 template <class Tr> struct AsmLoop { static constexpr bool value = false; };
 template <> struct AsmLoop<TraitsBF16S> { static constexpr bool value = true; };
 template <> struct AsmLoop<TraitsF16S> { static constexpr bool value = true; };
+template <> struct AsmLoop<TraitsF16X3S> { static constexpr bool value = true; };
 template <class Tr, class = void> struct IsSplit { static constexpr bool value = false; };
 template <class Tr> struct IsSplit<Tr, decltype((void)Tr::kSplit)> { static constexpr bool value = Tr::kSplit; };
 // MFMA instructions one (row tile, column tile) pair issues in k-step s of a stage

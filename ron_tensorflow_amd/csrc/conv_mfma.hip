@@ -121,7 +121,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   static_assert(SPREAD == 1 || SPREAD == 2, "SPREAD");
   // The 256 x 256 tile on FOUR waves (128 x 128 per wave, one wave per SIMD, 256 accumulator + 256 vector registers) runs its K loop
   // as the assembly of kloop4w.inc (tools/gen_kloop4w.py): two tiles of LDS-DMA in flight over two LDS stages, three barriers per
-  // K step.  bf16 / f16 only.
+  // K step.  bf16, f16 and the split-precision form (three MFMAs per block); fp32 stays on the eight-wave loop.
   constexpr bool kAsmLoop = AsmLoop<Tr>::value && BM == 256 && BN == 256 && WM == 2 && WN == 2 && S == 2;
   // layout: [A stage 0 .. S-1][B stage 0 .. S-1][in_off: BM ints][out_off: BM ints][out2_off: BM ints][step table (kAsmLoop)]
   char* s_a = smem;
@@ -338,7 +338,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
           "{s44}"(dst_b), "{v[100:107]}"(av), "{v[108:115]}"(bv), "{v116}"(rd_a0), "{v117}"(rd_a1), "{v118}"(rd_b0),                \
           "{v119}"(rd_b1), "{v120}"(tab)                                                                                            \
         : RON_KLOOP4W_CLOBBERS
-    if constexpr (Tr::kIsBf16) asm volatile(RON_KLOOP4W_BF16 RON_KLOOP4W_OPERANDS);
+    if constexpr (IsSplit<Tr>::value) asm volatile(RON_KLOOP4W_F16X3 RON_KLOOP4W_OPERANDS);
+    else if constexpr (Tr::kIsBf16) asm volatile(RON_KLOOP4W_BF16 RON_KLOOP4W_OPERANDS);
     else asm volatile(RON_KLOOP4W_F16 RON_KLOOP4W_OPERANDS);
 #undef RON_KLOOP4W_OPERANDS
     igemm_finish<Tr, MR, NR, MT, EPA, TM, TN>(p, AccAgpr4w{c0, c1, c2, c3, c4, c5, c6, c7}, s_out_off, s_out2_off, zsplit, m0, n0, wm, wn, fr, fh);

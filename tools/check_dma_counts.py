@@ -143,7 +143,7 @@ def check_asm4w(name, lines):
 
 
 def is_asm4w(name):
-    return template_ints(name)[:5] == [256, 256, 2, 2, 2] and ('TraitsBF16S' in name or 'TraitsF16S' in name) and 'mixed' not in name
+    return template_ints(name)[:5] == [256, 256, 2, 2, 2] and ('TraitsBF16S' in name or 'TraitsF16S' in name or 'TraitsF16X3S' in name) and 'mixed' not in name
 
 
 def check_igemm(name, lines):
@@ -199,8 +199,8 @@ def check_file(source):
 
 
 # instantiations the Makefile's build holds (dtypes x tile forms); a different count means the check no longer sees all of them
-# (+ the four-wave assembly form of the 256 x 256 tile and of its grouped kernel, bf16 / f16)
-EXPECTED = {'conv_patch.hip': 4 * (3 + 3), 'conv_mfma.hip': 4 * (4 + 3 + 1) + 2 * 2}
+# (+ the four-wave assembly form of the 256 x 256 tile and of its grouped kernel: bf16, f16, f16x3)
+EXPECTED = {'conv_patch.hip': 4 * (3 + 3), 'conv_mfma.hip': 4 * (4 + 3 + 1) + 3 * 2}
 
 
 def main():

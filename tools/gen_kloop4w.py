@@ -39,7 +39,7 @@ def vr(first, n=4):
     return 'v[%d:%d]' % (first, first + n - 1)
 
 
-def gen(mfma):
+def gen(mfma, split=False):
     L = []
     e = L.append
     # ---- set-up
@@ -108,30 +108,32 @@ def gen(mfma):
     e('s_barrier')
     for j in range(8):
         e('ds_read_b128 %s, v90 offset:%d' % (vr(FB[0][j]), j * FRAG_STEP))
-    for i in range(8):
+    for i in range(7 if split else 8):          # split precision: the last hi fragment of A is read inside the step (see below)
         e('ds_read_b128 %s, v88 offset:%d' % (vr(FA[0][i]), i * FRAG_STEP))
     e('s_waitcnt lgkmcnt(0)')
     # ---- the K step
-    ev = {m: [] for m in range(128)}            # instructions issued right after MFMA m
+    NM = 192 if split else 128
+    ev = {m: [] for m in range(NM)}             # instructions issued right after MFMA m
 
     def at(m, s):
         ev[m].append(s)
-    # B k-half 1 (+ the table entry of tile t+2)
+    # B second fragment set (k-half 1 / lo plane) + the table entry of tile t+2
     for j in range(8):
         at(2 * j, 'ds_read_b128 %s, v91 offset:%d' % (vr(FB[1][j]), j * FRAG_STEP))
     at(1, 'ds_read_b64 v[86:87], v84')
     at(3, 'v_add_u32 v84, 8, v84')
+    if split:
+        at(3, 'ds_read_b128 %s, v88 offset:%d' % (vr(FA[0][7]), 7 * FRAG_STEP))
     at(5, 's_cmp_lt_u32 s58, s42')
     at(5, 's_cselect_b32 s50, s40, 0')
     at(7, 's_cselect_b32 s54, s41, 0')
     at(7, 's_add_u32 s58, s58, 1')
-    at(10, 's_waitcnt lgkmcnt(5)')              # X0 and the table entry are back
+    at(10, 's_waitcnt lgkmcnt(%d)' % (6 if split else 5))      # the table entry is back (LDS operations return in order)
     at(10, 'v_readfirstlane_b32 s56, v86')
     at(10, 'v_readfirstlane_b32 s57, v87')
     at(19, 's_mov_b32 m0, s60')
     at(20, 's_waitcnt lgkmcnt(0)')
     at(21, 's_barrier')
-    # B pieces 0..4 interleaved with the A k-half-1 reads
     bpos = [22, 25, 28, 31, 34, 52, 55, 58]
     for it, m in enumerate(bpos):
         at(m, 'buffer_load_dwordx4 v%d, s[52:55], s57 offen lds' % (108 + it))
@@ -141,38 +143,53 @@ def gen(mfma):
         at(m, 'ds_read_b128 %s, v89 offset:%d' % (vr(FA[1][i]), i * FRAG_STEP))
     at(50, 's_waitcnt lgkmcnt(0)')
     at(51, 's_barrier')
-    apos = [61, 64, 85, 87, 89, 96, 100, 124]
+    if not split:
+        apos = [61, 64, 85, 87, 89, 96, 100, 124]
+        t_xor, t_wait = 83, 91
+        bpos_rd = [93, 94, 95, 97, 98, 102, 103, 104]
+        apos_rd0 = [105, 106, 109, 112, 114, 117, 120, 123]
+        end_wait = 's_waitcnt lgkmcnt(0)'
+    else:
+        # Three products per 16 x 16 x 32 block, in the order of the eight-wave loop (bit-identical sums): MFMA 0..63 hi * hi,
+        # 64..127 lo(A) * hi(B), 128..191 hi(A) * lo(B).  hi(B) is dead after 127 and hi(A) of row tile i after 128 + 8 i + 7: the next
+        # tile's hi fragments go straight into those registers (the last one, row tile 7, at the start of the next step).
+        apos = [61, 64, 67, 70, 73, 76, 79, 82]
+        t_xor, t_wait = 120, 123
+        bpos_rd = [128, 130, 132, 134, 136, 138, 140, 142]
+        apos_rd0 = [137, 145, 153, 161, 169, 177, 185]
+        end_wait = 's_waitcnt lgkmcnt(1)'           # everything but the newest read (hi(A) of row tile 6, needed at MFMA 48)
     for it, m in enumerate(apos):
         at(m, 'buffer_load_dwordx4 v%d, s[48:51], s56 offen lds' % (100 + it))
         if it < 7:
             at(m + 1, 's_add_u32 m0, m0, 0x%x' % PIECE_STEP)
     for k in range(4):
-        at(83, 'v_xor_b32 v%d, v%d, v%d' % (88 + k, 92 + k, 88 + k))
-    at(91, 's_waitcnt vmcnt(13)')
-    at(92, 's_barrier')
-    bpos_rd = [93, 94, 95, 97, 98, 102, 103, 104]
+        at(t_xor, 'v_xor_b32 v%d, v%d, v%d' % (88 + k, 92 + k, 88 + k))
+    n_before = sum(1 for m in range(t_wait) for s_ in ev[m] if s_.startswith('buffer_load'))
+    at(t_wait, 's_waitcnt vmcnt(%d)' % n_before)
+    at(t_wait + 1, 's_barrier')
     for j, m in enumerate(bpos_rd):
         at(m, 'ds_read_b128 %s, v90 offset:%d' % (vr(FB[0][j]), j * FRAG_STEP))
-    apos_rd0 = [105, 106, 109, 112, 114, 117, 120, 123]
     for i, m in enumerate(apos_rd0):
         at(m, 'ds_read_b128 %s, v88 offset:%d' % (vr(FA[0][i]), i * FRAG_STEP))
-    at(125, 's_xor_b32 s59, s59, s62')
-    at(125, 's_xor_b32 s60, s60, s63')
-    at(126, 's_sub_u32 s61, s61, 1')
-    at(126, 's_cmp_eq_u32 s61, 0')
-    at(126, 's_waitcnt lgkmcnt(0)')
-    # sanity: every DMA has an instruction between it and the M0 write before it; counts
-    n_dma = sum(1 for m in ev for s in ev[m] if s.startswith('buffer_load'))
+    at(NM - 3, 's_xor_b32 s59, s59, s62')
+    at(NM - 3, 's_xor_b32 s60, s60, s63')
+    at(NM - 2, 's_sub_u32 s61, s61, 1')
+    at(NM - 2, 's_cmp_eq_u32 s61, 0')
+    at(NM - 2, end_wait)
+    n_dma = sum(1 for m in ev for s_ in ev[m] if s_.startswith('buffer_load'))
     assert n_dma == 16
-    before_91 = sum(1 for m in range(91) for s in ev[m] if s.startswith('buffer_load'))
-    assert before_91 == 13, before_91
+    assert n_before == (16 if split else 13), n_before
     e('.Lk4w_loop_%=:')
-    for m in range(128):
-        h, i, j = m // 64, (m % 64) // 8, m % 8
+    for m in range(NM):
+        ph, i, j = m // 64, (m % 64) // 8, m % 8
         acc = 4 * (8 * i + j)
-        e('%s a[%d:%d], %s, %s, a[%d:%d]' % (mfma, acc, acc + 3, vr(FA[h][i]), vr(FB[h][j]), acc, acc + 3))
-        for s in ev[m]:
-            e(s)
+        if split:
+            a, b = (FA[0][i], FB[0][j]) if ph == 0 else ((FA[1][i], FB[0][j]) if ph == 1 else (FA[0][i], FB[1][j]))
+        else:
+            a, b = FA[ph][i], FB[ph][j]
+        e('%s a[%d:%d], %s, %s, a[%d:%d]' % (mfma, acc, acc + 3, vr(a), vr(b), acc, acc + 3))
+        for s_ in ev[m]:
+            e(s_)
     e('s_cbranch_scc0 .Lk4w_loop_%=')
     e('s_waitcnt vmcnt(0)')
     e('.Lk4w_end_%=:')
@@ -186,9 +203,10 @@ def main():
     with open(out, 'w') as f:
         f.write('// GENERATED by tools/gen_kloop4w.py - do not edit.  The K loop of the 256 x 256 tile on four waves as inline assembly;\n')
         f.write('// interface, schedule and rationale: the generator\'s docstring.\n')
-        for name, mfma in (('BF16', 'v_mfma_f32_16x16x32_bf16'), ('F16', 'v_mfma_f32_16x16x32_f16')):
+        for name, mfma, split in (('BF16', 'v_mfma_f32_16x16x32_bf16', False), ('F16', 'v_mfma_f32_16x16x32_f16', False),
+                                  ('F16X3', 'v_mfma_f32_16x16x32_f16', True)):
             f.write('#define RON_KLOOP4W_%s \\\n' % name)
-            lines = gen(mfma)
+            lines = gen(mfma, split)
             for k, s in enumerate(lines):
                 f.write('  "%s\\n"%s\n' % (s, ' \\' if k + 1 < len(lines) else ''))
             f.write('\n')
