@@ -58,7 +58,8 @@ struct ConvArgs {
   void* out2;
   int out2_Hp, out2_Wp, out2_cstride, out2_pad, out2_coff;
   // tile order inside an XCD's run of workgroups: 0 = N fastest (the column tiles that re-read one activation tile share an L2),
-  // 1 = M fastest (the row tiles that re-read one weight slice do: fc6's 205 MB of weights are then fetched once, not once per XCD)
+  // 1 = M fastest (the row tiles that re-read one weight slice do: fc6's 205 MB of weights are then fetched once, not once per XCD),
+  // 2 = panels of 8 column tiles walked row by row (launches that are both wide and tall)
   int m_fastest;
   // Rows ordered by output row first (m = (oy * n_img + img) * Wo + ox) instead of image-major: a tile then covers few output rows
   // oy, and the filter rows ky whose taps fall into the zero halo for ALL of them are skipped.  (Round 4: the images used to be the

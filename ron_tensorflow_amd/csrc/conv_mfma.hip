@@ -99,6 +99,8 @@ __device__ __forceinline__ void igemm_finish(const ConvArgs& p, const Reader& rd
 // launch: wave-uniform bookkeeping of a few scalar instructions per step.
 // One tile of launch `p`: workgroup `bid` of the `nwg` that launch consists of (a launch of its own, or a range of the
 // workgroups of a grouped launch).
+constexpr int kPanelCols = 8;      // ConvArgs::m_fastest == 2
+
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigned bid, const unsigned nwg, char* smem) {
   constexpr int kLanesPerRow = kRowBytes / 16;       // 16-byte chunks per row
@@ -145,6 +147,14 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   const unsigned tiles_m = (unsigned)p.tiles_total / (unsigned)p.tiles_n;
   int tile_n = (int)(p.m_fastest ? tile / tiles_m : tile % (unsigned)p.tiles_n);
   int tile_m = (int)(p.m_fastest ? tile % tiles_m : tile / (unsigned)p.tiles_n);
+  if (p.m_fastest == 2) {
+    // panels of kPanelCols column tiles, walked row by row: the 32 tiles an XCD runs at a time are 4 rows x 8 columns (12 operand
+    // streams instead of 1 + 32 on a wide launch)
+    const unsigned per_panel = tiles_m * kPanelCols, panel = tile / per_panel, r = tile - panel * per_panel;
+    const unsigned width = min((unsigned)kPanelCols, (unsigned)p.tiles_n - panel * kPanelCols);
+    tile_m = (int)(r / width);
+    tile_n = (int)(panel * kPanelCols + r - (r / width) * width);
+  }
   if (p.center_from_n > 0 && p.splitk == 1) {
     // Column tiles that run the centre tap only (a 1x1 branch beside 3x3 ones) are short: a ninth of the K steps plus a whole
     // tile's set-up and stores.  Interleaved with the long ones they cost more than they save (measured: 857 -> 736 us where
@@ -728,6 +738,12 @@ static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int 
   const int per_xcd = std::max(1, tiles_m * tiles_n / 8);
   const double cost_n = (per_xcd / tiles_n + 1) * a_tile + std::min(tiles_n, per_xcd) * b_tile;
   const double cost_m = std::min(tiles_m, per_xcd) * a_tile + (per_xcd / tiles_m + 1) * b_tile;
+  // 2: panels of kPanelCols column tiles (wide AND tall launches: plain GEMM shapes, fc7 at large batches)
+  if (tiles_n >= 2 * kPanelCols && tiles_m >= 8 && c.center_from == 0) {
+    const double cost_p = std::min(tiles_m, per_xcd / kPanelCols + 1) * a_tile +
+                          std::min(tiles_n, kPanelCols * (per_xcd / (tiles_m * kPanelCols) + 1)) * b_tile;
+    if (cost_p < 0.9 * std::min(cost_n, cost_m)) return 2;
+  }
   return cost_m < 0.95 * cost_n ? 1 : 0;
 }
 
