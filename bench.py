@@ -217,9 +217,9 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    from ron_tensorflow_amd import parallel
+    lay = parallel.rank_layout()
+    world, rank, local_rank = lay['world'], lay['rank'], lay['local_rank']
     if args.gpus != world and world > 1:
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     if args.gpus > 1 and world == 1:
@@ -229,7 +229,7 @@ def main():
     dev = torch.device('cuda', local_rank)
     # under torch.distributed.run the process group (RCCL) exists even for one rank, so that `--nproc-per-node 1` exercises
     # the same gather path as N > 1
-    use_dist = world > 1 or 'RANK' in os.environ
+    use_dist = lay['use_dist']
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -243,22 +243,24 @@ def main():
     ssd = args.variant == 'ssd512'
     ron_class = nets_factory.get_network('ssd_512_vgg' if ssd else 'ron_320_vgg')
     ron_params = ron_class.default_params._replace(num_classes=21)
+    # the same weights on every rank: made once per node and shared through /dev/shm (12 s of RNG per rank otherwise)
     if ssd:
-        weights = ssd_synthetic_weights(seed=5)
+        weights, weights_s, weights_how = parallel.shared_host_arrays(lambda: ssd_synthetic_weights(seed=5), 'ssd512_5', local_rank, use_dist)
         net = ron_class(ron_params, dtype=args.dtype, max_batch=args.batch, device=dev, fuse_pools=True)
     else:
-        weights = synthetic_weights(args.variant, seed=1)     # seed 1: ~4.8 k candidates, ~230 detections per image (full)
+        # seed 1: ~4.8 k candidates, ~230 detections per image (full)
+        weights, weights_s, weights_how = parallel.shared_host_arrays(lambda: synthetic_weights(args.variant, seed=1), args.variant + '_1',
+                                                                      local_rank, use_dist)
         net = ron_class(ron_params, variant=args.variant, dtype=args.dtype, max_batch=args.batch, device=dev, fuse_pools=True,
                         multi_stream=args.multi_stream, head_plan=args.head_plan)
     net.load_weights(weights)
-    images = torch.from_numpy(synthetic_images(args.batch, seed=3 + rank, img_shape=ron_params.img_shape)).to(dev)   # resident in HBM
+    images = torch.from_numpy(synthetic_images(args.batch, seed=lay['image_seed'], img_shape=ron_params.img_shape)).to(dev)   # resident in HBM
     top_k = 400
 
     # One step = one batch through ron_detect.  `--in-flight F` batches are kept in flight on F execution slots (shared
     # weights, one stream each): a step is submitted as soon as its slot's previous batch has been consumed.  The loop itself
     # (step / consume / gather / check, barriers, MAX over ranks) is parallel.bench_loop, which the world-size-2 gloo test
     # drives with a stub pipeline.
-    from ron_tensorflow_amd import parallel
     from ron_tensorflow_amd.pipeline import DetectPipeline
     in_flight = max(1, args.in_flight)
     pipe = DetectPipeline(net, slots=in_flight, top_k=top_k)
@@ -283,6 +285,15 @@ def main():
                               use_dist=use_dist, device=dev, check_gather=args.check_gather, consumer_stream=io_stream,
                               before_timed=before_timed, after_timed=after_timed)
     dt, det, gather_check = res['dt'], res['det'], res['gather_check']
+    ranks_seen = None
+    if use_dist:
+        # who took part: the process group's size and the distinct GPUs behind its ranks (one process per GPU: they must be equal)
+        mine = {'rank': rank, 'local_rank': local_rank, 'device': torch.cuda.current_device(),
+                'uuid': str(getattr(torch.cuda.get_device_properties(dev), 'uuid', 'cuda:%d' % local_rank)), 'image_seed': lay['image_seed']}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        ranks_seen = {'world_size': dist.get_world_size(), 'distinct_devices': len({e['uuid'] for e in every}),
+                      'device_of_rank': [e['device'] for e in every], 'image_seed_of_rank': [e['image_seed'] for e in every]}
 
     # ---- per-launch timing of the timed region (HIP events on the launch stream, inside libron_hip)
     def collect_rows(ctxs):
@@ -384,6 +395,12 @@ def main():
         }
         if gather_check is not None:
             out['gather_check'] = gather_check
+        if use_dist:
+            per_rank = [args.batch * args.steps / t for t in res['rank_dt']]
+            out['ranks_seen'] = ranks_seen
+            out['per_rank_images_per_s'] = {'min': min(per_rank), 'max': max(per_rank)}
+            out['gather_ms'] = res['gather_ms']
+        out['weights'] = {'synthesis_s': weights_s, 'how': weights_how + (' (shared through /dev/shm by local rank 0)' if use_dist and world > 1 else '')}
         if world == 1 and not args.no_cpu_baseline:
             from ron_tensorflow_amd.metrics import detection_agreement
             n1 = max(1, min(args.cpu_images, args.batch))

@@ -14,6 +14,13 @@
  *   - Nothing here synchronises with the host unless stated; work is enqueued on `stream`.
  *   - Ownership: the caller owns every input/output buffer; a ron_ctx owns its weights,
  *     anchors and workspace.  One ron_ctx per device; calls on one ctx are not re-entrant.
+ *     Everything a ctx owns - activations, split-K scratch, ron_detect's head buffers and
+ *     post-processing workspace - is allocated by ron_create / ron_finalize_weights /
+ *     ron_clone for max_batch: no entry point that enqueues work allocates or frees.
+ *     The post-processing workspace of a ctx is cleaned by the kernels that use it, in
+ *     stream order: the ron_detect calls of ONE ctx must all go to one stream, or be ordered
+ *     by the caller (events); two batches in flight take two contexts (ron_clone).  A
+ *     ron_detect that returns an error leaves the workspace to be re-zeroed by the next call.
  *   - Tensor layout: NHWC, row-major, fp32 at the boundary.  Boxes are (ymin, xmin, ymax, xmax)
  *     in normalised image coordinates.  Head tensors are ordered coarse -> fine
  *     (block7 5x5, block6 10x10, block5 20x20, block4 40x40), RONParams.feat_layers,

@@ -99,7 +99,7 @@ int64_t conv_scratch_bytes(const ConvLaunch& c);   // fp32 split-K slabs this la
 // the mixed-width form models the launch's schedule, ~1 ms of host time), or null to compute them here
 int launch_conv_group(const ConvLaunch* ls, int n, int cfg, void* scratch, int64_t scratch_bytes, hipStream_t stream, const int* sk_plan = nullptr);
 void conv_group_plan(const ConvLaunch* ls, int n, int cfg, int* sk);
-int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg);
+int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg, const int* sk_plan = nullptr);   // sk_plan: from conv_group_plan, or null
 constexpr int kMaxConvGroup = 8;
 // launch_conv_group only: every member on the 128-row tile of its own width (128 x 128 when Npad % 128 == 0, else 128 x 64)
 constexpr int kGroupMixed = 64;

@@ -1043,7 +1043,7 @@ static int64_t group_slab_bytes(const ConvLaunch& c, int sk) {
   return sk > 1 ? ron::align_up((int64_t)sk * c.in.N * c.Ho * c.Wo * c.Npad * 4, 256) : 0;
 }
 
-int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg) {
+int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg, const int* sk_plan) {
   int64_t total = 0;
   if (cfg == kCfgPatch64) {                      // a pair of the patch kernel, or each launch on its own
     for (int k = 0; k < n; ++k) total = std::max(total, conv_scratch_bytes(ls[k]));
@@ -1051,7 +1051,8 @@ int64_t conv_group_scratch_bytes(const ConvLaunch* ls, int n, int cfg) {
   }
   if (n < 1 || n > kMaxConvGroup) return 0;
   int sk[kMaxConvGroup];
-  group_splitks(ls, n, cfg, sk);
+  if (sk_plan != nullptr) for (int k = 0; k < n; ++k) sk[k] = sk_plan[k];
+  else group_splitks(ls, n, cfg, sk);
   for (int k = 0; k < n; ++k) total += group_slab_bytes(ls[k], sk[k]);
   return total;
 }

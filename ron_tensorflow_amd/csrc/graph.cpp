@@ -116,6 +116,7 @@ struct ron_ctx {
   float* d_head[3][RON_MAX_LAYERS] = {};
   void* d_post_ws = nullptr;
   int64_t post_ws_bytes = 0;
+  bool post_ws_dirty = false;     // a ron_detect call failed after its select pass may have run: the self-cleaning counters are re-zeroed on the next call
   void* d_stem_w = nullptr;             // conv1_1 fragments + bias for the dedicated stem kernel (bf16 / f16)
   float* d_stem_b = nullptr;
   float stem_oscale = 1.f;              // split precision: 2^-k of the stem weights' scale
@@ -1013,17 +1014,53 @@ static int slot_resources(ron_ctx* c) {
     size_t j = i + 1;
     if (o.kind == OP_CONV && o.group >= 0) while (j < c->ops.size() && c->ops[j].group == o.group) ++j;
     if (o.kind == OP_CONV && (o.group >= 0 || o.up == 0)) {
-      for (int nb = 1; nb <= c->cfg.max_batch; ++nb) {
+      // a clone takes the plans (and with them the scratch sizes) of the slot it was cloned from: the schedule model of a grouped
+      // launch costs ~1 ms per (group, batch)
+      const ron_ctx* from = c->weights_owner;
+      std::vector<std::array<int, kMaxConvGroup>>* plans = nullptr;
+      if (o.group >= 0) {
+        plans = &c->group_sk[(int)i];
+        if (from != nullptr && from->group_sk.count((int)i)) *plans = from->group_sk.at((int)i);
+        else plans->assign(c->cfg.max_batch + 1, std::array<int, kMaxConvGroup>{});
+      }
+      for (int nb = 1; nb <= c->cfg.max_batch && from == nullptr; ++nb) {
         ConvLaunch L[kMaxConvGroup];
         for (size_t k = i; k < j; ++k) describe_conv(c, c->ops[k], nb, nullptr, &L[k - i]);
-        const int64_t b = o.group >= 0 ? conv_group_scratch_bytes(L, (int)(j - i), o.group_cfg) : conv_scratch_bytes(L[0]);
+        int64_t b;
+        if (o.group >= 0) {
+          // the plan ron_forward will launch with, and its scratch, from ONE run of the model
+          conv_group_plan(L, (int)(j - i), o.group_cfg, (*plans)[nb].data());
+          b = conv_group_scratch_bytes(L, (int)(j - i), o.group_cfg, (*plans)[nb].data());
+        } else {
+          b = conv_scratch_bytes(L[0]);
+        }
         if (b > c->splitk_bytes[o.lane]) c->splitk_bytes[o.lane] = b;
       }
     }
     i = j;
   }
+  if (c->weights_owner != nullptr) for (int l = 0; l < 4; ++l) c->splitk_bytes[l] = c->weights_owner->splitk_bytes[l];
   for (int l = 0; l < 4; ++l)
     if (c->splitk_bytes[l] > 0) RON_HIP_CHECK(hipMalloc(&c->d_splitk[l], (size_t)c->splitk_bytes[l]));
+  // ron_detect's head buffers and post-processing workspace, for max_batch: allocated (and the workspace zeroed) here, so that the
+  // first ron_detect is as free of host synchronisation as every later one (include/ron_hip.h, Ownership)
+  {
+    const int mb = c->cfg.max_batch;
+    for (int i = 0; i < c->n_feat; ++i) {
+      const int A = c->feat_A[i];
+      const size_t cells = (size_t)mb * c->feat_h[i] * c->feat_w[i];
+      RON_HIP_CHECK(hipMalloc((void**)&c->d_head[0][i], cells * A * c->cfg.num_classes * sizeof(float)));
+      if (c->has_obj) RON_HIP_CHECK(hipMalloc((void**)&c->d_head[1][i], cells * A * 2 * sizeof(float)));
+      RON_HIP_CHECK(hipMalloc((void**)&c->d_head[2][i], cells * A * 4 * sizeof(float)));
+    }
+    ron_heads hd;
+    memset(&hd, 0, sizeof(hd));
+    int rc = ron_heads_describe(c, &hd);
+    if (rc) return rc;
+    c->post_ws_bytes = ron_post_np_workspace_bytes(&hd, mb);
+    RON_HIP_CHECK(hipMalloc(&c->d_post_ws, (size_t)c->post_ws_bytes));
+    RON_HIP_CHECK(hipMemset(c->d_post_ws, 0, (size_t)c->post_ws_bytes));      // once: the kernels keep the counters clean
+  }
   c->timing.assign(c->ops.size() + 1, OpTiming());
   // names ron_profile_get hands out: a grouped launch is reported on its first member as "group[first+N]", the other members as
   // "(name)"; built once so that the pointers stay valid until ron_destroy
@@ -1147,7 +1184,7 @@ extern "C" int ron_forward(ron_ctx* c, const float* d_images, int n, ron_heads* 
         RON_REQUIRE(j - oi < (size_t)kMaxConvGroup, "conv group %d has more than %d members", o.group, kMaxConvGroup);
         if ((rc = describe_conv(c, c->ops[j], n, out, &L[j - oi]))) return rc;
       }
-      std::vector<std::array<int, kMaxConvGroup>>& plans = c->group_sk[(int)oi];
+      std::vector<std::array<int, kMaxConvGroup>>& plans = c->group_sk[(int)oi];      // filled by slot_resources
       if (plans.empty()) plans.assign(c->cfg.max_batch + 1, std::array<int, kMaxConvGroup>{});
       if (plans[n][0] == 0) conv_group_plan(L, (int)(j - oi), o.group_cfg, plans[n].data());
       if ((rc = launch_conv_group(L, (int)(j - oi), o.group_cfg, c->d_splitk[o.lane], c->splitk_bytes[o.lane], s, plans[n].data()))) {
@@ -1305,23 +1342,17 @@ extern "C" int ron_detect(ron_ctx* c, const float* d_images, int n, const ron_po
   memset(&hd, 0, sizeof(hd));
   DeviceGuard on_device(c->cfg.device);
   RON_HIP_CHECK(on_device.err);
-  if (c->d_head[0][0] == nullptr) {          // first call: allocate ctx-owned head buffers + scratch
-    for (int i = 0; i < c->n_feat; ++i) {
-      const int A = c->feat_A[i];
-      const size_t cells = (size_t)mb * c->feat_h[i] * c->feat_w[i];
-      RON_HIP_CHECK(hipMalloc((void**)&c->d_head[0][i], cells * A * c->cfg.num_classes * sizeof(float)));
-      if (c->has_obj) RON_HIP_CHECK(hipMalloc((void**)&c->d_head[1][i], cells * A * 2 * sizeof(float)));
-      RON_HIP_CHECK(hipMalloc((void**)&c->d_head[2][i], cells * A * 4 * sizeof(float)));
-    }
-  }
+  if (!c->finalized) { ron::set_error("ron_detect before ron_finalize_weights"); return RON_ERR_STATE; }
+  (void)mb;
+  // (head buffers and workspace: slot_resources, at ron_finalize_weights / ron_clone)
   for (int i = 0; i < c->n_feat; ++i) { hd.cls[i] = c->d_head[0][i]; hd.obj[i] = c->d_head[1][i]; hd.loc[i] = c->d_head[2][i]; }
+  if (c->post_ws_dirty) {
+    // an earlier call failed between its select pass and the pass that zeroes the counters again: start from a clean workspace
+    RON_HIP_CHECK(hipMemsetAsync(c->d_post_ws, 0, (size_t)c->post_ws_bytes, (hipStream_t)stream));
+    c->post_ws_dirty = false;
+  }
   int rc = ron_forward(c, d_images, n, &hd, stream);
   if (rc) return rc;
-  if (c->d_post_ws == nullptr) {
-    c->post_ws_bytes = ron_post_np_workspace_bytes(&hd, mb);
-    RON_HIP_CHECK(hipMalloc(&c->d_post_ws, (size_t)c->post_ws_bytes));
-    RON_HIP_CHECK(hipMemsetAsync(c->d_post_ws, 0, (size_t)c->post_ws_bytes, (hipStream_t)stream));      // once: the kernels keep the counters clean
-  }
   ron_post_cfg pc = *cfg;
   pc.input_flags = ron::kPostWsClean;      // logits + raw offsets straight from the conv stack; self-cleaning workspace (common.h)
   const bool prof = !c->pending.empty() && !c->pending_ops.back().empty() && c->pending_ops.back().back() <= -1 &&
@@ -1337,6 +1368,7 @@ extern "C" int ron_detect(ron_ctx* c, const float* d_images, int n, const ron_po
   };
   if (prof && (rc = post_stamp(-2))) return rc;
   rc = ron_post_np(&hd, n, &pc, c->d_post_ws, c->post_ws_bytes, out, nullptr, nullptr, stream);
+  if (rc != RON_OK) c->post_ws_dirty = true;
   if (rc == RON_OK && prof) rc = post_stamp(-3);
   return rc;
 }

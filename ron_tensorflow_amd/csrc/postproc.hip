@@ -208,6 +208,9 @@ struct ImageLds {
   u64 keptw[kTopkThreads / 64][kMaskWords];  // class-wise NMS: the scanning wave's kept rows, one word per 64 grouped positions
 };
 
+// gfx950 only: 64 KB is the static LDS limit of every other target, this struct is 65 832 bytes (the CU has 160 KB)
+static_assert(sizeof(ImageLds) <= 160 * 1024, "ImageLds exceeds the 160 KB of LDS a gfx950 CU has");
+
 __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int j) {
   const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v & 0xFFFFFFFFull), j, 64);
   const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), j, 64);

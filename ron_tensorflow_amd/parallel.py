@@ -21,6 +21,49 @@ def shard_range(n_images, rank, world_size):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def rank_layout(env=None):
+    """What a process launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` derives from its environment:
+    world size, rank, the GPU it drives (cuda:LOCAL_RANK: one process per GPU of the node) and the seed of ITS synthetic images
+    (3 + rank: every rank infers different images, the weights are the same everywhere).  `use_dist`: a process group exists even for one
+    rank under torch.distributed.run, so that `--nproc-per-node 1` exercises the gather path."""
+    import os
+    env = os.environ if env is None else env
+    world, rank, local_rank = int(env.get('WORLD_SIZE', '1')), int(env.get('RANK', '0')), int(env.get('LOCAL_RANK', '0'))
+    if not (0 <= rank < world and 0 <= local_rank <= rank):
+        raise ValueError('inconsistent launch environment: WORLD_SIZE %d RANK %d LOCAL_RANK %d' % (world, rank, local_rank))
+    return dict(world=world, rank=rank, local_rank=local_rank, device_index=local_rank, image_seed=3 + rank,
+                use_dist=world > 1 or 'RANK' in env)
+
+
+def shared_host_arrays(make, tag, local_rank, use_dist, directory='/dev/shm'):
+    """A dict of numpy arrays every rank of the node needs (bench.py's synthetic weights: 229 M parameters, ~12 s of single-threaded
+    RNG): local rank 0 makes it and publishes it as one .npz in `directory` (memory-backed), the others load that after a barrier;
+    the file is removed once everyone has it.  Returns (arrays, seconds this rank spent, 'made' | 'loaded')."""
+    import os
+    import time
+    import numpy as np
+    t0 = time.perf_counter()
+    if not use_dist or dist.get_world_size() == 1:
+        arrays = make()
+        return arrays, time.perf_counter() - t0, 'made'
+    path = os.path.join(directory, 'ron_shared_%s_%s.npz' % (tag, os.environ.get('MASTER_PORT', '0')))
+    how = 'loaded'
+    if local_rank == 0:
+        arrays = make()
+        tmp = path + '.tmp.npz'
+        np.savez(tmp, **arrays)
+        os.replace(tmp, path)
+        how = 'made'
+    dist.barrier()
+    if local_rank != 0:
+        with np.load(path) as z:
+            arrays = {k: z[k] for k in z.files}
+    dist.barrier()
+    if local_rank == 0:
+        os.remove(path)
+    return arrays, time.perf_counter() - t0, how
+
+
 def pack_records(classes, scores, bboxes, anchor_index, count):
     """Per-image detection lists -> one float32 tensor [N, top_k + 1, 7] (same device)."""
     n, k = scores.shape
@@ -74,7 +117,8 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
     After the timed region every rank compares the slice of `gathered` that is its own with its local records and checks
     every rank's counts; the verdict is the MIN over ranks, so one bad rank makes it 'MISMATCH' everywhere.
 
-    Returns dict(dt, det (this rank's last detections), gathered, gather_check ('ok' | 'MISMATCH' | None))."""
+    Returns dict(dt, det (this rank's last detections), gathered, gather_check ('ok' | 'MISMATCH' | None), rank_dt (every rank's own
+    time of the timed region), gather_ms (one all-gather of the records alone, after the timed region))."""
     import contextlib
     import time
     if synchronize is None:
@@ -140,8 +184,24 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
         flag = torch.tensor([1 if (same and sane) else 0], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         gather_check = 'ok' if int(flag.item()) == 1 else 'MISMATCH'
+    rank_dt, gather_ms = [dt], None
     if use_dist:
+        # every rank's own time (the reported one is their MAX) and what ONE gather of the records costs on its own
+        mine = torch.tensor([dt], dtype=torch.float64, device=device)
+        every = torch.empty((world,), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every, mine)
+        rank_dt = [float(x) for x in every.tolist()]
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dict(dt=dt, det=det, gathered=gathered, gather_check=gather_check)
+        rec = pack(det)
+        scratch = torch.empty_like(gathered)       # (not `gathered`: that holds what the timed region's last step gathered)
+        synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        for _ in range(5):
+            with consumer():
+                gather_detections(rec, out=scratch)
+        synchronize()
+        gather_ms = (time.perf_counter() - g0) / 5 * 1e3
+    return dict(dt=dt, det=det, gathered=gathered, gather_check=gather_check, rank_dt=rank_dt, gather_ms=gather_ms)

@@ -20,7 +20,9 @@ def _check_hw_queues(streams_needed):
     default of 4, and streams that share a queue serialise behind each other (measured: -1.8 % images/s).  The runtime reads
     GPU_MAX_HW_QUEUES when it initialises: the package sets it to 8 at import (ron_tensorflow_amd/__init__.py) unless the
     application exported a value of its own.  That cannot help when HIP was already initialised by then (e.g. torch.cuda used before
-    the import, or a profiler's preloaded library): the import time state is recorded below and the case is reported here."""
+    the import): the import time state is recorded below and that case is reported here.  A profiler's preloaded library (rocprofv3)
+    initialises HIP before python starts and is NOT visible from here - the environment reads 8 by then although the runtime took its
+    default: export GPU_MAX_HW_QUEUES=8 in the shell that starts the profiler (tools/profile_round.sh, tools/pmc_*.sh do)."""
     try:
         have = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
     except ValueError:

@@ -22,3 +22,9 @@ def test_single_rank_torchrun_gathers_its_own_records(torchrun_child):
     assert out['gather_check'] == 'ok'
     assert out['n_gpus'] == 1 and out['steps'] == 5 and out['scaling'] == 'weak'
     assert out['value'] > 0 and out['config']['mean_detections_per_image'] > 0
+    # the fields an N > 1 line carries (round 5): who took part, every rank's own rate, one gather alone, how the weights were made
+    assert out['ranks_seen'] == {'world_size': 1, 'distinct_devices': 1, 'device_of_rank': [0], 'image_seed_of_rank': [3]}
+    assert out['per_rank_images_per_s']['min'] > 0 and out['per_rank_images_per_s']['max'] >= out['per_rank_images_per_s']['min']
+    assert abs(out['per_rank_images_per_s']['max'] - out['value']) / out['value'] < 1e-6       # one rank: its rate is the job's
+    assert 0 < out['gather_ms'] < 50
+    assert out['weights']['how'].startswith('made') and out['weights']['synthesis_s'] > 0

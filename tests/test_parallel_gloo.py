@@ -1,4 +1,5 @@
-"""CPU, world_size 2 over gloo: the N > 1 path of bench.py (image sharding + one all-gather of records)."""
+"""CPU, world_size 2 and 8 over gloo: the N > 1 path of bench.py (rank layout, shared weights, image sharding, one all-gather of
+records, the timed loop with its barriers and MAX-over-ranks time)."""
 import os
 import socket
 
@@ -74,14 +75,14 @@ class _StubTicket(object):
 class _StubPipeline(object):
     """submit() -> a ticket whose detections depend on (rank, step); rank r sleeps r * 20 ms per step (ranks finish apart)."""
 
-    def __init__(self, rank, n, k):
-        self.rank, self.n, self.k, self.step, self.log = rank, n, k, 0, []
+    def __init__(self, rank, n, k, sleep_s=0.02):
+        self.rank, self.n, self.k, self.step, self.log, self.sleep_s = rank, n, k, 0, [], sleep_s
 
     def submit(self, images, **detect_args):
         import time
         from ron_tensorflow_amd.ops import DetectionBuffers
         assert detect_args == dict(select_threshold=0.01, nms_threshold=0.45)
-        time.sleep(0.02 * self.rank)
+        time.sleep(self.sleep_s * self.rank)
         det = DetectionBuffers(self.n, self.k, 'cpu')
         cl, sc, bb, ai, cnt = _fake_detections(1000 * self.rank + self.step, self.n, self.k)
         det.classes, det.scores, det.bboxes, det.anchor_index, det.count = cl.to(torch.int32), sc, bb, ai.to(torch.int32), cnt
@@ -93,13 +94,13 @@ def _pack_cpu(det):
     return parallel.pack_records(det.classes, det.scores, det.bboxes, det.anchor_index, det.count)
 
 
-def _bench_worker(rank, world, port, corrupt_rank, ret):
+def _bench_worker(rank, world, port, corrupt_rank, ret, sleep_s=0.02):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         n, k, steps, warmup, in_flight = 3, 400, 4, 2, 2
-        pipe = _StubPipeline(rank, n, k)
+        pipe = _StubPipeline(rank, n, k, sleep_s)
         images = torch.zeros((n, 8, 8, 3))
 
         def after_timed(det):
@@ -115,7 +116,7 @@ def _bench_worker(rank, world, port, corrupt_rank, ret):
         for r in range(world):
             want = parallel.pack_records(*_fake_detections(1000 * r + warmup + steps - 1, n, k))
             found.append(bool(torch.equal(res['gathered'][r], want)))
-        ret[rank] = dict(dt=res['dt'], gather_check=res['gather_check'], found=found,
+        ret[rank] = dict(dt=res['dt'], gather_check=res['gather_check'], found=found, rank_dt=res['rank_dt'], gather_ms=res['gather_ms'],
                          det_is_last=bool(torch.equal(res['det'].count, _fake_detections(1000 * rank + warmup + steps - 1, n, k)[4])))
     finally:
         dist.destroy_process_group()
@@ -136,6 +137,66 @@ def test_bench_loop_world2(corrupt_rank):
     assert r0['dt'] >= 4 * 0.02                                               # ... and it is the slow rank's (4 steps x 20 ms)
     want = 'ok' if corrupt_rank < 0 else 'MISMATCH'
     assert r0['gather_check'] == want and r1['gather_check'] == want          # one bad rank fails the check on every rank
+
+
+def test_bench_loop_world8():
+    """The launch the driver makes on an 8-GPU node (`--nproc-per-node 8`), rehearsed on CPU: eight ranks through the whole timed loop.
+    Every rank ends up with every rank's records, the time is the slowest rank's on all of them, the per-rank times and the cost of one
+    gather are reported."""
+    world, sleep_s = 8, 0.005
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bench_worker, args=(world, _free_port(), -1, ret, sleep_s), nprocs=world, join=True)
+    assert sorted(ret.keys()) == list(range(world))
+    for r in range(world):
+        assert ret[r]['found'] == [True] * world and ret[r]['det_is_last'] and ret[r]['gather_check'] == 'ok'
+        assert ret[r]['dt'] == ret[0]['dt']                                   # MAX over ranks, identical everywhere
+        assert len(ret[r]['rank_dt']) == world and ret[r]['rank_dt'] == ret[0]['rank_dt']
+        assert max(ret[r]['rank_dt']) == ret[r]['dt'] and min(ret[r]['rank_dt']) > 0
+        assert ret[r]['gather_ms'] is not None and ret[r]['gather_ms'] > 0
+    assert ret[0]['dt'] >= 4 * sleep_s * (world - 1)                          # rank 7 sleeps 7 x 5 ms in each of the 4 timed steps
+
+
+def test_rank_layout_of_an_eight_gpu_node():
+    """RANK / LOCAL_RANK / WORLD_SIZE as torch.distributed.run sets them -> one GPU and one image seed per rank."""
+    lays = [parallel.rank_layout({'WORLD_SIZE': '8', 'RANK': str(r), 'LOCAL_RANK': str(r), 'MASTER_ADDR': '127.0.0.1'}) for r in range(8)]
+    assert [l['device_index'] for l in lays] == list(range(8))                # cuda:LOCAL_RANK, every GPU exactly once
+    assert [l['image_seed'] for l in lays] == [3 + r for r in range(8)]       # different images on every rank
+    assert all(l['use_dist'] and l['world'] == 8 for l in lays)
+    one = parallel.rank_layout({})                                            # plain `python bench.py`
+    assert one == dict(world=1, rank=0, local_rank=0, device_index=0, image_seed=3, use_dist=False)
+    assert parallel.rank_layout({'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})['use_dist']     # --nproc-per-node 1: the gather path
+    with pytest.raises(ValueError):
+        parallel.rank_layout({'WORLD_SIZE': '2', 'RANK': '2', 'LOCAL_RANK': '0'})
+
+
+def _share_worker(rank, world, port, tmpdir, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def make():
+            calls.append(1)
+            g = np.random.RandomState(7)
+            return {'ron_320_vgg/conv1/conv1_1/weights': g.rand(3, 3, 3, 64).astype(np.float32), 'b': g.rand(5).astype(np.float32)}
+
+        arrays, secs, how = parallel.shared_host_arrays(make, 'test', rank, True, directory=tmpdir)
+        ret[rank] = dict(made=len(calls), how=how, sum=float(sum(v.astype(np.float64).sum() for v in arrays.values())),
+                         keys=sorted(arrays), left=sorted(os.listdir(tmpdir)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shared_host_arrays_made_once_per_node(tmp_path):
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_share_worker, args=(world, _free_port(), str(tmp_path), ret), nprocs=world, join=True)
+    assert [ret[r]['made'] for r in range(world)] == [1, 0, 0] and [ret[r]['how'] for r in range(world)] == ['made', 'loaded', 'loaded']
+    assert ret[0]['sum'] == ret[1]['sum'] == ret[2]['sum'] and ret[0]['keys'] == ret[1]['keys'] == ['b', 'ron_320_vgg/conv1/conv1_1/weights']
+    assert os.listdir(str(tmp_path)) == []                                    # the file is gone once everyone has the arrays
 
 
 def test_shard_range_partitions_every_image_once():

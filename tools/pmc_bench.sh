@@ -8,6 +8,8 @@
 # dispatches to the first call's (round 3's f16x3 files summed the bf16 and the f16x3 passes that way).
 set -u
 export TMPDIR=/tmp
+# read by the HIP runtime when it initialises; under rocprofv3 that is before python starts (bench.py's setdefault comes too late there)
+export GPU_MAX_HW_QUEUES=8
 OUT=$1; shift
 mkdir -p $OUT
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_layers.txt

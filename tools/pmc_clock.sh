@@ -3,6 +3,8 @@
 # usage: tools/pmc_clock.sh <outdir> [layer,layer,...]
 set -u
 export TMPDIR=/tmp
+# read by the HIP runtime when it initialises; under rocprofv3 that is before python starts (bench.py's setdefault comes too late there)
+export GPU_MAX_HW_QUEUES=8
 OUT=$1; L=${2:-conv4_2,b4_trio,fc6_full,conv3_2}
 mkdir -p $OUT
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/clk -- python3 tools/sweep_conv.py --only $L --cfgs 0 --iters 6 > $OUT/clk.log 2>&1

@@ -3,6 +3,8 @@
 # usage: tools/pmc_conv.sh <layer-substring> <cfg> <outdir>
 set -u
 export TMPDIR=/tmp
+# read by the HIP runtime when it initialises; under rocprofv3 that is before python starts (bench.py's setdefault comes too late there)
+export GPU_MAX_HW_QUEUES=8
 L=$1; CFG=$2; OUT=$3
 mkdir -p $OUT
 rm -rf $OUT/p[0-9]*          # one call = one set of runs (never add a previous call's dispatches)

@@ -4,6 +4,8 @@
 # usage: tools/pmc_mfma.sh <outdir> [bench.py args...]      -> <outdir>/mfma_busy_<variant>_<dtype>_bs<batch>.json
 set -u
 export TMPDIR=/tmp
+# read by the HIP runtime when it initialises; under rocprofv3 that is before python starts (bench.py's setdefault comes too late there)
+export GPU_MAX_HW_QUEUES=8
 OUT=$1; shift
 mkdir -p $OUT
 rm -rf $OUT/pmc_mfma          # one run per call: never add another call's dispatches (see pmc_bench.sh)

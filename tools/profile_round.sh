@@ -3,6 +3,8 @@
 # usage: RON_COMMIT=<sha> tools/profile_round.sh
 set -u
 export TMPDIR=/tmp
+# read by the HIP runtime when it initialises; under rocprofv3 that is before python starts (bench.py's setdefault comes too late there)
+export GPU_MAX_HW_QUEUES=8
 O=gpurun_out/final
 mkdir -p $O
 python3 bench.py --layers $O/layers_cfg2_inflight2.txt > $O/bench_cfg2_default.json 2> $O/bench_cfg2_default.err
