@@ -39,6 +39,7 @@ extern "C" {
 #define RON_MAX_ANCHORS_PER_CELL 16
 #define RON_MAX_GT 256             /* ground-truth boxes per image ron_bboxes_matching accepts */
 #define RON_MAX_TOPK 512           /* rows a detection list can hold (np_methods top_k = 400) */
+#define RON_MAX_CLASSES 128        /* RONParams.num_classes (background included) the entry points accept: VOC 21, COCO 81 / 91 */
 
 typedef enum {
   RON_OK = 0,

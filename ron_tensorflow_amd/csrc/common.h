@@ -58,6 +58,10 @@ struct PerDeviceOnce {
 // ron_post_np leaves them zero (topk_nms_kernel cleans up after itself) - set by ron_detect for its context-owned workspace only
 constexpr unsigned kPostWsClean = 0x40000000u;
 
+// class ids the post-processing kernels group and encode (a power of two: label masks, anchor * kMaxClasses + label keys)
+constexpr int kMaxClasses = RON_MAX_CLASSES;
+static_assert((kMaxClasses & (kMaxClasses - 1)) == 0, "kMaxClasses must be a power of two");
+
 // Makes `device` current for the lifetime of the guard and restores the caller's device afterwards.
 struct DeviceGuard {
   int prev = -1;

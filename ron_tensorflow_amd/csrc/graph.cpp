@@ -590,7 +590,7 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
   RON_REQUIRE(cfg->dtype >= 0 && cfg->dtype <= RON_DTYPE_F16X3, "unknown dtype %d", cfg->dtype);
   RON_REQUIRE(cfg->img_h > 0 && cfg->img_h % 64 == 0 && cfg->img_w > 0 && cfg->img_w % 64 == 0, "image size must be a multiple of 64");
   if (cfg->variant == RON_VARIANT_SSD512) RON_REQUIRE(cfg->img_h == 512 && cfg->img_w == 512, "SSD-512 runs on 512 x 512 inputs");
-  RON_REQUIRE(cfg->num_classes >= 2 && cfg->num_classes <= 64, "num_classes out of range");
+  RON_REQUIRE(cfg->num_classes >= 2 && cfg->num_classes <= RON_MAX_CLASSES, "num_classes %d out of range [2, %d]", cfg->num_classes, RON_MAX_CLASSES);
   RON_REQUIRE(cfg->max_batch >= 1, "max_batch must be >= 1");
   RON_HIP_CHECK(hipSetDevice(cfg->device));
   std::unique_ptr<ron_ctx> c(new ron_ctx());
@@ -1057,7 +1057,9 @@ static int slot_resources(ron_ctx* c) {
     memset(&hd, 0, sizeof(hd));
     int rc = ron_heads_describe(c, &hd);
     if (rc) return rc;
+    for (int i = 0; i < c->n_feat; ++i) { hd.cls[i] = c->d_head[0][i]; hd.obj[i] = c->d_head[1][i]; hd.loc[i] = c->d_head[2][i]; }
     c->post_ws_bytes = ron_post_np_workspace_bytes(&hd, mb);
+    if (c->post_ws_bytes <= 0) return RON_ERR_INVALID;      // (ron_last_error says why)
     RON_HIP_CHECK(hipMalloc(&c->d_post_ws, (size_t)c->post_ws_bytes));
     RON_HIP_CHECK(hipMemset(c->d_post_ws, 0, (size_t)c->post_ws_bytes));      // once: the kernels keep the counters clean
   }

@@ -11,6 +11,7 @@
 // sorted descending reproduces "score descending, position ascending".
 #include "common.h"
 
+using ron::kMaxClasses;
 namespace {
 
 constexpr int kSelectThreads = 256;
@@ -201,7 +202,7 @@ struct ImageLds {
   int scalars[8];
   int order[kMaxTopK];             // class-grouped position -> sorted row (class-wise NMS)
   int keep[kMaxTopK];              // sorted row -> kept?
-  int cstart[66];                  // first class-grouped position of every class
+  int cstart[kMaxClasses + 2];     // first class-grouped position of every class
   float gbox[kMaxTopK][4];         // boxes in class-grouped order (class-wise NMS: no double indirection in the pair loop)
   int rbeg[kMaxTopK];              // class-grouped position -> first position of its class
   float gvol[kMaxTopK];            // area of gbox[pos], as bboxes_jaccard computes it
@@ -400,7 +401,7 @@ __device__ __forceinline__ bool pair_suppresses(const float* be, float ve, const
 }
 
 // Greedy NMS of the n sorted boxes in lds, any flavour, all rows one segment (the TF variant: one workgroup per class; np_methods
-// with class ids beyond the class-wise scan's 64: mode 0 with the label test).  Same scheme as nms_scan_classwise below: the bit
+// with class ids beyond the class-wise scan's kMaxClasses - not reachable through the entry points: mode 0 with the label test).  Same scheme as nms_scan_classwise below: the bit
 // matrix by COLUMNS (row b: the earlier rows that overlap it), a quarter wave per row, then per 64-row block the fixed point of
 // kept = alive & ((column & kept) == 0) on wave 0.  Stopping after max_keep kept rows = keeping the first max_keep of them.
 // Leaves in lds.hist: [0..15] low / [16..31] high halves of the keep bits per 64-row word, [32..47] exclusive kept counts per
@@ -501,10 +502,10 @@ __device__ void nms_scan_classwise(ImageLds& lds, int n, float nms_thr, int num_
   u64* mask = lds.sort;    // [n][kMaskWords], indexed by class-grouped position
   // class-grouped order, stable inside a class (n <= kMaxTopK <= blockDim: one row per thread).  Rank of a row among the
   // rows of its class = same-class rows in earlier waves + same-class lanes below it in its own wave (ballots).
-  int* wcnt = reinterpret_cast<int*>(lds.sort);      // [kMaskWords waves][64 classes]; the mask is written after this phase
-  for (int i = tid; i < kMaskWords * 64; i += nth) wcnt[i] = 0;
+  int* wcnt = reinterpret_cast<int*>(lds.sort);      // [kMaskWords waves][kMaxClasses]; the mask is written after this phase
+  for (int i = tid; i < kMaskWords * kMaxClasses; i += nth) wcnt[i] = 0;
   __syncthreads();
-  const int c_me = tid < n ? (lds.cls[tid] & 63) : -1;
+  const int c_me = tid < n ? (lds.cls[tid] & (kMaxClasses - 1)) : -1;
   int rank_me = 0;
   if ((wave << 6) < n) {
     u64 todo = __ballot(c_me >= 0);
@@ -513,30 +514,29 @@ __device__ void nms_scan_classwise(ImageLds& lds, int n, float nms_thr, int num_
       const int lc = __shfl(c_me, leader, 64);
       const u64 same = __ballot(c_me == lc);
       if (c_me == lc) rank_me = __popcll(same & ((1ull << lane) - 1ull));
-      if (lane == leader) wcnt[(wave << 6) + lc] = __popcll(same);
+      if (lane == leader) wcnt[wave * kMaxClasses + lc] = __popcll(same);
       todo &= ~same;
     }
   }
   __syncthreads();
-  if (tid < 64) {            // per class: exclusive prefix over the waves, then the exclusive scan of the class totals
+  if (tid < kMaxClasses) {   // per class: exclusive prefix over the waves; the class totals go through lds.rbeg (written for real below)
     int run = 0;
     for (int w = 0; w < words; ++w) {
-      const int t = wcnt[(w << 6) + tid];
-      wcnt[(w << 6) + tid] = run;
+      const int t = wcnt[w * kMaxClasses + tid];
+      wcnt[w * kMaxClasses + tid] = run;
       run += t;
     }
-    int incl = run;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int v = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += v;
-    }
-    lds.cstart[tid] = incl - run;
-    if (tid == 63) lds.cstart[64] = incl;
+    lds.rbeg[tid] = run;
+  }
+  __syncthreads();
+  if (tid <= kMaxClasses) {  // exclusive scan of the class totals (classes >= num_classes are empty)
+    int before = 0;
+    for (int c = 0; c < tid && c < num_classes; ++c) before += lds.rbeg[c];
+    lds.cstart[tid] = before;
   }
   __syncthreads();
   if (tid < n) {
-    const int pos = lds.cstart[c_me] + wcnt[(wave << 6) + c_me] + rank_me;
+    const int pos = lds.cstart[c_me] + wcnt[wave * kMaxClasses + c_me] + rank_me;
     lds.order[pos] = tid;
     lds.rbeg[pos] = lds.cstart[c_me];
     lds.keep[tid] = 0;
@@ -579,7 +579,7 @@ __device__ void nms_scan_classwise(ImageLds& lds, int n, float nms_thr, int num_
     }
   }
   __syncthreads();
-  for (int c = wave; c < 64 && c < num_classes; c += nwaves) {   // one wave per class
+  for (int c = wave; c < kMaxClasses && c < num_classes; c += nwaves) {   // one wave per class
     // (read through readfirstlane: the class bounds are wave-uniform)
     const int s0 = __builtin_amdgcn_readfirstlane(lds.cstart[c]), s1 = __builtin_amdgcn_readfirstlane(lds.cstart[c + 1]);
     if (s0 >= s1) continue;
@@ -643,8 +643,8 @@ __device__ void nms_and_store(ImageLds& lds, int n, float nms_thr, const float* 
                               const DetDev& out, int img, int num_classes) {
   const int tid = threadIdx.x;
   const int nth = blockDim.x;
-  if (num_classes > 0 && num_classes <= 64) nms_scan_classwise(lds, n, nms_thr, num_classes);
-  else nms_scan(lds, n, nms_thr, 0, n);       // class ids outside [0, 64): generic all-pairs form
+  if (num_classes > 0 && num_classes <= kMaxClasses) nms_scan_classwise(lds, n, nms_thr, num_classes);
+  else nms_scan(lds, n, nms_thr, 0, n);       // class ids outside [0, kMaxClasses): generic all-pairs form
   const int total = lds.scalars[4];
   const float sy = ref[2] - ref[0], sx = ref[3] - ref[1];
   for (int i = tid; i < out.capacity; i += nth) {
@@ -848,7 +848,7 @@ __global__ void softmax_last_kernel(const float* x, long long rows, int c, int p
 int build_heads_dev(const ron_heads* h, HeadsDev* d, bool need_anchors) {
   RON_REQUIRE(h != nullptr, "heads is NULL");
   RON_REQUIRE(h->num_layers >= 1 && h->num_layers <= RON_MAX_LAYERS, "num_layers %d out of range", h->num_layers);
-  RON_REQUIRE(h->num_classes >= 2 && h->num_classes <= 64, "num_classes %d out of range", h->num_classes);
+  RON_REQUIRE(h->num_classes >= 2 && h->num_classes <= RON_MAX_CLASSES, "num_classes %d out of range [2, %d]", h->num_classes, RON_MAX_CLASSES);
   d->num_layers = h->num_layers;
   d->num_classes = h->num_classes;
   d->anchor_base[0] = 0;
@@ -939,6 +939,10 @@ extern "C" int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cf
   if (!(cfg->input_flags & ron::kPostWsClean)) RON_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * cnt_bytes, s));
   dim3 grid(hd.block_base[RON_MAX_LAYERS], n);
   const size_t lds = (size_t)kSelectThreads * hd.num_classes * sizeof(float);
+  if (lds > 48 * 1024) {          // beyond ~48 classes the staging tile needs the dynamic-LDS limit raised (128 classes: 128 KB of the CU's 160)
+    static ron::PerDeviceOnce once;
+    RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&select_kernel), (int)lds));
+  }
   hipLaunchKernelGGL(select_kernel, grid, dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
   // only lists that can exceed kPartMin need the partial pass at all (its workgroups return at once for shorter ones)
   if (cap > kPartMin)
@@ -1237,7 +1241,7 @@ __global__ __launch_bounds__(kSelectThreads) void eval_select_kernel(HeadsDev hd
   const float ms = pc.min_size[img];
   if (!(ws > ms && hs > ms && xc > 0.f && yc > 0.f && xc < 1.f && yc < 1.f)) return;
   const int pos = atomicAdd(&counts[img * kCountStride], 1);
-  if (pos < cap) keys[(size_t)img * cap + pos] = make_key(best, (unsigned)(hd.anchor_base[layer] + local) * 64u + (unsigned)label);
+  if (pos < cap) keys[(size_t)img * cap + pos] = make_key(best, (unsigned)(hd.anchor_base[layer] + local) * (unsigned)kMaxClasses + (unsigned)label);
 }
 
 constexpr int kEvalCand = 1024;     // NMS candidates of the ron_eval.py variant per pass: one thread each
@@ -1273,7 +1277,7 @@ __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, Eva
       const u64 k = lds.sort[tid];
       my_score = __uint_as_float((unsigned)(k >> 32));
       my_p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
-      const int anchor = (int)(my_p >> 6);
+      const int anchor = (int)(my_p / (unsigned)kMaxClasses);
       int layer = 0;
 #pragma unroll
       for (int l = 1; l < RON_MAX_LAYERS; ++l)
@@ -1283,7 +1287,7 @@ __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, Eva
     if (n > 0) below = lds.sort[n - 1];                                     // the next pass continues under this key
     __syncthreads();                                                        // every key is read before boxes overwrite the tail
     box[tid * 4 + 0] = my[0]; box[tid * 4 + 1] = my[1]; box[tid * 4 + 2] = my[2]; box[tid * 4 + 3] = my[3];
-    const int my_label = (int)(my_p & 63u);
+    const int my_label = (int)(my_p & (unsigned)(kMaxClasses - 1));
     lab[tid] = my_label;
     bool alive = tid < n;
     for (int j = 0; j < n_kept && alive; ++j)                               // boxes kept by earlier passes come first in score order
@@ -1302,8 +1306,8 @@ __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, Eva
         alive = false;
         lds.box[n_kept][0] = my[0]; lds.box[n_kept][1] = my[1]; lds.box[n_kept][2] = my[2]; lds.box[n_kept][3] = my[3];
         lds.score[n_kept] = my_score;
-        lds.cls[n_kept] = (int)(my_p & 63u);
-        lds.anchor[n_kept] = (int)(my_p >> 6);
+        lds.cls[n_kept] = (int)(my_p & (unsigned)(kMaxClasses - 1));
+        lds.anchor[n_kept] = (int)(my_p / (unsigned)kMaxClasses);
       }
       ++n_kept;
       if (alive && (!by_class || lab[first] == my_label) && tfe_suppresses(&box[first * 4], my, pc.nms_thr, mode)) alive = false;
@@ -1346,7 +1350,7 @@ extern "C" int ron_post_eval(const ron_heads* heads, int n, const float* min_siz
   RON_REQUIRE(cfg != nullptr && n > 0 && out != nullptr && min_sizes != nullptr, "bad argument");
   RON_REQUIRE(cfg->keep_top_k >= 1 && cfg->keep_top_k <= kMaxTopK, "keep_top_k %d not in [1, %d]", cfg->keep_top_k, kMaxTopK);
   RON_REQUIRE(cfg->nms_mode >= 0 && cfg->nms_mode <= 3, "unknown mode to use for nms.");
-  RON_REQUIRE(heads != nullptr && heads->num_classes <= 64, "num_classes must be <= 64");
+  RON_REQUIRE(heads != nullptr && heads->num_classes <= RON_MAX_CLASSES, "num_classes must be <= %d", RON_MAX_CLASSES);
   HeadsDev hd;
   int rc = build_heads_dev(heads, &hd, (cfg->input_flags & RON_IN_LOC_DECODED) == 0);
   if (rc != RON_OK) return rc;
@@ -1366,6 +1370,10 @@ extern "C" int ron_post_eval(const ron_heads* heads, int n, const float* min_siz
   const int cap = hd.anchor_base[RON_MAX_LAYERS];
   RON_HIP_CHECK(hipMemsetAsync(counts, 0, cbytes, s));
   const size_t lds = (size_t)kSelectThreads * hd.num_classes * sizeof(float);
+  if (lds > 48 * 1024) {          // beyond ~48 classes the staging tile needs the dynamic-LDS limit raised (128 classes: 128 KB of the CU's 160)
+    static ron::PerDeviceOnce once;
+    RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&eval_select_kernel), (int)lds));
+  }
   hipLaunchKernelGGL(eval_select_kernel, dim3(hd.block_base[RON_MAX_LAYERS], n), dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
   hipLaunchKernelGGL(eval_nms_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, d_out);
   RON_HIP_CHECK(hipGetLastError());
@@ -1405,6 +1413,10 @@ extern "C" int ron_post_tfe(const ron_heads* heads, int n, const ron_tfe_cfg* cf
   const int cap = hd.anchor_base[RON_MAX_LAYERS];
   RON_HIP_CHECK(hipMemsetAsync(counts, 0, ron::align_up(lists * 4, 256), s));
   const size_t lds = (size_t)kSelectThreads * hd.num_classes * sizeof(float);
+  if (lds > 48 * 1024) {          // beyond ~48 classes the staging tile needs the dynamic-LDS limit raised (128 classes: 128 KB of the CU's 160)
+    static ron::PerDeviceOnce once;
+    RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&tfe_select_kernel), (int)lds));
+  }
   hipLaunchKernelGGL(tfe_select_kernel, dim3(hd.block_base[RON_MAX_LAYERS], n), dim3(kSelectThreads), lds, s, hd, pc, keys,
                      counts, cap);
   hipLaunchKernelGGL(tfe_topk_nms_kernel, dim3(C1, n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, scores, bboxes);

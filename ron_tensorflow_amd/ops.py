@@ -127,7 +127,7 @@ def _workspace(device, nbytes):
     return ent[0]
 
 
-def post_np(cls, obj, loc, anchors_dev, num_classes=21, objectness_thres=0.03, select_threshold=0.01,
+def post_np(cls, obj, loc, anchors_dev, num_classes=None, objectness_thres=0.03, select_threshold=0.01,
             nms_threshold=0.45, top_k=400, bbox_img=(0., 0., 1., 1.), prior_scaling=(0.1, 0.1, 0.2, 0.2),
             cls_is_prob=False, obj_is_prob=False, loc_decoded=False, want_sorted=False):
     """np_methods pipeline on the GPU (ron_post_np): per-layer lists of GPU tensors in, DetectionBuffers out.
@@ -138,6 +138,8 @@ def post_np(cls, obj, loc, anchors_dev, num_classes=21, objectness_thres=0.03, s
     """
     n = cls[0].shape[0]
     dev = cls[0].device
+    if num_classes is None:
+        num_classes = int(cls[0].shape[-1])          # RONParams.num_classes = the class tensors' last axis
     heads, keep = _fill_heads(cls, obj, loc, None if loc_decoded else anchors_dev, num_classes)
     cfg = PostCfg()
     # select_threshold None / 0: the arg-max branch of ssd_bboxes_select_layer (np_methods.py:82-89)
