@@ -19,7 +19,9 @@ from ron_tensorflow_amd.preprocessing import ssd_vgg_preprocessing
 from ron_tensorflow_amd.nets import nets_factory
 
 
-def main():
+def main(argv=None):
+    """Runs the evaluation; `argv` None = the command line.  Returns what it printed as data: {'AP_VOC07/mAP', 'AP_VOC12/mAP',
+    'seconds_per_batch', 'detections': per batch {class: (scores, bboxes) as numpy}} (tests/test_gpu_eval.py runs it in-process)."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--select_threshold', type=float, default=0.01)      # eval_ron_network.py:64-65
     ap.add_argument('--objectness_thres', type=float, default=0.03)      # :66-67
@@ -40,7 +42,7 @@ def main():
     ap.add_argument('--images', default='', help='.npy [N,320,320,3] pre-whitened float32; synthetic if empty')
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--variant', default='reducedfc', help="what RONNet.net builds in the reference (nets/ron_vgg_320.py:144)")
-    FLAGS = ap.parse_args()
+    FLAGS = ap.parse_args(argv)
 
     # Get the RON network and its anchors.                                eval_ron_network.py:147-152
     ron_class = nets_factory.get_network(FLAGS.model_name)
@@ -72,7 +74,7 @@ def main():
     labels = list(range(1, FLAGS.num_classes))
     tp_fp_metric = tfe_metrics.StreamingTpFp(labels)
 
-    times = []
+    times, detections = [], []
     for i in range(0, min(len(data), n_total), FLAGS.batch_size):
         torch.cuda.synchronize()
         start = time.time()
@@ -101,11 +103,16 @@ def main():
         torch.cuda.synchronize()
         times.append(time.time() - start)
         kept = sum(int((v > 0).sum().item()) for v in rscores.values())
+        detections.append({c: (rscores[c].cpu().numpy(), rbboxes[c].cpu().numpy()) for c in labels})
         print('batch %d: %d detections over %d classes' % (i // FLAGS.batch_size, kept, len(rscores)))
     res = tfe_metrics.evaluate(tp_fp_metric)                                                                  # :289-335
     print('AP_VOC07/mAP %.6f  AP_VOC12/mAP %.6f  (synthetic weights and ground truth: plumbing check, not accuracy)'
           % (res['AP_VOC07/mAP'], res['AP_VOC12/mAP']))
-    print('Time spent per BATCH: %.3f seconds.' % (sum(times[1:]) / max(len(times) - 1, 1)))
+    per_batch = sum(times[1:]) / max(len(times) - 1, 1)
+    print('Time spent per BATCH: %.3f seconds.' % per_batch)
+    ron_net.close()
+    return {'AP_VOC07/mAP': res['AP_VOC07/mAP'], 'AP_VOC12/mAP': res['AP_VOC12/mAP'], 'seconds_per_batch': per_batch,
+            'detections': detections}
 
 
 if __name__ == '__main__':

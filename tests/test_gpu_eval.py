@@ -85,3 +85,32 @@ def test_matching_rejects_too_many_gt():
     with pytest.raises(RuntimeError):
         metrics.bboxes_matching(torch.zeros((1, 1, 4), device=dev), torch.zeros((1, 1, 4, 4), device=dev),
                                 np.zeros((1, 300), np.int64), np.zeros((1, 300, 4), np.float32), np.zeros((1, 300), np.int64))
+
+
+def test_eval_driver_main(tmp_path, capsys):
+    """The drop-in caller itself (ron_tensorflow_amd/eval_ron_network.py::main, the call sequence of the reference's
+    eval_ron_network.py:137-366), in-process: once on synthetic weights, once restoring the same weights from a TF V2 checkpoint
+    bundle written by checkpoint.write_checkpoint.  Both print the reference's summary lines and give identical detections."""
+    import re
+    from ron_tensorflow_amd import checkpoint, eval_ron_network
+    from ron_tensorflow_amd import weights as W
+    common = ['--batch_size', '1', '--max_num_batches', '3', '--dtype', 'fp32']
+    first = eval_ron_network.main(common)
+    out1 = capsys.readouterr().out
+    prefix = str(tmp_path / 'model.ckpt-120000')
+    checkpoint.write_checkpoint(prefix, W.synthetic_weights('reducedfc', 21))
+    second = eval_ron_network.main(common + ['--checkpoint_path', str(tmp_path)])      # a directory: latest_checkpoint, like tf_utils.py
+    out2 = capsys.readouterr().out
+    for out in (out1, out2):
+        assert re.search(r'AP_VOC07/mAP \d\.\d{6}  AP_VOC12/mAP \d\.\d{6}', out), out
+        assert re.search(r'Time spent per BATCH: \d+\.\d{3} seconds\.', out), out
+        assert len(re.findall(r'^batch \d+: \d+ detections over 20 classes$', out, re.M)) == 3
+    assert first['AP_VOC07/mAP'] == second['AP_VOC07/mAP'] and first['AP_VOC12/mAP'] == second['AP_VOC12/mAP']
+    assert len(first['detections']) == len(second['detections']) == 3
+    kept = 0
+    for a, b in zip(first['detections'], second['detections']):
+        assert sorted(a) == sorted(b) == list(range(1, 21))
+        for c in a:
+            assert np.array_equal(a[c][0], b[c][0]) and np.array_equal(a[c][1], b[c][1]), c
+            kept += int((a[c][0] > 0).sum())
+    assert kept > 0
