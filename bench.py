@@ -171,6 +171,29 @@ def load_traffic(args):
     return t.get('hbm_bytes_per_conv_launch'), src
 
 
+def load_mfma_busy(args):
+    """Matrix-pipe occupancy of this command by counter (tools/pmc_mfma.sh -> profiles/<round>/mfma_busy_*.json: SQ_VALU_MFMA_BUSY_CYCLES
+    over elapsed cycles, the clock the dispatches ran at, and busy x clock / 2.4 GHz = fraction of the nominal matrix peak).  Like
+    `traffic`: a committed measurement of an earlier run of the same command, returned with its provenance, or (None, None)."""
+    import glob
+    key = '%s_%s_bs%d' % (args.variant, args.dtype, args.batch)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'mfma_busy_%s.json' % key)) +
+                   glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'final_mfma_busy_%s.json' % key)),
+                   key=lambda f: (os.path.basename(os.path.dirname(f)), os.path.basename(f)))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    w = t.get('whole_run', {})
+    val = {'whole_run': w.get('mfma_busy_fraction'), 'clock_ghz': w.get('clock_ghz'),
+           'busy_x_clock_over_nominal': w.get('mfma_busy_x_clock_over_nominal'),
+           'per_kernel': {k: v.get('mfma_busy_fraction') for k, v in t.get('per_kernel', {}).items() if 'conv' in k or 'stem' in k}}
+    src = {'file': os.path.relpath(files[-1], ROOT), 'commit': t.get('commit'), 'command': t.get('command'),
+           'note': 'committed rocprofv3 --pmc measurement of an earlier run of this command, one batch in flight (SQ_VALU_MFMA_BUSY_CYCLES '
+                   '/ (1024 SIMDs x GRBM_GUI_ACTIVE / 8)); not collected in this run'}
+    return val, src
+
+
 def parity_mode_leg(args, ron_class, ron_params, weights, images, dev, detect_args, top_k, ref_dets):
     """The same workload in the arithmetic that meets north_star's float tolerance (split precision, dtype f16x3: detections
     within 1e-4 of the fp32 CPU reference), AFTER the headline's timed region and outside its clock: a second context over the
@@ -351,6 +374,7 @@ def main():
                  'the conv kernel too); per-launch durations overlap, see concurrency' % in_flight)
     algo_bytes = sum(r['bytes_per_launch'] * r['launches'] for r in conv) / max(conv_launches, 1)
     traffic, traffic_source = load_traffic(args)
+    mfma_busy, mfma_busy_source = load_mfma_busy(args)
     peak = {'bf16': PEAK_BF16_TFLOPS, 'fp16': PEAK_F16_TFLOPS, 'fp32': PEAK_F32_TFLOPS, 'f16x3': PEAK_F16X3_TFLOPS}[args.dtype]
 
     if rank == 0:
@@ -380,6 +404,7 @@ def main():
                        'mean_detections_per_image': float(det.count.float().mean().item())},
             'roofline': {'bound': 'mfma', 'kernel': 'conv kernels: conv_igemm_kernel (+ its grouped form conv_igemm_group_kernel), conv3x3_patch_kernel and conv3x3_c64_kernel', 'achieved': achieved, 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_source,
+                         'mfma_busy': mfma_busy, 'mfma_busy_source': mfma_busy_source,
                          'basis': basis,
                          # the per-kernel definition: conv FLOPs per launch / that launch's own duration, one launch at a
                          # time (3 steps after the timed region when several batches were in flight during it)
