@@ -1,3 +1,4 @@
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 
@@ -10,6 +11,26 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 const char* get_error() { return g_err; }
+
+bool plan_only() {
+  static const bool on = getenv("RON_PLAN_ONLY") != nullptr;
+  return on;
+}
+// dry run: addresses from a counter (4 KB apart at least, never handed to HIP, never dereferenced on the host)
+static std::atomic<uint64_t> g_fake_next{0x100000000ull};
+hipError_t dev_malloc(void** p, size_t bytes) {
+  if (!plan_only()) return hipMalloc(p, bytes);
+  *p = reinterpret_cast<void*>(g_fake_next.fetch_add((uint64_t)align_up((int64_t)bytes + 1, 4096)));
+  return hipSuccess;
+}
+hipError_t dev_free(void* p) { return plan_only() ? hipSuccess : hipFree(p); }
+hipError_t dev_memset(void* p, int v, size_t bytes) { return plan_only() ? hipSuccess : hipMemset(p, v, bytes); }
+hipError_t dev_memset_async(void* p, int v, size_t bytes, hipStream_t s) { return plan_only() ? hipSuccess : hipMemsetAsync(p, v, bytes, s); }
+hipError_t dev_memcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  return plan_only() ? hipSuccess : hipMemcpy(dst, src, bytes, kind);
+}
+hipError_t dev_set_device(int device) { return plan_only() ? hipSuccess : hipSetDevice(device); }
+hipError_t launch_error() { return plan_only() ? hipSuccess : hipGetLastError(); }
 }  // namespace ron
 
 extern "C" const char* ron_last_error(void) { return ron::get_error(); }

@@ -35,6 +35,24 @@ void set_error(const char* fmt, ...);
 
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// Dry run (RON_PLAN_ONLY=1 in the environment, read once): every host-side decision of the library is made - launch plans, tile
+// choices, split-K factors, kernel arguments, workspace sizes - but no HIP call: device "allocations" are distinct fake addresses
+// nobody dereferences, copies, events and kernel launches are skipped.  What `make asan` (csrc/Makefile) runs the host planners
+// under AddressSanitizer / UBSan with, on a machine without a GPU (tools/plan_sweep.cpp, tests/test_asan_plan_sweep.py).
+bool plan_only();
+hipError_t dev_malloc(void** p, size_t bytes);
+hipError_t dev_free(void* p);
+hipError_t dev_memset(void* p, int v, size_t bytes);
+hipError_t dev_memset_async(void* p, int v, size_t bytes, hipStream_t s);
+hipError_t dev_memcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+hipError_t dev_set_device(int device);
+hipError_t launch_error();                     // hipGetLastError(), hipSuccess in a dry run
+template <class T> hipError_t dev_malloc(T** p, size_t bytes) { return dev_malloc(reinterpret_cast<void**>(p), bytes); }
+#define RON_LAUNCH(...)                                          \
+  do {                                                           \
+    if (!ron::plan_only()) hipLaunchKernelGGL(__VA_ARGS__);      \
+  } while (0)
+
 // hipFuncSetAttribute applies to the current device only: one of these per kernel instantiation remembers on which
 // devices (id < 64) the dynamic-LDS limit has been raised.  Safe from several host threads: nobody returns before the
 // attribute is set on his device.
@@ -42,6 +60,7 @@ struct PerDeviceOnce {
   std::atomic<uint64_t> done{0};
   std::mutex mu;
   hipError_t max_dynamic_lds(const void* kernel, int bytes) {
+    if (plan_only()) return hipSuccess;
     int dev = 0;
     const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev <= 63;     // unknown device: just set it again
     const uint64_t bit = known ? 1ull << dev : 0;
@@ -68,6 +87,7 @@ struct DeviceGuard {
   bool switched = false;
   hipError_t err = hipSuccess;
   explicit DeviceGuard(int device) {
+    if (plan_only()) return;
     err = hipGetDevice(&prev);
     if (err == hipSuccess && prev != device) { err = hipSetDevice(device); switched = err == hipSuccess; }
   }

@@ -216,8 +216,8 @@ template <class Tr>
 int launch_c64_16_t(const C64Args& a, hipStream_t s) {
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_c64_kernel16<Tr>), kC6Lds));
-  hipLaunchKernelGGL((conv3x3_c64_kernel16<Tr>), dim3(a.n_slots * a.halves), dim3(512), kC6Lds, s, a);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_LAUNCH((conv3x3_c64_kernel16<Tr>), dim3(a.n_slots * a.halves), dim3(512), kC6Lds, s, a);
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 

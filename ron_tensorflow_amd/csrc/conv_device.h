@@ -431,10 +431,11 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
             if (ooff < 0) continue;
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
-              if (j >= n_valid) break;
-              float x = fmaf(w[u][j], p.oscale, bias_v[j]);
-              if (p.relu) x = fmaxf(x, 0.f);
-              Tr::store(p.out2, ooff + n_store + j, x);
+              if (j < n_valid) {                 // (no run-time `break` in a loop that is to be unrolled: hipcc then refuses)
+                float x = fmaf(w[u][j], p.oscale, bias_v[j]);
+                if (p.relu) x = fmaxf(x, 0.f);
+                Tr::store(p.out2, ooff + n_store + j, x);
+              }
             }
           }
         }
@@ -442,11 +443,12 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
         if (ooff < 0) continue;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-          if (j >= n_valid) break;
-          const float mx = fmaxf(fmaxf(w[0][j], w[1][j]), fmaxf(w[2][j], w[3][j]));
-          float x = fmaf(mx, p.oscale, bias_v[j]);
-          if (p.relu) x = fmaxf(x, 0.f);
-          Tr::store(p.out, ooff + n_store + j, x);
+          if (j < n_valid) {
+            const float mx = fmaxf(fmaxf(w[0][j], w[1][j]), fmaxf(w[2][j], w[3][j]));
+            float x = fmaf(mx, p.oscale, bias_v[j]);
+            if (p.relu) x = fmaxf(x, 0.f);
+            Tr::store(p.out, ooff + n_store + j, x);
+          }
         }
       }
     }
@@ -463,12 +465,13 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
       const int o = ooff + tap_off + n_store;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        if (j >= n_valid) break;
-        float x = fmaf(v[j], p.oscale, bias_v[j]);
-        if (p.relu) x = fmaxf(x, 0.f);
-        if (p.res != nullptr) x = fmaxf(x + Tr::load(p.res, o + j), 0.f);
-        if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = x;
-        else Tr::store(p.out, o + j, x);
+        if (j < n_valid) {
+          float x = fmaf(v[j], p.oscale, bias_v[j]);
+          if (p.relu) x = fmaxf(x, 0.f);
+          if (p.res != nullptr) x = fmaxf(x + Tr::load(p.res, o + j), 0.f);
+          if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = x;
+          else Tr::store(p.out, o + j, x);
+        }
       }
     }
   }

@@ -45,9 +45,10 @@ __device__ __forceinline__ void pin_ksteps() {
       if (((q2 + 1) * ps) / MM > (q2 * ps) / MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     if constexpr (s < KS - 1 && RD > MM) __builtin_amdgcn_sched_group_barrier(0x100, RD - MM, 0);
+    if constexpr (ps > MM) {                 // more pieces than MFMA gaps in this k-step (never with the shipped tiles): the rest in a row
 #pragma unroll
-    for (int x = 0; x < 16; ++x)
-      if (x < ps - MM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      for (int x = 0; x < ps - MM; ++x) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
     pin_ksteps<Tr, MR, NR, KS, LPT, SPREAD, s + 1>();
   }
 }
@@ -636,8 +637,8 @@ int launch_t(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, AsmLoop<Tr>::value && BM == 256 && WM == 2);
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), (int)lds));
-  hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_LAUNCH((conv_igemm_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(a.tiles_total * a.splitk), dim3(WM * WN * 64), lds, s, a);
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -669,8 +670,8 @@ template <class Tr>
 int launch_finalize(const ConvArgs& a, hipStream_t s) {
   const long long total = (long long)a.M * (a.Npad / 4);
   const int grid = (int)std::min<long long>((total + 255) / 256, 2048);
-  hipLaunchKernelGGL(splitk_finalize_kernel<Tr>, dim3(grid), dim3(256), 0, s, a);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_LAUNCH(splitk_finalize_kernel<Tr>, dim3(grid), dim3(256), 0, s, a);
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -864,7 +865,7 @@ int launch_group_finalize(const ConvGroupArgs& g, hipStream_t s) {
   for (int k = 0; k < g.n; ++k)
     if (g.op[k].splitk > 1) most = std::max(most, (long long)g.op[k].M * (g.op[k].Npad / 4));
   const int grid = (int)std::min<long long>((most + 255) / 256, 512);
-  hipLaunchKernelGGL(splitk_finalize_group_kernel<Tr>, dim3(grid, g.n), dim3(256), 0, s, g);
+  RON_LAUNCH(splitk_finalize_group_kernel<Tr>, dim3(grid, g.n), dim3(256), 0, s, g);
   return RON_OK;
 }
 
@@ -873,9 +874,9 @@ int launch_group_t(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
   const size_t lds = (size_t)igemm_lds_bytes(BM, BN, S, AsmLoop<Tr>::value && BM == 256 && WM == 2);
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), (int)lds));
-  hipLaunchKernelGGL((conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(g.first[g.ne]), dim3(WM * WN * 64), lds, s, g);
+  RON_LAUNCH((conv_igemm_group_kernel<Tr, BM, BN, WM, WN, S, SPREAD>), dim3(g.first[g.ne]), dim3(WM * WN * 64), lds, s, g);
   if (any_split) launch_group_finalize<Tr>(g, s);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -884,9 +885,9 @@ int launch_group_mixed(const ConvGroupArgs& g, bool any_split, hipStream_t s) {
   const size_t lds = (size_t)igemm_lds_bytes(128, 128, 2);
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_group_mixed_kernel<Tr>), (int)lds));
-  hipLaunchKernelGGL((conv_igemm_group_mixed_kernel<Tr>), dim3(g.first[g.ne]), dim3(256), lds, s, g);
+  RON_LAUNCH((conv_igemm_group_mixed_kernel<Tr>), dim3(g.first[g.ne]), dim3(256), lds, s, g);
   if (any_split) launch_group_finalize<Tr>(g, s);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 

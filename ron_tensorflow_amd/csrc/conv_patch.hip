@@ -425,8 +425,8 @@ int launch_patch_pair_t(const PatchArgs& a, const ConvArgs& second, int first, i
   const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * TPS * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_patch_pair_kernel<Tr, BN, WN, SB, TPS>), (int)lds));
-  hipLaunchKernelGGL((conv3x3_patch_pair_kernel<Tr, BN, WN, SB, TPS>), dim3(grid), dim3(512), lds, s, a, second, first);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_LAUNCH((conv3x3_patch_pair_kernel<Tr, BN, WN, SB, TPS>), dim3(grid), dim3(512), lds, s, a, second, first);
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -435,8 +435,8 @@ int launch_patch_t(const PatchArgs& a, int grid, hipStream_t s) {
   const size_t lds = 2 * (size_t)kPatchRows * kRowBytes + SB * TPS * (size_t)BN * kRowBytes + 2 * 256 * sizeof(int) + 1024;
   static PerDeviceOnce once;
   RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<Tr, BN, WN, SB, TPS>), (int)lds));
-  hipLaunchKernelGGL((conv3x3_patch_kernel<Tr, BN, WN, SB, TPS>), dim3(grid), dim3(512), lds, s, a);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_LAUNCH((conv3x3_patch_kernel<Tr, BN, WN, SB, TPS>), dim3(grid), dim3(512), lds, s, a);
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 

@@ -269,10 +269,10 @@ int vec_elems(int dtype) { return dtype == RON_DTYPE_F16X3 ? 8 : 16 / (int)dtype
 // launches KERNEL<T> for the element type of `dtype`
 #define RON_DISPATCH_DTYPE(dtype, KERNEL, grid, stream, ...)                                                               \
   do {                                                                                                                     \
-    if ((dtype) == RON_DTYPE_BF16) hipLaunchKernelGGL(KERNEL<__hip_bfloat16>, dim3(grid), dim3(256), 0, stream, __VA_ARGS__); \
-    else if ((dtype) == RON_DTYPE_F16) hipLaunchKernelGGL(KERNEL<_Float16>, dim3(grid), dim3(256), 0, stream, __VA_ARGS__);  \
-    else if ((dtype) == RON_DTYPE_F16X3) hipLaunchKernelGGL(KERNEL<SplitF16>, dim3(grid), dim3(256), 0, stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL(KERNEL<float>, dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                                  \
+    if ((dtype) == RON_DTYPE_BF16) RON_LAUNCH(KERNEL<__hip_bfloat16>, dim3(grid), dim3(256), 0, stream, __VA_ARGS__); \
+    else if ((dtype) == RON_DTYPE_F16) RON_LAUNCH(KERNEL<_Float16>, dim3(grid), dim3(256), 0, stream, __VA_ARGS__);  \
+    else if ((dtype) == RON_DTYPE_F16X3) RON_LAUNCH(KERNEL<SplitF16>, dim3(grid), dim3(256), 0, stream, __VA_ARGS__); \
+    else RON_LAUNCH(KERNEL<float>, dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                                  \
   } while (0)
 
 }  // namespace
@@ -281,7 +281,7 @@ int launch_im2col_c3(const float* x, int n, int h, int w, int dtype, void* out, 
   const long long total = (long long)n * h * w * (kchunk / vec_elems(dtype));
   const int g = grid_for(total);
   RON_DISPATCH_DTYPE(dtype, im2col_c3_kernel, g, s, x, n, h, w, kchunk, out);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -293,7 +293,7 @@ int launch_maxpool2x2(const TensorView& in, const TensorView& out, int dtype, hi
   const long long total = (long long)out.N * out.H * out.W * (out.C / V);
   const int g = grid_for(total);
   RON_DISPATCH_DTYPE(dtype, maxpool2x2_kernel, g, s, to_dev(in), to_dev(out));
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -303,7 +303,7 @@ int launch_maxpool3x3s1(const TensorView& in, const TensorView& out, int dtype, 
   RON_REQUIRE(out.C % V == 0 && in.cstride % V == 0 && out.cstride % V == 0, "maxpool3x3: channels must be a multiple of %d", V);
   const int g = grid_for((long long)out.N * out.H * out.W * (out.C / V));
   RON_DISPATCH_DTYPE(dtype, maxpool3x3s1_kernel, g, s, to_dev(in), to_dev(out));
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -313,7 +313,7 @@ int launch_l2norm(const TensorView& in, const TensorView& out, const float* d_ga
   const long long waves = (long long)in.N * in.H * in.W;
   const int g = (int)std::min<long long>((waves + 3) / 4, 256 * 8);
   RON_DISPATCH_DTYPE(dtype, l2norm_kernel, g, s, to_dev(in), to_dev(out), d_gamma);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -328,7 +328,7 @@ int launch_pack_input(const float* x, const TensorView& out, int dtype, hipStrea
   if (rc) return rc;
   const int g = grid_for((long long)out.N * out.H * out.W * out.C);
   RON_DISPATCH_DTYPE(dtype, pack_kernel, g, s, x, to_dev(out));
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -337,7 +337,7 @@ int launch_fill_random(const TensorView& out, int dtype, unsigned seed, hipStrea
   if (rc) return rc;
   const int g = grid_for((long long)out.N * out.H * out.W * out.C);
   RON_DISPATCH_DTYPE(dtype, fill_random_kernel, g, s, to_dev(out), seed);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -346,7 +346,7 @@ int launch_unpack(const TensorView& in, int dtype, int in_is_f32, float* y, hipS
   if (rc) return rc;
   const int g = grid_for((long long)in.N * in.H * in.W * in.C);
   RON_DISPATCH_DTYPE(in_is_f32 ? RON_DTYPE_F32 : dtype, unpack_kernel, g, s, to_dev(in), y);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 

@@ -106,8 +106,8 @@ extern "C" int ron_bboxes_matching(const float* scores, const float* bboxes, int
   RON_REQUIRE(n_gbboxes != nullptr && tp != nullptr && fp != nullptr, "bad argument");
   RON_REQUIRE(n > 0 && num_lists > 0 && k > 0, "bad argument");
   RON_REQUIRE(g >= 1 && g <= RON_MAX_GT, "ground-truth boxes per image %d not in [1, %d]", g, RON_MAX_GT);
-  hipLaunchKernelGGL(ron::bboxes_matching_kernel, dim3(num_lists, n), dim3(64), 0, (hipStream_t)stream, scores, bboxes, k,
+  RON_LAUNCH(ron::bboxes_matching_kernel, dim3(num_lists, n), dim3(64), 0, (hipStream_t)stream, scores, bboxes, k,
                      glabels, gbboxes, gdifficults, g, matching_threshold, n_gbboxes, tp, fp);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }

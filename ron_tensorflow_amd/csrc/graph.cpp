@@ -270,15 +270,15 @@ int upload(ron_ctx* c, const Rows& r, int cout) {
   std::vector<uint8_t> bytes = pack_conv_weights(r.w, r.npad, c->cfg.dtype, &p.oscale);
   p.w_bytes = (int64_t)bytes.size();
   p.Npad = r.npad; p.Cout = cout;
-  RON_HIP_CHECK(hipMalloc(&p.d_w, bytes.size()));
-  RON_HIP_CHECK(hipMemcpy(p.d_w, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+  RON_HIP_CHECK(ron::dev_malloc(&p.d_w, bytes.size()));
+  RON_HIP_CHECK(ron::dev_memcpy(p.d_w, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
   if (dtype_is_half(c->cfg.dtype) && r.kh == 3 && r.kw == 3 && r.cin == 64 && r.npad == cout && cout % 64 == 0) {
     const std::vector<uint8_t> img = pack_conv_c64_weights(r.w, r.npad, c->cfg.dtype);
-    RON_HIP_CHECK(hipMalloc(&p.d_w_c64, img.size()));
-    RON_HIP_CHECK(hipMemcpy(p.d_w_c64, img.data(), img.size(), hipMemcpyHostToDevice));
+    RON_HIP_CHECK(ron::dev_malloc(&p.d_w_c64, img.size()));
+    RON_HIP_CHECK(ron::dev_memcpy(p.d_w_c64, img.data(), img.size(), hipMemcpyHostToDevice));
   }
-  RON_HIP_CHECK(hipMalloc((void**)&p.d_bias, r.b.size() * sizeof(float)));
-  RON_HIP_CHECK(hipMemcpy(p.d_bias, r.b.data(), r.b.size() * sizeof(float), hipMemcpyHostToDevice));
+  RON_HIP_CHECK(ron::dev_malloc((void**)&p.d_bias, r.b.size() * sizeof(float)));
+  RON_HIP_CHECK(ron::dev_memcpy(p.d_bias, r.b.data(), r.b.size() * sizeof(float), hipMemcpyHostToDevice));
   c->packed.push_back(p);
   return (int)c->packed.size() - 1;
 }
@@ -438,8 +438,8 @@ int make_anchors_ssd(ron_ctx* c) {
     if (rc) return rc;
     const std::vector<float>* src[4] = {&y, &x, &hh, &ww};
     for (int k = 0; k < 4; ++k) {
-      RON_HIP_CHECK(hipMalloc((void**)&c->d_anchor[i][k], src[k]->size() * sizeof(float)));
-      RON_HIP_CHECK(hipMemcpy(c->d_anchor[i][k], src[k]->data(), src[k]->size() * sizeof(float), hipMemcpyHostToDevice));
+      RON_HIP_CHECK(ron::dev_malloc((void**)&c->d_anchor[i][k], src[k]->size() * sizeof(float)));
+      RON_HIP_CHECK(ron::dev_memcpy(c->d_anchor[i][k], src[k]->data(), src[k]->size() * sizeof(float), hipMemcpyHostToDevice));
     }
   }
   return RON_OK;
@@ -592,7 +592,7 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
   if (cfg->variant == RON_VARIANT_SSD512) RON_REQUIRE(cfg->img_h == 512 && cfg->img_w == 512, "SSD-512 runs on 512 x 512 inputs");
   RON_REQUIRE(cfg->num_classes >= 2 && cfg->num_classes <= RON_MAX_CLASSES, "num_classes %d out of range [2, %d]", cfg->num_classes, RON_MAX_CLASSES);
   RON_REQUIRE(cfg->max_batch >= 1, "max_batch must be >= 1");
-  RON_HIP_CHECK(hipSetDevice(cfg->device));
+  RON_HIP_CHECK(ron::dev_set_device(cfg->device));
   std::unique_ptr<ron_ctx> c(new ron_ctx());
   c->cfg = *cfg;
   c->c6 = cfg->variant == RON_VARIANT_FULL ? 4096 : 1024;
@@ -640,11 +640,11 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
     if (t.bytes >= ((int64_t)1 << 32)) {
       ron::set_error("tensor %s needs %lld bytes for max_batch %d: above the 4 GiB buffer-addressing limit; lower max_batch",
                      t.name.c_str(), (long long)t.bytes, cfg->max_batch);
-      for (auto& u : c->tensors) if (u.d) (void)hipFree(u.d);
+      for (auto& u : c->tensors) if (u.d) (void)ron::dev_free(u.d);
       return RON_ERR_INVALID;
     }
-    RON_HIP_CHECK(hipMalloc(&t.d, (size_t)t.bytes));
-    RON_HIP_CHECK(hipMemset(t.d, 0, (size_t)t.bytes));     // halos stay zero forever: kernels write interiors only
+    RON_HIP_CHECK(ron::dev_malloc(&t.d, (size_t)t.bytes));
+    RON_HIP_CHECK(ron::dev_memset(t.d, 0, (size_t)t.bytes));     // halos stay zero forever: kernels write interiors only
   }
   // ---- anchors (RONNet.default_params, nets/ron_vgg_320.py:97-124) ----
   if (c->is_ssd()) {
@@ -663,8 +663,8 @@ extern "C" int ron_create(ron_ctx** out, const ron_config* cfg) {
     if (rc) return rc;
     const std::vector<float>* src[4] = {&y, &x, &hh, &ww};
     for (int k = 0; k < 4; ++k) {
-      RON_HIP_CHECK(hipMalloc((void**)&c->d_anchor[i][k], src[k]->size() * sizeof(float)));
-      RON_HIP_CHECK(hipMemcpy(c->d_anchor[i][k], src[k]->data(), src[k]->size() * sizeof(float), hipMemcpyHostToDevice));
+      RON_HIP_CHECK(ron::dev_malloc((void**)&c->d_anchor[i][k], src[k]->size() * sizeof(float)));
+      RON_HIP_CHECK(ron::dev_memcpy(c->d_anchor[i][k], src[k]->data(), src[k]->size() * sizeof(float), hipMemcpyHostToDevice));
     }
   }
   *out = c.release();
@@ -680,25 +680,25 @@ extern "C" int ron_destroy(ron_ctx* c) {
     c->packed.clear();
     c->d_l2_gamma = nullptr; c->d_stem_w = nullptr; c->d_stem_b = nullptr; c->d_stem2_w = nullptr; c->d_stem2_b = nullptr; c->d_stem2_w1 = nullptr;
   }
-  for (auto& t : c->tensors) if (t.d) (void)hipFree(t.d);
-  for (auto& p : c->packed) { if (p.d_w) (void)hipFree(p.d_w); if (p.d_w_c64) (void)hipFree(p.d_w_c64); if (p.d_bias) (void)hipFree(p.d_bias); }
-  for (int i = 0; i < RON_MAX_LAYERS; ++i) for (int k = 0; k < 4; ++k) if (c->d_anchor[i][k]) (void)hipFree(c->d_anchor[i][k]);
-  for (int k = 0; k < 3; ++k) for (int i = 0; i < RON_MAX_LAYERS; ++i) if (c->d_head[k][i]) (void)hipFree(c->d_head[k][i]);
-  if (c->d_l2_gamma) (void)hipFree(c->d_l2_gamma);
+  for (auto& t : c->tensors) if (t.d) (void)ron::dev_free(t.d);
+  for (auto& p : c->packed) { if (p.d_w) (void)ron::dev_free(p.d_w); if (p.d_w_c64) (void)ron::dev_free(p.d_w_c64); if (p.d_bias) (void)ron::dev_free(p.d_bias); }
+  for (int i = 0; i < RON_MAX_LAYERS; ++i) for (int k = 0; k < 4; ++k) if (c->d_anchor[i][k]) (void)ron::dev_free(c->d_anchor[i][k]);
+  for (int k = 0; k < 3; ++k) for (int i = 0; i < RON_MAX_LAYERS; ++i) if (c->d_head[k][i]) (void)ron::dev_free(c->d_head[k][i]);
+  if (c->d_l2_gamma) (void)ron::dev_free(c->d_l2_gamma);
   for (auto& call : c->pending) for (hipEvent_t e : call) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-  if (c->d_post_ws) (void)hipFree(c->d_post_ws);
+  if (c->d_post_ws) (void)ron::dev_free(c->d_post_ws);
   for (int l = 0; l < 4; ++l) {
-    if (c->d_splitk[l]) (void)hipFree(c->d_splitk[l]);
+    if (c->d_splitk[l]) (void)ron::dev_free(c->d_splitk[l]);
     if (c->side[l]) (void)hipStreamDestroy(c->side[l]);
     if (c->lane_ready[l]) (void)hipEventDestroy(c->lane_ready[l]);
     if (c->lane_done[l]) (void)hipEventDestroy(c->lane_done[l]);
   }
-  if (c->d_stem_w) (void)hipFree(c->d_stem_w);
-  if (c->d_stem_b) (void)hipFree(c->d_stem_b);
-  if (c->d_stem2_w) (void)hipFree(c->d_stem2_w);
-  if (c->d_stem2_b) (void)hipFree(c->d_stem2_b);
-  if (c->d_stem2_w1) (void)hipFree(c->d_stem2_w1);
+  if (c->d_stem_w) (void)ron::dev_free(c->d_stem_w);
+  if (c->d_stem_b) (void)ron::dev_free(c->d_stem_b);
+  if (c->d_stem2_w) (void)ron::dev_free(c->d_stem2_w);
+  if (c->d_stem2_b) (void)ron::dev_free(c->d_stem2_b);
+  if (c->d_stem2_w1) (void)ron::dev_free(c->d_stem2_w1);
   delete c;
   return RON_OK;
 }
@@ -734,7 +734,7 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
   if (c->finalized) { ron::set_error("weights are already finalized"); return RON_ERR_STATE; }
   for (auto& v : c->vars)
     if (!v.loaded) { ron::set_error("variable '%s' was not loaded", v.name.c_str()); return RON_ERR_STATE; }
-  RON_HIP_CHECK(hipSetDevice(c->cfg.device));
+  RON_HIP_CHECK(ron::dev_set_device(c->cfg.device));
   const int H = c->cfg.img_h, W = c->cfg.img_w;
   auto T = [&](const std::string& n) { return c->tensor_index.at(n); };
   double flops = 0, mark = 0;
@@ -758,10 +758,10 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
         std::vector<uint16_t> frags;
         if (c->cfg.dtype == RON_DTYPE_F16X3) c->stem_oscale = stem_pack_weights_split(c->var(scope + "/weights").data.data(), &frags);
         else stem_pack_weights(c->var(scope + "/weights").data.data(), c->cfg.dtype, &frags);
-        RON_HIP_CHECK(hipMalloc(&c->d_stem_w, frags.size() * 2));
-        RON_HIP_CHECK(hipMemcpy(c->d_stem_w, frags.data(), frags.size() * 2, hipMemcpyHostToDevice));
-        RON_HIP_CHECK(hipMalloc((void**)&c->d_stem_b, 64 * sizeof(float)));
-        RON_HIP_CHECK(hipMemcpy(c->d_stem_b, c->var(scope + "/biases").data.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
+        RON_HIP_CHECK(ron::dev_malloc(&c->d_stem_w, frags.size() * 2));
+        RON_HIP_CHECK(ron::dev_memcpy(c->d_stem_w, frags.data(), frags.size() * 2, hipMemcpyHostToDevice));
+        RON_HIP_CHECK(ron::dev_malloc((void**)&c->d_stem_b, 64 * sizeof(float)));
+        RON_HIP_CHECK(ron::dev_memcpy(c->d_stem_b, c->var(scope + "/biases").data.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
         Op o; o.kind = OP_STEM; o.name = nm; o.out = T(nm);
         c->ops.push_back(o);
       } else {
@@ -788,14 +788,14 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
         // conv1_1 + conv1_2 + pool1 as one kernel (stem.hip): neither full-resolution 64-channel map touches HBM
         std::vector<uint16_t> img;
         stem2_pack_weights(c->var("conv1/conv1_2/weights").data.data(), c->cfg.dtype, &img);
-        RON_HIP_CHECK(hipMalloc(&c->d_stem2_w, img.size() * 2));
-        RON_HIP_CHECK(hipMemcpy(c->d_stem2_w, img.data(), img.size() * 2, hipMemcpyHostToDevice));
-        RON_HIP_CHECK(hipMalloc((void**)&c->d_stem2_b, 64 * sizeof(float)));
-        RON_HIP_CHECK(hipMemcpy(c->d_stem2_b, c->var("conv1/conv1_2/biases").data.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
+        RON_HIP_CHECK(ron::dev_malloc(&c->d_stem2_w, img.size() * 2));
+        RON_HIP_CHECK(ron::dev_memcpy(c->d_stem2_w, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+        RON_HIP_CHECK(ron::dev_malloc((void**)&c->d_stem2_b, 64 * sizeof(float)));
+        RON_HIP_CHECK(ron::dev_memcpy(c->d_stem2_b, c->var("conv1/conv1_2/biases").data.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
         // conv1_1 as 16x16x32 fragments for the fused kernel (the stand-alone stem kernel keeps its 32x32 fragments in d_stem_w)
         stem2_pack_w1(c->var("conv1/conv1_1/weights").data.data(), c->cfg.dtype, &img);
-        RON_HIP_CHECK(hipMalloc(&c->d_stem2_w1, img.size() * 2));
-        RON_HIP_CHECK(hipMemcpy(c->d_stem2_w1, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+        RON_HIP_CHECK(ron::dev_malloc(&c->d_stem2_w1, img.size() * 2));
+        RON_HIP_CHECK(ron::dev_memcpy(c->d_stem2_w1, img.data(), img.size() * 2, hipMemcpyHostToDevice));
         Op f; f.kind = OP_STEM2; f.name = "conv1_1+conv1_2+pool1"; f.out = T(pname);
         f.flops = c->ops[n_ops - 2].flops + c->ops[n_ops - 1].flops;
         c->ops.pop_back(); c->ops.pop_back();
@@ -835,8 +835,8 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
     // ---- multibox heads (nets/ssd_vgg_300.py:403-431) ----
     {
       const Var& g = c->var("block4_box/L2Normalization/gamma");
-      RON_HIP_CHECK(hipMalloc((void**)&c->d_l2_gamma, g.data.size() * sizeof(float)));
-      RON_HIP_CHECK(hipMemcpy(c->d_l2_gamma, g.data.data(), g.data.size() * sizeof(float), hipMemcpyHostToDevice));
+      RON_HIP_CHECK(ron::dev_malloc((void**)&c->d_l2_gamma, g.data.size() * sizeof(float)));
+      RON_HIP_CHECK(ron::dev_memcpy(c->d_l2_gamma, g.data.data(), g.data.size() * sizeof(float), hipMemcpyHostToDevice));
       Op o; o.kind = OP_L2NORM; o.name = "block4_l2norm"; o.in = T("conv4_3"); o.out = T("block4_norm");
       c->ops.push_back(o);
     }
@@ -1041,7 +1041,7 @@ static int slot_resources(ron_ctx* c) {
   }
   if (c->weights_owner != nullptr) for (int l = 0; l < 4; ++l) c->splitk_bytes[l] = c->weights_owner->splitk_bytes[l];
   for (int l = 0; l < 4; ++l)
-    if (c->splitk_bytes[l] > 0) RON_HIP_CHECK(hipMalloc(&c->d_splitk[l], (size_t)c->splitk_bytes[l]));
+    if (c->splitk_bytes[l] > 0) RON_HIP_CHECK(ron::dev_malloc(&c->d_splitk[l], (size_t)c->splitk_bytes[l]));
   // ron_detect's head buffers and post-processing workspace, for max_batch: allocated (and the workspace zeroed) here, so that the
   // first ron_detect is as free of host synchronisation as every later one (include/ron_hip.h, Ownership)
   {
@@ -1049,9 +1049,9 @@ static int slot_resources(ron_ctx* c) {
     for (int i = 0; i < c->n_feat; ++i) {
       const int A = c->feat_A[i];
       const size_t cells = (size_t)mb * c->feat_h[i] * c->feat_w[i];
-      RON_HIP_CHECK(hipMalloc((void**)&c->d_head[0][i], cells * A * c->cfg.num_classes * sizeof(float)));
-      if (c->has_obj) RON_HIP_CHECK(hipMalloc((void**)&c->d_head[1][i], cells * A * 2 * sizeof(float)));
-      RON_HIP_CHECK(hipMalloc((void**)&c->d_head[2][i], cells * A * 4 * sizeof(float)));
+      RON_HIP_CHECK(ron::dev_malloc((void**)&c->d_head[0][i], cells * A * c->cfg.num_classes * sizeof(float)));
+      if (c->has_obj) RON_HIP_CHECK(ron::dev_malloc((void**)&c->d_head[1][i], cells * A * 2 * sizeof(float)));
+      RON_HIP_CHECK(ron::dev_malloc((void**)&c->d_head[2][i], cells * A * 4 * sizeof(float)));
     }
     ron_heads hd;
     memset(&hd, 0, sizeof(hd));
@@ -1060,8 +1060,8 @@ static int slot_resources(ron_ctx* c) {
     for (int i = 0; i < c->n_feat; ++i) { hd.cls[i] = c->d_head[0][i]; hd.obj[i] = c->d_head[1][i]; hd.loc[i] = c->d_head[2][i]; }
     c->post_ws_bytes = ron_post_np_workspace_bytes(&hd, mb);
     if (c->post_ws_bytes <= 0) return RON_ERR_INVALID;      // (ron_last_error says why)
-    RON_HIP_CHECK(hipMalloc(&c->d_post_ws, (size_t)c->post_ws_bytes));
-    RON_HIP_CHECK(hipMemset(c->d_post_ws, 0, (size_t)c->post_ws_bytes));      // once: the kernels keep the counters clean
+    RON_HIP_CHECK(ron::dev_malloc(&c->d_post_ws, (size_t)c->post_ws_bytes));
+    RON_HIP_CHECK(ron::dev_memset(c->d_post_ws, 0, (size_t)c->post_ws_bytes));      // once: the kernels keep the counters clean
   }
   c->timing.assign(c->ops.size() + 1, OpTiming());
   // names ron_profile_get hands out: a grouped launch is reported on its first member as "group[first+N]", the other members as
@@ -1350,7 +1350,7 @@ extern "C" int ron_detect(ron_ctx* c, const float* d_images, int n, const ron_po
   for (int i = 0; i < c->n_feat; ++i) { hd.cls[i] = c->d_head[0][i]; hd.obj[i] = c->d_head[1][i]; hd.loc[i] = c->d_head[2][i]; }
   if (c->post_ws_dirty) {
     // an earlier call failed between its select pass and the pass that zeroes the counters again: start from a clean workspace
-    RON_HIP_CHECK(hipMemsetAsync(c->d_post_ws, 0, (size_t)c->post_ws_bytes, (hipStream_t)stream));
+    RON_HIP_CHECK(ron::dev_memset_async(c->d_post_ws, 0, (size_t)c->post_ws_bytes, (hipStream_t)stream));
     c->post_ws_dirty = false;
   }
   int rc = ron_forward(c, d_images, n, &hd, stream);

@@ -943,13 +943,13 @@ extern "C" int ron_post_np(const ron_heads* heads, int n, const ron_post_cfg* cf
     static ron::PerDeviceOnce once;
     RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&select_kernel), (int)lds));
   }
-  hipLaunchKernelGGL(select_kernel, grid, dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
+  RON_LAUNCH(select_kernel, grid, dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
   // only lists that can exceed kPartMin need the partial pass at all (its workgroups return at once for shorter ones)
   if (cap > kPartMin)
-    hipLaunchKernelGGL(topk_partial_kernel, dim3(kPartChunks, n), dim3(kTopkThreads), 0, s, keys, counts, cap, pc.top_k, part_keys, part_total);
-  hipLaunchKernelGGL(topk_nms_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, part_keys, part_total, d_out,
+    RON_LAUNCH(topk_partial_kernel, dim3(kPartChunks, n), dim3(kTopkThreads), 0, s, keys, counts, cap, pc.top_k, part_keys, part_total);
+  RON_LAUNCH(topk_nms_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, part_keys, part_total, d_out,
                      d_sorted, n_candidates);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -970,9 +970,9 @@ extern "C" int ron_np_sort_nms(const int32_t* classes, const float* scores, cons
   int rc;
   if ((rc = to_det_dev(out, &d_out, top_k, "out", false)) != RON_OK) return rc;
   if ((rc = to_det_dev(sorted_out, &d_sorted, top_k, "sorted_out", true)) != RON_OK) return rc;
-  hipLaunchKernelGGL(list_sort_nms_kernel, dim3(n), dim3(kTopkThreads), 0, (hipStream_t)stream, classes, scores,
+  RON_LAUNCH(list_sort_nms_kernel, dim3(n), dim3(kTopkThreads), 0, (hipStream_t)stream, classes, scores,
                      bboxes, n_valid, n_in, top_k, nms_threshold, (u64*)workspace, d_out, d_sorted);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -984,10 +984,10 @@ extern "C" int ron_bboxes_decode_layer(const float* loc, int n, int feat_h, int 
   RON_REQUIRE(n > 0 && feat_h > 0 && feat_w > 0 && num_anchors > 0, "bad shape");
   const size_t total = (size_t)n * feat_h * feat_w * num_anchors;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
-  hipLaunchKernelGGL(decode_layer_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, loc, n, feat_h * feat_w,
+  RON_LAUNCH(decode_layer_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, loc, n, feat_h * feat_w,
                      num_anchors, anchor_y, anchor_x, anchor_h, anchor_w, prior_scaling[0], prior_scaling[1],
                      prior_scaling[2], prior_scaling[3], out);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -1014,17 +1014,17 @@ extern "C" int ron_pack_records(const ron_detections* det, int n, float* records
   RON_REQUIRE(det->capacity >= 1, "ron_pack_records: empty detection buffers");
   DetDev d{det->capacity, det->classes, det->scores, det->bboxes, det->anchor_index, det->count};
   RON_REQUIRE(d.classes && d.scores && d.bboxes && d.anchor_index && d.count, "ron_pack_records: every detection array is needed");
-  hipLaunchKernelGGL(pack_records_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, d, records);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_LAUNCH(pack_records_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, d, records);
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
 extern "C" int ron_softmax_last(const float* x, int64_t rows, int c, int pick, float* y, void* stream) {
   RON_REQUIRE(x && y && rows > 0 && c > 0 && pick < c, "bad argument");
   const int blocks = (int)std::min<int64_t>((rows + 255) / 256, 4096);
-  hipLaunchKernelGGL(softmax_last_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, c,
+  RON_LAUNCH(softmax_last_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, c,
                      pick, y);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -1374,9 +1374,9 @@ extern "C" int ron_post_eval(const ron_heads* heads, int n, const float* min_siz
     static ron::PerDeviceOnce once;
     RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&eval_select_kernel), (int)lds));
   }
-  hipLaunchKernelGGL(eval_select_kernel, dim3(hd.block_base[RON_MAX_LAYERS], n), dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
-  hipLaunchKernelGGL(eval_nms_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, d_out);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_LAUNCH(eval_select_kernel, dim3(hd.block_base[RON_MAX_LAYERS], n), dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
+  RON_LAUNCH(eval_nms_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, d_out);
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -1417,9 +1417,9 @@ extern "C" int ron_post_tfe(const ron_heads* heads, int n, const ron_tfe_cfg* cf
     static ron::PerDeviceOnce once;
     RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&tfe_select_kernel), (int)lds));
   }
-  hipLaunchKernelGGL(tfe_select_kernel, dim3(hd.block_base[RON_MAX_LAYERS], n), dim3(kSelectThreads), lds, s, hd, pc, keys,
+  RON_LAUNCH(tfe_select_kernel, dim3(hd.block_base[RON_MAX_LAYERS], n), dim3(kSelectThreads), lds, s, hd, pc, keys,
                      counts, cap);
-  hipLaunchKernelGGL(tfe_topk_nms_kernel, dim3(C1, n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, scores, bboxes);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_LAUNCH(tfe_topk_nms_kernel, dim3(C1, n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, scores, bboxes);
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }

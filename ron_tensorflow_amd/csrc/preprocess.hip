@@ -72,8 +72,8 @@ extern "C" int ron_preprocess_eval_geom(const uint8_t* packed, const int64_t* of
   ron::Means m;
   for (int c = 0; c < 3; ++c) m.m[c] = means[c];
   const int px = out_h * out_w;
-  hipLaunchKernelGGL(ron::preprocess_eval_kernel, dim3((px + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, packed, offsets, hw,
+  RON_LAUNCH(ron::preprocess_eval_kernel, dim3((px + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, packed, offsets, hw,
                      geom, out_h, out_w, m, out);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }

@@ -483,15 +483,15 @@ int launch_stem_conv(const float* x, int n, int h, int w, int dtype, const void*
   const long long tiles = (long long)n * h * (w / 32);
   const int grid = (int)std::min<long long>((tiles + 3) / 4, 256 * 8);
   if (dtype == RON_DTYPE_F16X3)
-    hipLaunchKernelGGL(stem_conv_split_kernel, dim3(grid), dim3(256), 0, s, x, n, h, w, (const u32x4*)d_wfrag, d_bias, oscale,
+    RON_LAUNCH(stem_conv_split_kernel, dim3(grid), dim3(256), 0, s, x, n, h, w, (const u32x4*)d_wfrag, d_bias, oscale,
                        (unsigned*)out.base, out.Hp(), out.Wp(), out.pad);
   else if (dtype == RON_DTYPE_BF16)
-    hipLaunchKernelGGL(stem_conv_kernel<StemBF16>, dim3(grid), dim3(256), 0, s, x, n, h, w, (const u32x4*)d_wfrag, d_bias,
+    RON_LAUNCH(stem_conv_kernel<StemBF16>, dim3(grid), dim3(256), 0, s, x, n, h, w, (const u32x4*)d_wfrag, d_bias,
                        (unsigned*)out.base, out.Hp(), out.Wp(), out.pad);
   else
-    hipLaunchKernelGGL(stem_conv_kernel<StemF16>, dim3(grid), dim3(256), 0, s, x, n, h, w, (const u32x4*)d_wfrag, d_bias,
+    RON_LAUNCH(stem_conv_kernel<StemF16>, dim3(grid), dim3(256), 0, s, x, n, h, w, (const u32x4*)d_wfrag, d_bias,
                        (unsigned*)out.base, out.Hp(), out.Wp(), out.pad);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
@@ -539,12 +539,12 @@ int launch_stem2(const float* x, int n, int h, int w, int dtype, const void* d_w
   RON_HIP_CHECK(attr_set[which].max_dynamic_lds(which == 0 ? reinterpret_cast<const void*>(&stem2_kernel<StemBF16>)
                                                            : reinterpret_cast<const void*>(&stem2_kernel<StemF16>), kS2Lds));
   if (which == 0)
-    hipLaunchKernelGGL(stem2_kernel<StemBF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
+    RON_LAUNCH(stem2_kernel<StemBF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
                        (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad);
   else
-    hipLaunchKernelGGL(stem2_kernel<StemF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
+    RON_LAUNCH(stem2_kernel<StemF16>, dim3(grid), dim3(512), kS2Lds, s, x, n, h, w, (const u32x4*)d_w1frag, d_bias1,
                        (const u32x4*)d_w2img, d_bias2, (unsigned short*)out.base, out.Hp(), out.Wp(), out.pad);
-  RON_HIP_CHECK(hipGetLastError());
+  RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }
 
