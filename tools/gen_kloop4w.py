@@ -51,10 +51,8 @@ def gen(mfma, split=False):
     e('s_and_b32 s53, s39, 0xffff')
     e('s_mov_b32 s54, s41')
     e('s_mov_b32 s55, 0x00020000')
-    for r in range(256):
-        e('v_accvgpr_write_b32 a%d, 0' % r)
     e('s_cmp_eq_u32 s42, 0')
-    e('s_cbranch_scc1 .Lk4w_end_%=')
+    e('s_cbranch_scc1 .Lk4w_zero_%=')
     for k in range(4):
         e('v_mov_b32 v%d, v%d' % (88 + k, 116 + k))                    # v88 rdA0, v89 rdA1, v90 rdB0, v91 rdB1
         e('v_add_u32 v%d, 0x%x, v%d' % (92 + k, STAGE, 88 + k))
@@ -104,6 +102,9 @@ def gen(mfma, split=False):
     e('s_xor_b32 s60, s60, s63')
     e('s_mov_b32 s58, 2')
     e('s_mov_b32 s61, s42')
+    # the accumulators are cleared while the first two tiles are on their way (1 k cycles of v_accvgpr_write)
+    for r in range(256):
+        e('v_accvgpr_write_b32 a%d, 0' % r)
     e('s_waitcnt vmcnt(16)')
     e('s_barrier')
     for j in range(8):
@@ -192,6 +193,10 @@ def gen(mfma, split=False):
             e(s_)
     e('s_cbranch_scc0 .Lk4w_loop_%=')
     e('s_waitcnt vmcnt(0)')
+    e('s_branch .Lk4w_end_%=')
+    e('.Lk4w_zero_%=:')                          # no K steps (an empty split-K slice): zeros
+    for r in range(256):
+        e('v_accvgpr_write_b32 a%d, 0' % r)
     e('.Lk4w_end_%=:')
     e('s_nop 15')
     e('s_nop 15')
