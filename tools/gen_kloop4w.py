@@ -27,6 +27,8 @@ Interface (physical registers; conv_mfma.hip, conv_igemm_tile, binds them):
 """
 import os
 
+OPTS = set(x for x in os.environ.get('KLOOP_OPTS', '').split(',') if x)
+
 STAGE = 32768          # bytes of one operand's stage: 256 rows x 128 B
 PIECE_STEP = 4096      # LDS bytes between a wave's consecutive DMA pieces (4 waves x 1 KB)
 FRAG_STEP = 2048       # LDS bytes between consecutive 16-row fragments
@@ -129,7 +131,11 @@ def gen(mfma, split=False):
     at(5, 's_cselect_b32 s50, s40, 0')
     at(7, 's_cselect_b32 s54, s41, 0')
     at(7, 's_add_u32 s58, s58, 1')
-    at(10, 's_waitcnt lgkmcnt(%d)' % (6 if split else 5))      # the table entry is back (LDS operations return in order)
+    if 'endwait' in OPTS and not split:
+        at(7, 's_waitcnt lgkmcnt(11)')           # 7 reads of the previous step + 5 of this one issued: the oldest (row tile 1's A) is back
+        at(10, 's_waitcnt lgkmcnt(5)')
+    else:
+        at(10, 's_waitcnt lgkmcnt(%d)' % (6 if split else 5))      # the table entry is back (LDS operations return in order)
     at(10, 'v_readfirstlane_b32 s56, v86')
     at(10, 'v_readfirstlane_b32 s57, v87')
     at(19, 's_mov_b32 m0, s60')
@@ -146,10 +152,16 @@ def gen(mfma, split=False):
     at(51, 's_barrier')
     if not split:
         apos = [61, 64, 85, 87, 89, 96, 100, 124]
+        if 'earlyA' in OPTS:
+            apos = [61, 64, 67, 70, 73, 76, 79, 82]
         t_xor, t_wait = 83, 91
         bpos_rd = [93, 94, 95, 97, 98, 102, 103, 104]
         apos_rd0 = [105, 106, 109, 112, 114, 117, 120, 123]
         end_wait = 's_waitcnt lgkmcnt(0)'
+        if 'endwait' in OPTS:
+            # only the first A fragment of the next step is needed by its first 8 MFMAs: the other seven reads may still be in flight at
+            # the branch; MFMA 8 (row tile 1) is covered by a counted wait in front of it, the rest by the step's own waits
+            end_wait = 's_waitcnt lgkmcnt(7)'
     else:
         # Three products per 16 x 16 x 32 block, in the order of the eight-wave loop (bit-identical sums): MFMA 0..63 hi * hi,
         # 64..127 lo(A) * hi(B), 128..191 hi(A) * lo(B).  hi(B) is dead after 127 and hi(A) of row tile i after 128 + 8 i + 7: the next
@@ -179,7 +191,7 @@ def gen(mfma, split=False):
     at(NM - 2, end_wait)
     n_dma = sum(1 for m in ev for s_ in ev[m] if s_.startswith('buffer_load'))
     assert n_dma == 16
-    assert n_before == (16 if split else 13), n_before
+    assert n_before in (13, 16), n_before
     e('.Lk4w_loop_%=:')
     for m in range(NM):
         ph, i, j = m // 64, (m % 64) // 8, m % 8
@@ -204,7 +216,7 @@ def gen(mfma, split=False):
 
 
 def main():
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ron_tensorflow_amd', 'csrc', 'kloop4w.inc')
+    out = os.environ.get('KLOOP_OUT') or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ron_tensorflow_amd', 'csrc', 'kloop4w.inc')
     with open(out, 'w') as f:
         f.write('// GENERATED by tools/gen_kloop4w.py - do not edit.  The K loop of the 256 x 256 tile on four waves as inline assembly;\n')
         f.write('// interface, schedule and rationale: the generator\'s docstring.\n')
