@@ -70,7 +70,8 @@ enum {
   kCfgIgemm256TapsInner = 7,   // 256 x 256 with K ordered chunk-major, taps innermost (layers with <= 2 column tiles)
   kCfgC64Resident = 8,     // 3x3 on a 64-channel map with the weights resident in LDS (conv_c64.hip)
   kCfgIgemm128EarlyTapsInner = 9,   // 128 x 128, early issue, K ordered chunk-major with the taps innermost (launches that do not split K)
-  kNumCfgs = 10
+  kCfgIgemm256x128 = 10,   // 256 x 128 on four waves with the assembly K loop (bf16 / f16 / f16x3): layers with Cout = 128 (conv2_x)
+  kNumCfgs = 11
 };
 inline bool conv_cfg_taps_inner(int cfg) { return cfg == kCfgIgemm256TapsInner || cfg == kCfgIgemm128EarlyTapsInner; }
 inline bool conv_cfg_is_patch(int cfg) { return cfg >= kCfgPatch256 && cfg <= kCfgPatch64; }

@@ -64,6 +64,14 @@ struct AccAgpr4w {
   }
 };
 
+// ... of the 256 x 128 tile: block (i, j), j < 4, in a[4 * (4 * i + j) : +3], two row tiles per tuple
+struct AccAgpr4wN128 {
+  const f32x32 &c0, &c1, &c2, &c3;
+  __device__ __forceinline__ void row(int i, int e, float (&v)[4]) const {
+    switch (i * 4 + e) { RON_ACC4W_N128_CASES }
+  }
+};
+
 // Everything after the K loop of conv_igemm_tile: raw fp32 slab store of a split-K slice, or the conv epilogue.
 template <class Tr, int MR, int NR, int MT, int EPA, int TM, int TN, class Reader>
 __device__ __forceinline__ void igemm_finish(const ConvArgs& p, const Reader& rd, const int* s_out_off, const int* s_out2_off, int zsplit,
@@ -125,7 +133,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   // The 256 x 256 tile on FOUR waves (128 x 128 per wave, one wave per SIMD, 256 accumulator + 256 vector registers) runs its K loop
   // as the assembly of kloop4w.inc (tools/gen_kloop4w.py): two tiles of LDS-DMA in flight over two LDS stages, three barriers per
   // K step.  bf16, f16 and the split-precision form (three MFMAs per block); fp32 stays on the eight-wave loop.
-  constexpr bool kAsmLoop = AsmLoop<Tr>::value && BM == 256 && BN == 256 && WM == 2 && WN == 2 && S == 2;
+  constexpr bool kAsmLoop = AsmLoop<Tr>::value && BM == 256 && (BN == 256 || BN == 128) && WM == 2 && WN == 2 && S == 2;
   // layout: [A stage 0 .. S-1][B stage 0 .. S-1][in_off: BM ints][out_off: BM ints][out2_off: BM ints][step table (kAsmLoop)]
   char* s_a = smem;
   char* s_b = smem + S * kABytes;
@@ -295,7 +303,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   const int a_base = wm * TM * kRowBytes;
   const int b_base = wn * TN * kRowBytes;
   if constexpr (kAsmLoop) {
-    static_assert(KS == 2 && MR == 8 && NR == 8 && A_IT == 8 && B_IT == 8, "kloop4w.inc is written for this tile");
+    static_assert(KS == 2 && MR == 8 && (NR == 8 || NR == 4) && A_IT == 8 && B_IT == NR, "kloop4w.inc is written for these tiles");
     // Step table: entry q = {soffset of the A pieces, soffset of the B pieces} of the tile's K step kt0 + q, in the launch's K order
     // (tap-major / taps innermost / position-major walk, see the loop of the other tiles below); two more entries than steps: the
     // loop stages two tiles ahead, past the end with zero-record descriptors.
@@ -331,7 +339,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
     __syncthreads();
     u32x8 av, bv;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) { av[it] = (unsigned)a_voff[it]; bv[it] = (unsigned)b_voff[it]; }
+    for (int it = 0; it < 8; ++it) { av[it] = (unsigned)a_voff[it]; bv[it] = it < B_IT ? (unsigned)b_voff[it < B_IT ? it : 0] : 0u; }
     const unsigned lds_a = (unsigned)(uintptr_t)(lds_void*)s_a, lds_b = (unsigned)(uintptr_t)(lds_void*)s_b;
     const unsigned dst_a = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_a + wave * 1024));
     const unsigned dst_b = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_b + wave * 1024));
@@ -341,19 +349,34 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
     const unsigned long long in_ptr = (unsigned long long)(uintptr_t)p.in, wgt_ptr = (unsigned long long)(uintptr_t)p.wgt;
     const unsigned in_bytes = p.in_bytes, wgt_bytes = p.wgt_bytes;
     const unsigned ns = (unsigned)__builtin_amdgcn_readfirstlane(nsteps);
-    f32x32 c0, c1, c2, c3, c4, c5, c6, c7;
-#define RON_KLOOP4W_OPERANDS                                                                                                        \
-        : "={a[0:31]}"(c0), "={a[32:63]}"(c1), "={a[64:95]}"(c2), "={a[96:127]}"(c3), "={a[128:159]}"(c4), "={a[160:191]}"(c5),      \
-          "={a[192:223]}"(c6), "={a[224:255]}"(c7)                                                                                  \
+#define RON_KLOOP4W_INPUTS                                                                                                          \
         : "{s[36:37]}"(in_ptr), "{s[38:39]}"(wgt_ptr), "{s40}"(in_bytes), "{s41}"(wgt_bytes), "{s42}"(ns), "{s43}"(dst_a),          \
           "{s44}"(dst_b), "{v[100:107]}"(av), "{v[108:115]}"(bv), "{v116}"(rd_a0), "{v117}"(rd_a1), "{v118}"(rd_b0),                \
           "{v119}"(rd_b1), "{v120}"(tab)                                                                                            \
         : RON_KLOOP4W_CLOBBERS
-    if constexpr (IsSplit<Tr>::value) asm volatile(RON_KLOOP4W_F16X3 RON_KLOOP4W_OPERANDS);
-    else if constexpr (Tr::kIsBf16) asm volatile(RON_KLOOP4W_BF16 RON_KLOOP4W_OPERANDS);
-    else asm volatile(RON_KLOOP4W_F16 RON_KLOOP4W_OPERANDS);
+    if constexpr (NR == 8) {
+      f32x32 c0, c1, c2, c3, c4, c5, c6, c7;
+#define RON_KLOOP4W_OPERANDS                                                                                                        \
+        : "={a[0:31]}"(c0), "={a[32:63]}"(c1), "={a[64:95]}"(c2), "={a[96:127]}"(c3), "={a[128:159]}"(c4), "={a[160:191]}"(c5),      \
+          "={a[192:223]}"(c6), "={a[224:255]}"(c7)                                                                                  \
+        RON_KLOOP4W_INPUTS
+      if constexpr (IsSplit<Tr>::value) asm volatile(RON_KLOOP4W_F16X3 RON_KLOOP4W_OPERANDS);
+      else if constexpr (Tr::kIsBf16) asm volatile(RON_KLOOP4W_BF16 RON_KLOOP4W_OPERANDS);
+      else asm volatile(RON_KLOOP4W_F16 RON_KLOOP4W_OPERANDS);
 #undef RON_KLOOP4W_OPERANDS
-    igemm_finish<Tr, MR, NR, MT, EPA, TM, TN>(p, AccAgpr4w{c0, c1, c2, c3, c4, c5, c6, c7}, s_out_off, s_out2_off, zsplit, m0, n0, wm, wn, fr, fh);
+      igemm_finish<Tr, MR, NR, MT, EPA, TM, TN>(p, AccAgpr4w{c0, c1, c2, c3, c4, c5, c6, c7}, s_out_off, s_out2_off, zsplit, m0, n0, wm, wn, fr, fh);
+    } else {
+      f32x32 c0, c1, c2, c3;
+#define RON_KLOOP4W_OPERANDS                                                                                                        \
+        : "={a[0:31]}"(c0), "={a[32:63]}"(c1), "={a[64:95]}"(c2), "={a[96:127]}"(c3)                                                \
+        RON_KLOOP4W_INPUTS
+      if constexpr (IsSplit<Tr>::value) asm volatile(RON_KLOOP4W_N128_F16X3 RON_KLOOP4W_OPERANDS);
+      else if constexpr (Tr::kIsBf16) asm volatile(RON_KLOOP4W_N128_BF16 RON_KLOOP4W_OPERANDS);
+      else asm volatile(RON_KLOOP4W_N128_F16 RON_KLOOP4W_OPERANDS);
+#undef RON_KLOOP4W_OPERANDS
+      igemm_finish<Tr, MR, NR, MT, EPA, TM, TN>(p, AccAgpr4wN128{c0, c1, c2, c3}, s_out_off, s_out2_off, zsplit, m0, n0, wm, wn, fr, fh);
+    }
+#undef RON_KLOOP4W_INPUTS
     return;
   } else {
   const int tap0 = ti ? kt0 % n_taps : kt0 / chunks_per_tap;
@@ -661,6 +684,12 @@ int launch_cfg(int cfg, const ConvArgs& a, hipStream_t s) {
     case kCfgIgemm128: return launch_t<Tr, 128, 128, 2, 2, 2, 1>(a, s);
     case kCfgIgemm128Early: case kCfgIgemm128EarlyTapsInner: return launch_t<Tr, 128, 128, 2, 2, 2, 2>(a, s);
     case kCfgIgemm128x64: return launch_t<Tr, 128, 64, 2, 2, 2, 2>(a, s);
+    case kCfgIgemm256x128:
+      if constexpr (AsmLoop<Tr>::value) {
+        if (asm_loop_ok(a.kt_split)) return launch_t<Tr, 256, 128, 2, 2, 2, 1>(a, s);
+      }
+      ron::set_error("conv: the 256 x 128 tile is the four-wave assembly loop's (bf16 / f16 / f16x3, <= %d K steps per workgroup)", kAsmLoopMaxSteps);
+      return RON_ERR_INVALID;
   }
   ron::set_error("conv: unknown tile config %d", cfg);
   return RON_ERR_INVALID;
@@ -684,10 +713,10 @@ int conv_n_tile(int cout) { return cout <= 64 ? 64 : 128; }
 int conv_num_cfgs() { return kNumCfgs; }
 
 static bool igemm_is256(int cfg) { return cfg == kCfgIgemm256 || cfg == kCfgIgemm256TapsInner; }
-static int igemm_bm(int cfg) { return igemm_is256(cfg) ? 256 : 128; }
+static int igemm_bm(int cfg) { return (igemm_is256(cfg) || cfg == kCfgIgemm256x128) ? 256 : 128; }
 static int igemm_bn(int cfg) { return igemm_is256(cfg) ? 256 : (cfg == kCfgIgemm128x64 ? 64 : 128); }
 // workgroups of a configuration the chip holds at once (256 CUs; 64 KB of LDS lets two share a CU)
-static int igemm_slots(int cfg) { return igemm_is256(cfg) ? 256 : 512; }
+static int igemm_slots(int cfg) { return (igemm_is256(cfg) || cfg == kCfgIgemm256x128) ? 256 : 512; }
 
 // Split-K factor for grids that leave most CUs idle: such launches are a serial chain of KT dependent
 // HBM round trips per workgroup, so the K loop is spread over enough workgroups to fill the chip (>= 8 steps each).
@@ -698,6 +727,8 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
   if (sk > KT / min_steps) sk = KT / min_steps;
   return sk < 1 ? 1 : sk;
 }
+
+constexpr int kAsmLoopMaxStepsHost = detail::kAsmLoopMaxSteps;
 
 // Default tile of the row-gather kernel, from tools/sweep_conv.py on MI355X at batch 32 (profiles/r01/sweep_*.txt).
 // The 256x256 tile wins once it yields >= ~160 workgroups; below that the grid is the problem and the 128x128 /
@@ -782,6 +813,11 @@ int conv_pick_cfg(const ConvLaunch& c) {
   // (split K: not with a fused pool / transposed conv, and a launch with centre-tap-only columns counts those tiles too)
   const bool may_split = c.center_from == 0 && !c.pool && c.up == 0 && c.splitk < 0;      // (the same answer when the scratch is being sized)
   const int KT = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
+  // Cout = 128 (conv2_x) on maps large enough to fill the chip with 256 x 128 tiles: the four-wave assembly loop at 48 KB staged per
+  // K step instead of two 128 x 128 workgroups per CU at 64 KB (sweep: profiles/r05/sweep_256x128.txt)
+  if (c.dtype != RON_DTYPE_F32 && c.Npad % 256 == 128 && c.center_from == 0 && c.up == 0 && c.out2.base == nullptr &&
+      ((M + 255) / 256) * (c.Npad / 128) >= 256 && KT <= kAsmLoopMaxStepsHost)
+    return kCfgIgemm256x128;
   const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, c.kh * c.kw * c.in.C, may_split);
   // taps innermost: only for the stride-1 convolutions it has been measured and tested on (the stride-2 3x3 convolutions of SSD-512's
   // extra blocks keep the tap-major order).  Centre-tap-only column tiles of such a launch keep the tap-major walk of their one tap.
@@ -839,6 +875,8 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
   a.pos_major = pick_pos_major(c, cfg, BM);
   a.taps_inner = conv_cfg_taps_inner(cfg) ? 1 : 0;
+  // the 256 x 128 tile: taps innermost by the rule of the other tiles (stride-1 filters that neither split K nor skip filter rows)
+  if (cfg == kCfgIgemm256x128 && c.kh * c.kw > 1 && c.stride == 1 && a.splitk == 1 && !a.pos_major) a.taps_inner = 1;
   if (c.center_from > 0)
     RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1) && c.up == 0,
                 "conv: centre-tap-only columns need an odd filter and a boundary on the N tile (%d)", BN);

@@ -188,7 +188,7 @@ def test_every_tile_configuration(ops, dev, cfg, dtype):
     """Each tile configuration of the row-gather kernel on a ragged multi-tile problem, K = 18 steps.  The shipped library
     holds exactly the configurations conv_pick_cfg() can select (the ablation builds live in libron_hip_diag.so)."""
     from ron_tensorflow_amd import _lib
-    assert _lib.lib().ron_conv_num_tile_cfgs() == 10
+    assert _lib.lib().ron_conv_num_tile_cfgs() == 11
     rs = np.random.RandomState(40 + cfg)
     x = rs.randn(3, 13, 11, 128).astype(np.float32)            # M = 429: two 256-row or four 128-row tiles, ragged
     wt = (rs.randn(3, 3, 128, 192) * 0.03).astype(np.float32)  # Cout 192 -> padded to 256
@@ -508,3 +508,52 @@ def test_halo_filter_rows_are_skipped_not_missed(ops, dev, shape, dtype):
     _check(got, ref_res, dtype)
     got = ops.conv2d_nhwc(xd, wt, b, residual=torch.from_numpy(res).to(dev), dilation=rate, relu=True, dtype=dtype, splitk=3).cpu().numpy()
     _check(got, ref_res, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16', 'f16x3'])
+def test_tile_256x128_of_the_assembly_loop(ops, dev, dtype):
+    """Tile configuration 10 (conv_mfma.h kCfgIgemm256x128: 256 x 128 on four waves, the assembly K loop with 4 column tiles per
+    wave; what conv_pick_cfg takes for conv2_x-sized layers with Cout = 128): ragged M over several tiles, Cout below the tile
+    width, K of 18 / 1 / 2 / 5 steps (shorter than the two tiles the loop keeps in flight, odd counts), a residual, fp32 output."""
+    rs = np.random.RandomState(90)
+    rnd = ROUND[dtype]
+    x = rs.randn(3, 13, 11, 128).astype(np.float32)                # M = 429: two 256-row tiles, the second ragged
+    wt = (rs.randn(3, 3, 128, 100) * 0.03).astype(np.float32)      # Cout 100 -> padded to 128: the last lanes' vectors are partial
+    b = (rs.randn(100) * 0.1).astype(np.float32)
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0)
+    xd = torch.from_numpy(x).to(dev)
+    got = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=10).cpu().numpy()
+    _check(got, ref, dtype)
+    # the same launch in the 128 x 128 tile: same products, the K order may differ (taps innermost) -> equal within rounding
+    _check(got, ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=1).cpu().numpy(), dtype)
+    chunk = 32 if dtype == 'f16x3' else 64
+    for steps in (1, 2, 5):
+        x2 = rs.randn(2, 9, 15, chunk * steps).astype(np.float32)
+        w2 = (rs.randn(1, 1, chunk * steps, 128) * 0.05).astype(np.float32)
+        res = np.maximum(rs.randn(2, 9, 15, 128), 0).astype(np.float32)
+        ref2 = np.maximum(orf.conv2d_np(rnd(x2), rnd(w2)) + rnd(res), 0)
+        got2 = ops.conv2d_nhwc(torch.from_numpy(x2).to(dev), w2, None, residual=torch.from_numpy(res).to(dev), relu=False, dtype=dtype,
+                               tile_cfg=10).cpu().numpy()
+        _check(got2, ref2, dtype)
+    # 256 x 128 is not a tile of the fp32 form
+    with pytest.raises(Exception, match='256 x 128'):
+        ops.conv2d_nhwc(xd, wt, b, relu=True, dtype='fp32', tile_cfg=10)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16x3'])
+def test_tile_256x128_with_fused_maxpool_and_by_choice(ops, dev, dtype):
+    """conv2_2's launch: 3x3, 128 -> 128, 2x2 max-pool fused, on a map large enough that conv_pick_cfg (-1) takes the 256 x 128 tile
+    (>= 256 tiles): the chosen launch and the explicit one give the same bits, both equal pool(conv) of the oracle."""
+    rs = np.random.RandomState(91)
+    rnd = ROUND[dtype]
+    x = rs.randn(2, 160, 208, 128).astype(np.float32)              # M = 66 560 rows = 260 tiles of 256
+    wt = (rs.randn(3, 3, 128, 128) * 0.03).astype(np.float32)
+    b = (rs.randn(128) * 0.1).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    got = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=10, pool=True).cpu().numpy()
+    auto = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=-1, pool=True).cpu().numpy()
+    assert np.array_equal(got, auto)
+    ref = orf.max_pool2x2_np(np.maximum(orf.conv2d_np(rnd(x[:1, :32]), rnd(wt)) + b, 0))      # the oracle on the top strip of image 0
+    _check(got[:1, :15], ref[:, :15], dtype)                        # (its last conv row lacks the strip's lower neighbour)
+    full = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=10)
+    assert np.array_equal(ops.maxpool2x2_nhwc(full, dtype=dtype).cpu().numpy(), got)

@@ -105,9 +105,10 @@ def check_patch(name, lines):
 
 
 def check_asm4w(name, lines):
-    """The four-wave assembly K loop (kloop4w.inc, tools/gen_kloop4w.py): two whole tiles (2 x 16 pieces) in the prologue and
-    `vmcnt(16)` before the first fragment reads; 16 pieces per K step; the loop's one `vmcnt(N)` has exactly N of them in front of
+    """The four-wave assembly K loop (kloop4w.inc, tools/gen_kloop4w.py): two whole tiles (2 x 16 pieces; 256 x 128: 2 x 12) in the
+    prologue and `vmcnt(pieces)` before the first fragment reads; 16 (12) pieces per K step; the loop's one `vmcnt(N)` has exactly N of them in front of
     it in the loop body (the previous step's tile has then landed), the rest behind."""
+    pieces = 8 + template_ints(name)[1] // 32          # per wave and K step: 8 of A + BN / 32 of B (256 x 256: 16, 256 x 128: 12)
     top = [i for i, l in enumerate(lines) if re.match(r'^\.Lk4w_loop_\d+:', l)]
     if len(top) != 1:
         return ['%d assembly K loops found, expected 1' % len(top)]
@@ -119,15 +120,15 @@ def check_asm4w(name, lines):
     end = end[0]
     problems = []
     pro = sum(1 for l in lines[start:top] if DMA.search(l))
-    if pro != 32:
-        problems.append('%d LDS-DMA instructions in the prologue, expected 32' % pro)
-    if not any(re.search(r's_waitcnt vmcnt\(16\)$', l.strip()) for l in lines[start:top]):
-        problems.append('no vmcnt(16) in the prologue')
+    if pro != 2 * pieces:
+        problems.append('%d LDS-DMA instructions in the prologue, expected %d' % (pro, 2 * pieces))
+    if not any(re.search(r's_waitcnt vmcnt\(%d\)$' % pieces, l.strip()) for l in lines[start:top]):
+        problems.append('no vmcnt(%d) in the prologue' % pieces)
     body = lines[top:end]
     waits = [(i, int(m.group(1))) for i, l in enumerate(body) for m in [re.search(r's_waitcnt vmcnt\((\d+)\)', l)] if m]
     n_dma = sum(1 for l in body if DMA.search(l))
-    if n_dma != 16:
-        problems.append('%d LDS-DMA instructions per K step, expected 16' % n_dma)
+    if n_dma != pieces:
+        problems.append('%d LDS-DMA instructions per K step, expected %d' % (n_dma, pieces))
     if len(waits) != 1:
         problems.append('%d vmcnt waits in the loop, expected 1' % len(waits))
     else:
@@ -143,7 +144,7 @@ def check_asm4w(name, lines):
 
 
 def is_asm4w(name):
-    return template_ints(name)[:5] == [256, 256, 2, 2, 2] and ('TraitsBF16S' in name or 'TraitsF16S' in name or 'TraitsF16X3S' in name) and 'mixed' not in name
+    return template_ints(name)[:5] in ([256, 256, 2, 2, 2], [256, 128, 2, 2, 2]) and ('TraitsBF16S' in name or 'TraitsF16S' in name or 'TraitsF16X3S' in name) and 'mixed' not in name
 
 
 def check_igemm(name, lines):
@@ -199,8 +200,8 @@ def check_file(source):
 
 
 # instantiations the Makefile's build holds (dtypes x tile forms); a different count means the check no longer sees all of them
-# (+ the four-wave assembly form of the 256 x 256 tile and of its grouped kernel: bf16, f16, f16x3)
-EXPECTED = {'conv_patch.hip': 4 * (3 + 3), 'conv_mfma.hip': 4 * (4 + 3 + 1) + 3 * 2}
+# (+ the four-wave assembly forms: the 256 x 256 tile and its grouped kernel, the 256 x 128 tile: bf16, f16, f16x3)
+EXPECTED = {'conv_patch.hip': 4 * (3 + 3), 'conv_mfma.hip': 4 * (4 + 3 + 1) + 3 * 2 + 3}
 
 
 def main():

@@ -29,19 +29,64 @@ import os
 
 OPTS = set(x for x in os.environ.get('KLOOP_OPTS', '').split(',') if x)
 
-STAGE = 32768          # bytes of one operand's stage: 256 rows x 128 B
+STAGE_A = 32768        # bytes of an A stage: 256 rows x 128 B
 PIECE_STEP = 4096      # LDS bytes between a wave's consecutive DMA pieces (4 waves x 1 KB)
 FRAG_STEP = 2048       # LDS bytes between consecutive 16-row fragments
-
-FA = [[128 + 4 * i for i in range(8)], [192 + 4 * i for i in range(8)]]     # FA[half][i]: first VGPR of A fragment i
-FB = [[160 + 4 * j for j in range(8)], [224 + 4 * j for j in range(8)]]
 
 
 def vr(first, n=4):
     return 'v[%d:%d]' % (first, first + n - 1)
 
 
-def gen(mfma, split=False):
+def schedule(NB, split):
+    """Where (after which MFMA of the step) every event of a K step goes.  NB = 16-column tiles per wave: 8 (256 x 256 tile) or 4
+    (256 x 128).  MFMA m of a phase is (row tile i, column tile j) = divmod(m % (8 * NB), NB)."""
+    if NB == 8 and not split:
+        d = dict(NM=128, b1_rd=[0, 2, 4, 6, 8, 10, 12, 14], valid=(5, 7), tab_wait=(10, 5), m0b=19, w1=20,
+                 bdma=[22, 25, 28, 31, 34, 52, 55, 58], a1_rd=[24, 27, 30, 33, 36, 38, 40, 42], w2=50,
+                 adma=[61, 64, 85, 87, 89, 96, 100, 124], xor=83, vm=91, b0_rd=[93, 94, 95, 97, 98, 102, 103, 104],
+                 a0_rd=[105, 106, 109, 112, 114, 117, 120, 123], end_wait='s_waitcnt lgkmcnt(0)')
+        if 'earlyA' in OPTS:
+            d['adma'] = [61, 64, 67, 70, 73, 76, 79, 82]
+        if 'endwait' in OPTS:
+            # only the first A fragment of the next step is needed by its first 8 MFMAs: the other seven reads may still be in flight at
+            # the branch; MFMA 8 (row tile 1) is covered by a counted wait in front of it, the rest by the step's own waits
+            d['end_wait'] = 's_waitcnt lgkmcnt(7)'
+            d['extra_wait'] = (7, 11)
+        return d
+    if NB == 8 and split:
+        # Three products per 16 x 16 x 32 block, in the order of the eight-wave loop (bit-identical sums): MFMA 0..63 hi * hi,
+        # 64..127 lo(A) * hi(B), 128..191 hi(A) * lo(B).  hi(B) is dead after 127 and hi(A) of row tile i after 128 + 8 i + 7: the next
+        # tile's hi fragments go straight into those registers (the last one, row tile 7, at the start of the next step).
+        return dict(NM=192, b1_rd=[0, 2, 4, 6, 8, 10, 12, 14], valid=(5, 7), tab_wait=(10, 6), m0b=19, w1=20,
+                    bdma=[22, 25, 28, 31, 34, 52, 55, 58], a1_rd=[24, 27, 30, 33, 36, 38, 40, 42], w2=50,
+                    adma=[61, 64, 67, 70, 73, 76, 79, 82], xor=120, vm=123, b0_rd=[128, 130, 132, 134, 136, 138, 140, 142],
+                    a0_rd=[137, 145, 153, 161, 169, 177, 185],
+                    end_wait='s_waitcnt lgkmcnt(1)')       # everything but the newest read (hi(A) of row tile 6, needed at MFMA 48)
+    if NB == 4 and not split:
+        # 64 MFMAs per step carry the same 24 fragment reads and 12 DMA pieces
+        return dict(NM=64, b1_rd=[0, 2, 4, 6], valid=(3, 5), tab_wait=(7, 3), m0b=8, w1=9,
+                    bdma=[11, 13, 15, 17], a1_rd=[12, 14, 16, 18, 20, 21, 22, 23], w2=27,
+                    adma=[29, 31, 33, 35, 37, 39, 41, 43], xor=44, vm=45, b0_rd=[47, 48, 49, 50],
+                    a0_rd=[51, 52, 53, 54, 55, 56, 57, 58], end_wait='s_waitcnt lgkmcnt(0)')
+    return dict(NM=96, b1_rd=[0, 2, 4, 6], valid=(3, 5), tab_wait=(7, 4), m0b=8, w1=9,
+                bdma=[11, 13, 15, 17], a1_rd=[12, 14, 16, 18, 20, 22, 24, 26], w2=29,
+                adma=[31, 33, 35, 37, 39, 41, 43, 45], xor=58, vm=60, b0_rd=[64, 65, 66, 67],
+                a0_rd=[69, 73, 77, 81, 85, 89, 93], end_wait='s_waitcnt lgkmcnt(1)')
+
+
+def gen(mfma, split=False, NB=8):
+    sc = schedule(NB, split)
+    NM = sc['NM']
+    STAGE_B = NB * 2 * 16 * 128                   # the B stage: 2 waves across x NB column tiles x 16 rows x 128 B
+    NBP = NB                                      # B pieces per wave and K step (A: 8)
+    if NB == 8:
+        FA = [[128 + 4 * i for i in range(8)], [192 + 4 * i for i in range(8)]]     # FA[half][i]: first VGPR of A fragment i
+        FB = [[160 + 4 * j for j in range(8)], [224 + 4 * j for j in range(8)]]
+    else:
+        FA = [[128 + 4 * i for i in range(8)], [160 + 4 * i for i in range(8)]]
+        FB = [[192 + 4 * j for j in range(4)], [208 + 4 * j for j in range(4)]]
+    NACC = 8 * NB * 4
     L = []
     e = L.append
     # ---- set-up
@@ -57,11 +102,11 @@ def gen(mfma, split=False):
     e('s_cbranch_scc1 .Lk4w_zero_%=')
     for k in range(4):
         e('v_mov_b32 v%d, v%d' % (88 + k, 116 + k))                    # v88 rdA0, v89 rdA1, v90 rdB0, v91 rdB1
-        e('v_add_u32 v%d, 0x%x, v%d' % (92 + k, STAGE, 88 + k))
+        e('v_add_u32 v%d, 0x%x, v%d' % (92 + k, STAGE_A if k < 2 else STAGE_B, 88 + k))
         e('v_xor_b32 v%d, v%d, v%d' % (92 + k, 92 + k, 88 + k))        # toggles between the two stages whatever the base
-    e('s_add_u32 s62, s43, 0x%x' % STAGE)
+    e('s_add_u32 s62, s43, 0x%x' % STAGE_A)
     e('s_xor_b32 s62, s62, s43')
-    e('s_add_u32 s63, s44, 0x%x' % STAGE)
+    e('s_add_u32 s63, s44, 0x%x' % STAGE_B)
     e('s_xor_b32 s63, s63, s44')
     e('s_mov_b32 s59, s43')
     e('s_mov_b32 s60, s44')
@@ -75,10 +120,10 @@ def gen(mfma, split=False):
     e('s_mov_b32 m0, s60')
     e('s_nop 4')
 
-    def tile_dma(first):
-        for it in range(8):
+    def tile_dma():
+        for it in range(NBP):
             e('buffer_load_dwordx4 v%d, s[52:55], s57 offen lds' % (108 + it))
-            if it < 7:
+            if it < NBP - 1:
                 e('s_add_u32 m0, m0, 0x%x' % PIECE_STEP)
                 e('s_nop 0')
         e('s_mov_b32 m0, s59')
@@ -88,7 +133,7 @@ def gen(mfma, split=False):
             if it < 7:
                 e('s_add_u32 m0, m0, 0x%x' % PIECE_STEP)
                 e('s_nop 0')
-    tile_dma(True)
+    tile_dma()
     # tile 1 -> stage 1 (a zero-record descriptor when there is no tile 1: nothing moves, the vmcnt bookkeeping stays uniform)
     e('v_readfirstlane_b32 s56, v96')
     e('v_readfirstlane_b32 s57, v97')
@@ -99,103 +144,83 @@ def gen(mfma, split=False):
     e('s_xor_b32 s60, s60, s63')
     e('s_mov_b32 m0, s60')
     e('s_nop 4')
-    tile_dma(False)
+    tile_dma()
     e('s_xor_b32 s59, s59, s62')
     e('s_xor_b32 s60, s60, s63')
     e('s_mov_b32 s58, 2')
     e('s_mov_b32 s61, s42')
     # the accumulators are cleared while the first two tiles are on their way (1 k cycles of v_accvgpr_write)
-    for r in range(256):
+    for r in range(NACC):
         e('v_accvgpr_write_b32 a%d, 0' % r)
-    e('s_waitcnt vmcnt(16)')
+    e('s_waitcnt vmcnt(%d)' % (8 + NBP))
     e('s_barrier')
-    for j in range(8):
+    for j in range(NB):
         e('ds_read_b128 %s, v90 offset:%d' % (vr(FB[0][j]), j * FRAG_STEP))
     for i in range(7 if split else 8):          # split precision: the last hi fragment of A is read inside the step (see below)
         e('ds_read_b128 %s, v88 offset:%d' % (vr(FA[0][i]), i * FRAG_STEP))
     e('s_waitcnt lgkmcnt(0)')
     # ---- the K step
-    NM = 192 if split else 128
     ev = {m: [] for m in range(NM)}             # instructions issued right after MFMA m
 
     def at(m, s):
         ev[m].append(s)
     # B second fragment set (k-half 1 / lo plane) + the table entry of tile t+2
-    for j in range(8):
-        at(2 * j, 'ds_read_b128 %s, v91 offset:%d' % (vr(FB[1][j]), j * FRAG_STEP))
+    for j in range(NB):
+        at(sc['b1_rd'][j], 'ds_read_b128 %s, v91 offset:%d' % (vr(FB[1][j]), j * FRAG_STEP))
     at(1, 'ds_read_b64 v[86:87], v84')
     at(3, 'v_add_u32 v84, 8, v84')
     if split:
         at(3, 'ds_read_b128 %s, v88 offset:%d' % (vr(FA[0][7]), 7 * FRAG_STEP))
-    at(5, 's_cmp_lt_u32 s58, s42')
-    at(5, 's_cselect_b32 s50, s40, 0')
-    at(7, 's_cselect_b32 s54, s41, 0')
-    at(7, 's_add_u32 s58, s58, 1')
-    if 'endwait' in OPTS and not split:
-        at(7, 's_waitcnt lgkmcnt(11)')           # 7 reads of the previous step + 5 of this one issued: the oldest (row tile 1's A) is back
-        at(10, 's_waitcnt lgkmcnt(5)')
-    else:
-        at(10, 's_waitcnt lgkmcnt(%d)' % (6 if split else 5))      # the table entry is back (LDS operations return in order)
-    at(10, 'v_readfirstlane_b32 s56, v86')
-    at(10, 'v_readfirstlane_b32 s57, v87')
-    at(19, 's_mov_b32 m0, s60')
-    at(20, 's_waitcnt lgkmcnt(0)')
-    at(21, 's_barrier')
-    bpos = [22, 25, 28, 31, 34, 52, 55, 58]
-    for it, m in enumerate(bpos):
+    v0, v1 = sc['valid']
+    at(v0, 's_cmp_lt_u32 s58, s42')
+    at(v0, 's_cselect_b32 s50, s40, 0')
+    at(v1, 's_cselect_b32 s54, s41, 0')
+    at(v1, 's_add_u32 s58, s58, 1')
+    if 'extra_wait' in sc:
+        at(sc['extra_wait'][0], 's_waitcnt lgkmcnt(%d)' % sc['extra_wait'][1])
+    at(sc['tab_wait'][0], 's_waitcnt lgkmcnt(%d)' % sc['tab_wait'][1])      # the table entry is back (LDS operations return in order)
+    at(sc['tab_wait'][0], 'v_readfirstlane_b32 s56, v86')
+    at(sc['tab_wait'][0], 'v_readfirstlane_b32 s57, v87')
+    at(sc['m0b'], 's_mov_b32 m0, s60')
+    at(sc['w1'], 's_waitcnt lgkmcnt(0)')
+    at(sc['w1'] + 1, 's_barrier')
+    for it, m in enumerate(sc['bdma']):
         at(m, 'buffer_load_dwordx4 v%d, s[52:55], s57 offen lds' % (108 + it))
-        at(m + 1, 's_add_u32 m0, m0, 0x%x' % PIECE_STEP if it < 7 else 's_mov_b32 m0, s59')
-    apos_rd = [24, 27, 30, 33, 36, 38, 40, 42]
-    for i, m in enumerate(apos_rd):
+        at(m + 1, 's_add_u32 m0, m0, 0x%x' % PIECE_STEP if it < NBP - 1 else 's_mov_b32 m0, s59')
+    for i, m in enumerate(sc['a1_rd']):
         at(m, 'ds_read_b128 %s, v89 offset:%d' % (vr(FA[1][i]), i * FRAG_STEP))
-    at(50, 's_waitcnt lgkmcnt(0)')
-    at(51, 's_barrier')
-    if not split:
-        apos = [61, 64, 85, 87, 89, 96, 100, 124]
-        if 'earlyA' in OPTS:
-            apos = [61, 64, 67, 70, 73, 76, 79, 82]
-        t_xor, t_wait = 83, 91
-        bpos_rd = [93, 94, 95, 97, 98, 102, 103, 104]
-        apos_rd0 = [105, 106, 109, 112, 114, 117, 120, 123]
-        end_wait = 's_waitcnt lgkmcnt(0)'
-        if 'endwait' in OPTS:
-            # only the first A fragment of the next step is needed by its first 8 MFMAs: the other seven reads may still be in flight at
-            # the branch; MFMA 8 (row tile 1) is covered by a counted wait in front of it, the rest by the step's own waits
-            end_wait = 's_waitcnt lgkmcnt(7)'
-    else:
-        # Three products per 16 x 16 x 32 block, in the order of the eight-wave loop (bit-identical sums): MFMA 0..63 hi * hi,
-        # 64..127 lo(A) * hi(B), 128..191 hi(A) * lo(B).  hi(B) is dead after 127 and hi(A) of row tile i after 128 + 8 i + 7: the next
-        # tile's hi fragments go straight into those registers (the last one, row tile 7, at the start of the next step).
-        apos = [61, 64, 67, 70, 73, 76, 79, 82]
-        t_xor, t_wait = 120, 123
-        bpos_rd = [128, 130, 132, 134, 136, 138, 140, 142]
-        apos_rd0 = [137, 145, 153, 161, 169, 177, 185]
-        end_wait = 's_waitcnt lgkmcnt(1)'           # everything but the newest read (hi(A) of row tile 6, needed at MFMA 48)
-    for it, m in enumerate(apos):
+    at(sc['w2'], 's_waitcnt lgkmcnt(0)')
+    at(sc['w2'] + 1, 's_barrier')
+    for it, m in enumerate(sc['adma']):
         at(m, 'buffer_load_dwordx4 v%d, s[48:51], s56 offen lds' % (100 + it))
         if it < 7:
             at(m + 1, 's_add_u32 m0, m0, 0x%x' % PIECE_STEP)
     for k in range(4):
-        at(t_xor, 'v_xor_b32 v%d, v%d, v%d' % (88 + k, 92 + k, 88 + k))
-    n_before = sum(1 for m in range(t_wait) for s_ in ev[m] if s_.startswith('buffer_load'))
-    at(t_wait, 's_waitcnt vmcnt(%d)' % n_before)
-    at(t_wait + 1, 's_barrier')
-    for j, m in enumerate(bpos_rd):
+        at(sc['xor'], 'v_xor_b32 v%d, v%d, v%d' % (88 + k, 92 + k, 88 + k))
+    n_before = sum(1 for m in range(sc['vm']) for s_ in ev[m] if s_.startswith('buffer_load'))
+    at(sc['vm'], 's_waitcnt vmcnt(%d)' % n_before)
+    at(sc['vm'] + 1, 's_barrier')
+    for j, m in enumerate(sc['b0_rd']):
         at(m, 'ds_read_b128 %s, v90 offset:%d' % (vr(FB[0][j]), j * FRAG_STEP))
-    for i, m in enumerate(apos_rd0):
+    for i, m in enumerate(sc['a0_rd']):
         at(m, 'ds_read_b128 %s, v88 offset:%d' % (vr(FA[0][i]), i * FRAG_STEP))
     at(NM - 3, 's_xor_b32 s59, s59, s62')
     at(NM - 3, 's_xor_b32 s60, s60, s63')
     at(NM - 2, 's_sub_u32 s61, s61, 1')
     at(NM - 2, 's_cmp_eq_u32 s61, 0')
-    at(NM - 2, end_wait)
+    at(NM - 2, sc['end_wait'])
     n_dma = sum(1 for m in ev for s_ in ev[m] if s_.startswith('buffer_load'))
-    assert n_dma == 16
-    assert n_before in (13, 16), n_before
+    assert n_dma == 8 + NBP
+    assert n_before in (13, 8 + NBP), n_before
+    # every LDS-DMA instruction has at least one instruction between it and the M0 write in front of it
+    flat = [s_ for m in range(NM) for s_ in (['MFMA'] + ev[m])]
+    for k, s_ in enumerate(flat):
+        assert not (s_.startswith('buffer_load') and 'm0' in flat[k - 1]), (k, flat[k - 1], s_)
     e('.Lk4w_loop_%=:')
+    per = 8 * NB
     for m in range(NM):
-        ph, i, j = m // 64, (m % 64) // 8, m % 8
-        acc = 4 * (8 * i + j)
+        ph, i, j = m // per, (m % per) // NB, m % NB
+        acc = 4 * (NB * i + j)
         if split:
             a, b = (FA[0][i], FB[0][j]) if ph == 0 else ((FA[1][i], FB[0][j]) if ph == 1 else (FA[0][i], FB[1][j]))
         else:
@@ -207,7 +232,7 @@ def gen(mfma, split=False):
     e('s_waitcnt vmcnt(0)')
     e('s_branch .Lk4w_end_%=')
     e('.Lk4w_zero_%=:')                          # no K steps (an empty split-K slice): zeros
-    for r in range(256):
+    for r in range(NACC):
         e('v_accvgpr_write_b32 a%d, 0' % r)
     e('.Lk4w_end_%=:')
     e('s_nop 15')
@@ -220,13 +245,14 @@ def main():
     with open(out, 'w') as f:
         f.write('// GENERATED by tools/gen_kloop4w.py - do not edit.  The K loop of the 256 x 256 tile on four waves as inline assembly;\n')
         f.write('// interface, schedule and rationale: the generator\'s docstring.\n')
-        for name, mfma, split in (('BF16', 'v_mfma_f32_16x16x32_bf16', False), ('F16', 'v_mfma_f32_16x16x32_f16', False),
-                                  ('F16X3', 'v_mfma_f32_16x16x32_f16', True)):
-            f.write('#define RON_KLOOP4W_%s \\\n' % name)
-            lines = gen(mfma, split)
-            for k, s in enumerate(lines):
-                f.write('  "%s\\n"%s\n' % (s, ' \\' if k + 1 < len(lines) else ''))
-            f.write('\n')
+        for NB, tag in ((8, ''), (4, 'N128_')):
+            for name, mfma, split in (('BF16', 'v_mfma_f32_16x16x32_bf16', False), ('F16', 'v_mfma_f32_16x16x32_f16', False),
+                                      ('F16X3', 'v_mfma_f32_16x16x32_f16', True)):
+                f.write('#define RON_KLOOP4W_%s%s \\\n' % (tag, name))
+                lines = gen(mfma, split, NB)
+                for k, s in enumerate(lines):
+                    f.write('  "%s\\n"%s\n' % (s, ' \\' if k + 1 < len(lines) else ''))
+                f.write('\n')
         # accumulator read-out, one output row of the lane at a time (AccAgpr4w::row in conv_mfma.hip): case i * 4 + e
         f.write('#define RON_ACC4W_CASES \\\n')
         for i in range(8):
@@ -236,6 +262,17 @@ def main():
                 last = (i == 7 and e_ == 3)
                 f.write('  case %d: asm volatile("%s" : %s : "{a[%d:%d]}"(c%d)); break;%s\n' %
                         (i * 4 + e_, txt, outs, 32 * i, 32 * i + 31, i, '' if last else ' \\'))
+        f.write('\n')
+        # the 256 x 128 tile: block (i, j), j < 4, in a[4 * (4 * i + j) : +3]; two row tiles per 32-register tuple
+        f.write('#define RON_ACC4W_N128_CASES \\\n')
+        for i in range(8):
+            for e_ in range(4):
+                txt = ''.join('v_accvgpr_read_b32 %%%d, a%d\\n' % (j, 16 * i + 4 * j + e_) for j in range(4))
+                outs = ', '.join('"=v"(v[%d])' % j for j in range(4))
+                last = (i == 7 and e_ == 3)
+                t = i // 2
+                f.write('  case %d: asm volatile("%s" : %s : "{a[%d:%d]}"(c%d)); break;%s\n' %
+                        (i * 4 + e_, txt, outs, 32 * t, 32 * t + 31, t, '' if last else ' \\'))
         f.write('\n')
         clob = ['"s%d"' % r for r in range(48, 65)] + ['"v%d"' % r for r in list(range(84, 100)) + list(range(121, 256))]
         f.write('#define RON_KLOOP4W_CLOBBERS "memory", "scc", %s\n' % ', '.join(clob))

@@ -62,6 +62,11 @@ LAYERS = [
     # Winograd F(2x2, 3x3) upper bound: its 16 transform-domain GEMMs of a 40 x 40 layer at batch 32 are each
     # M = 32 * 20 * 20 tiles, K = Cin, N = Cout; as ONE launch they have the GEMM shape of this 1x1 conv at --batch 128
     # (M = 16 * 12 800 rows), transforms free.  `--batch 128 --only wino_`
+    # SSD-512's extra blocks at batch 16 (`--batch 16`): latency chains, a few tiles each (stride-2 3x3 layers as stride-1 layers of the
+    # same GEMM shape: M = 16 x 16 / 16 x 4 rows)
+    ('ssd_b10_3x3', 4, 4, 128, 256, 3, 1, 1, 0),
+    ('ssd_b11_3x3', 2, 2, 128, 256, 3, 1, 1, 0),
+    ('ssd_b9_3x3', 8, 8, 128, 256, 3, 1, 1, 0),
     ('wino_conv4_2', 40, 40, 512, 512, 1, 1, 1, 0),
     ('wino_b4_trio', 40, 40, 512, 1536, 1, 1, 1, 0),
 ]
