@@ -428,7 +428,7 @@ __device__ void nms_scan(ImageLds& lds, int n, float nms_thr, int mode, int max_
       const int iters_me = (live && b > 0) ? ((b - 1) >> 4) + 1 : 0;   // 16-row slots [0, (b - 1) >> 4] hold the rows in [0, b)
       int iters = max(iters_me, __shfl_xor(iters_me, 16, 64));
       iters = max(iters, __shfl_xor(iters, 32, 64));
-#pragma unroll 2
+      // (no unroll pragma: hipcc refuses to unroll a loop with a run-time trip count around a ballot and says so with a warning)
       for (int it = 0; it < iters; ++it) {
         const int a = (it << 4) + sl;
         const int ac = min(a, kMaxTopK - 1);
@@ -567,7 +567,7 @@ __device__ void nms_scan_classwise(ImageLds& lds, int n, float nms_thr, int num_
       int iters = max(iters_me, __shfl_xor(iters_me, 16, 64));
       iters = max(iters, __shfl_xor(iters, 32, 64));
       // (loads and arithmetic unconditional on a clamped row, validity applied to the result: straight-line code)
-#pragma unroll 2
+      // (no unroll pragma: hipcc refuses to unroll a loop with a run-time trip count around a ballot and says so with a warning)
       for (int it = 0; it < iters; ++it) {
         const int a = ((k0 + it) << 4) + sl;
         const int ac = min(a, kMaxTopK - 1);

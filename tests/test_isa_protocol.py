@@ -21,7 +21,7 @@ import check_dma_counts as cdc  # noqa: E402
 def checked():
     if not os.path.exists('/opt/rocm/bin/hipcc'):
         pytest.skip('hipcc not available')
-    with ThreadPoolExecutor(2) as ex:                       # two hipcc -S runs side by side (~35 s and ~60 s)
+    with ThreadPoolExecutor(3) as ex:                       # three hipcc -S runs side by side (~35 s each)
         return dict(zip(cdc.EXPECTED, ex.map(cdc.check_file, cdc.EXPECTED)))
 
 

@@ -140,6 +140,23 @@ def check_asm4w(name, lines):
     total = sum(1 for l in lines if DMA.search(l))
     if total != pro + n_dma:
         problems.append('%d LDS-DMA instructions outside the assembly loop' % (total - pro - n_dma))
+    # The loop leaves its sums in a[0:255] and declares them clobbered; the epilogue reads them in asm statements of its own.  Between
+    # the loop and the end of the kernel the COMPILER's code must not touch an accumulation register (it would only as spill space).
+    loop_end = next(i for i in range(end, len(lines)) if '#ASMEND' in lines[i])
+    inside, touched, reads = False, [], 0
+    for l in lines[loop_end + 1:]:
+        if '#ASMSTART' in l:
+            inside = True
+        elif '#ASMEND' in l:
+            inside = False
+        elif inside:
+            reads += len(re.findall(r'v_accvgpr_read_b32 v\d+, a\d+', l))
+        elif re.search(r'\bv_accvgpr|\ba\[?\d+[\]:,\s]', l.split(';')[0]):
+            touched.append(l.strip())
+    if touched:
+        problems.append('compiler code touches accumulation registers behind the loop: %s' % touched[:3])
+    if reads == 0:
+        problems.append('no accumulator read-out behind the loop')
     return problems
 
 
@@ -201,12 +218,12 @@ def check_file(source):
 
 # instantiations the Makefile's build holds (dtypes x tile forms); a different count means the check no longer sees all of them
 # (+ the four-wave assembly forms: the 256 x 256 tile and its grouped kernel, the 256 x 128 tile: bf16, f16, f16x3)
-EXPECTED = {'conv_patch.hip': 4 * (3 + 3), 'conv_mfma.hip': 4 * (4 + 3 + 1) + 3 * 2 + 3}
+EXPECTED = {'conv_patch.hip': 4 * (3 + 3), 'conv_mfma.hip': 4 * (4 + 3 + 1), 'conv_mfma4w.hip': 3 * 2 + 3}
 
 
 def main():
     bad = 0
-    for source in ('conv_patch.hip', 'conv_mfma.hip'):
+    for source in ('conv_patch.hip', 'conv_mfma.hip', 'conv_mfma4w.hip'):
         res = check_file(source)
         for desc, problems in res:
             print('%s: %s' % (desc, 'ok' if not problems else '; '.join(problems)))

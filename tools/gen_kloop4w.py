@@ -22,7 +22,8 @@ Interface (physical registers; conv_mfma.hip, conv_igemm_tile, binds them):
        v[100:107] / v[108:115] per-lane source byte offsets of the wave's 8 A / 8 B pieces, v116 / v117 LDS byte address the lane's
        first A fragment is read from in stage 0 for k-half 0 / 1, v118 / v119 the same for B, v120 LDS byte address of the step
        table: entry q = {soffset of the A pieces, soffset of the B pieces} of K step q, steps + 2 entries
-  out: a[0:255] accumulators, block (i, j) of the wave's 8 x 8 grid of 16 x 16 tiles in a[4 * (8 * i + j) : +3]
+  out: a[0:255] accumulators (declared as clobbers: see main()), block (i, j) of the wave's 8 x 8 grid of 16 x 16 tiles in
+       a[4 * (8 * i + j) : +3] (256 x 128 tile: a[4 * (4 * i + j) : +3])
   clobbers: s[48:64], v[84:99], v[121:255], scc, M0
 """
 import os
@@ -260,8 +261,7 @@ def main():
                 txt = ''.join('v_accvgpr_read_b32 %%%d, a%d\\n' % (j, 32 * i + 4 * j + e_) for j in range(8))
                 outs = ', '.join('"=v"(v[%d])' % j for j in range(8))
                 last = (i == 7 and e_ == 3)
-                f.write('  case %d: asm volatile("%s" : %s : "{a[%d:%d]}"(c%d)); break;%s\n' %
-                        (i * 4 + e_, txt, outs, 32 * i, 32 * i + 31, i, '' if last else ' \\'))
+                f.write('  case %d: asm volatile("%s" : %s); break;%s\n' % (i * 4 + e_, txt, outs, '' if last else ' \\'))
         f.write('\n')
         # the 256 x 128 tile: block (i, j), j < 4, in a[4 * (4 * i + j) : +3]; two row tiles per 32-register tuple
         f.write('#define RON_ACC4W_N128_CASES \\\n')
@@ -270,12 +270,15 @@ def main():
                 txt = ''.join('v_accvgpr_read_b32 %%%d, a%d\\n' % (j, 16 * i + 4 * j + e_) for j in range(4))
                 outs = ', '.join('"=v"(v[%d])' % j for j in range(4))
                 last = (i == 7 and e_ == 3)
-                t = i // 2
-                f.write('  case %d: asm volatile("%s" : %s : "{a[%d:%d]}"(c%d)); break;%s\n' %
-                        (i * 4 + e_, txt, outs, 32 * t, 32 * t + 31, t, '' if last else ' \\'))
+                f.write('  case %d: asm volatile("%s" : %s); break;%s\n' % (i * 4 + e_, txt, outs, '' if last else ' \\'))
         f.write('\n')
+        # the accumulators are clobbers, not outputs: as eight 1024-bit physical-register outputs that stay live through the epilogue's
+        # few hundred basic blocks they cost hipcc 14 s of "Live Variable Analysis" per kernel (9 kernels); the epilogue reads them with
+        # v_accvgpr_read in asm statements of its own, and tools/check_dma_counts.py verifies in the ISA that the compiler itself
+        # touches no accumulation register between the loop and the last of those reads
         clob = ['"s%d"' % r for r in range(48, 65)] + ['"v%d"' % r for r in list(range(84, 100)) + list(range(121, 256))]
-        f.write('#define RON_KLOOP4W_CLOBBERS "memory", "scc", %s\n' % ', '.join(clob))
+        clob_a = ['"a%d"' % r for r in range(256)]
+        f.write('#define RON_KLOOP4W_CLOBBERS "memory", "scc", %s, %s\n' % (', '.join(clob), ', '.join(clob_a)))
     print('wrote', out)
 
 
