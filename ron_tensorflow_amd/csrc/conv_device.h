@@ -390,76 +390,6 @@ __device__ __forceinline__ void conv_epilogue_pool_rows(const ConvArgs& p, const
   }
 }
 
-// Run-time-switch form of conv_epilogue_rows (full channel vectors, any combination of the switches)
-template <class Tr, int MR, int NR, int MT, int EPA, class Reader>
-__device__ __forceinline__ void conv_epilogue_rows_rt(const ConvArgs& p, const Reader& rd, const int* s_out_off, int row0, int fh,
-                                                      const float (&bias_v)[NR], int n_store, int tap_off) {
-#pragma unroll
-  for (int i = 0; i < MR; ++i) {
-#pragma unroll
-    for (int e = 0; e < EPA; ++e) {
-      float v[NR];
-      rd.row(i, e, v);
-      const int ooff = s_out_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
-      if (ooff < 0) continue;
-      const int o = ooff + tap_off + n_store;
-#pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        v[j] = fmaf(v[j], p.oscale, bias_v[j]);
-        if (p.relu) v[j] = fmaxf(v[j], 0.f);
-      }
-      if (p.res != nullptr) {
-        float rv[NR];
-        Tr::template load_vec<NR>(p.res, o, rv);
-#pragma unroll
-        for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j] + rv[j], 0.f);
-      }
-      if (p.out_f32) store_f32_vec<NR>(reinterpret_cast<float*>(p.out) + o, v);
-      else Tr::template store_vec<NR>(p.out, o, v);
-    }
-  }
-}
-
-template <class Tr, int MR, int NR, int MT, int EPA, class Reader>
-__device__ __forceinline__ void conv_epilogue_pool_rows_rt(const ConvArgs& p, const Reader& rd, const int* s_out_off, const int* s_out2_off,
-                                                           int row0, int fh, const float (&bias_v)[NR], int n_store) {
-  const bool out2 = p.out2 != nullptr && s_out2_off != nullptr;
-#pragma unroll
-  for (int i = 0; i < MR; ++i) {
-#pragma unroll
-    for (int t = 0; t < EPA / 4; ++t) {
-      float w[4][NR];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) rd.row(i, 4 * t + u, w[u]);
-      if (out2) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = 4 * t + u;
-          const int ooff = s_out2_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
-          if (ooff < 0) continue;
-          float v[NR];
-#pragma unroll
-          for (int j = 0; j < NR; ++j) {
-            v[j] = fmaf(w[u][j], p.oscale, bias_v[j]);
-            if (p.relu) v[j] = fmaxf(v[j], 0.f);
-          }
-          Tr::template store_vec<NR>(p.out2, ooff + n_store, v);
-        }
-      }
-      const int ooff = s_out_off[row0 + i * MT + 8 * t + 4 * fh];
-      if (ooff < 0) continue;
-      float v[NR];
-#pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        const float mx = fmaxf(fmaxf(w[0][j], w[1][j]), fmaxf(w[2][j], w[3][j]));
-        v[j] = fmaf(mx, p.oscale, bias_v[j]);
-        if (p.relu) v[j] = fmaxf(v[j], 0.f);
-      }
-      Tr::template store_vec<NR>(p.out, ooff + n_store, v);
-    }
-  }
-}
-
 template <class Tr, int MR, int NR, int MT, int EPA, class Reader>
 __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader& rd, const int* s_out_off, int row0,
                                                 int fh, int n_glob, int n_store, int tap_off, const int* s_out2_off = nullptr) {
@@ -468,32 +398,32 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
   for (int j = 0; j < NR; ++j) bias_v[j] = p.bias[n_glob + j];
   const int n_valid = p.Cout - n_glob;                 // channels of this lane's group that exist (may be <= 0)
   if (n_valid <= 0) return;
-  if (n_valid >= NR) {
-    // every channel of the lane's vector exists (all lanes but the last column tile's tail)
-    if (p.pool) {
-      const bool out2 = p.out2 != nullptr && s_out2_off != nullptr;
-      if (Reader::kSpecialise && p.relu) {          // (the graph pools behind ReLU layers only)
-        if (out2) conv_epilogue_pool_rows<Tr, MR, NR, MT, EPA, true, true>(p, rd, s_out_off, s_out2_off, row0, fh, bias_v, n_store);
-        else conv_epilogue_pool_rows<Tr, MR, NR, MT, EPA, true, false>(p, rd, s_out_off, s_out2_off, row0, fh, bias_v, n_store);
+  if constexpr (Reader::kSpecialise) {
+    if (n_valid >= NR) {
+      // every channel of the lane's vector exists (all lanes but the last column tile's tail): the combinations the graphs launch -
+      // ReLU layers (1), head logits in fp32 (4), the reverse connection's relu(x + residual) (3), plain (0), pooled ReLU layers -
+      // as straight-line row loops; anything else through the run-time form below
+      if (p.pool) {
+        if (p.relu) {
+          if (p.out2 != nullptr && s_out2_off != nullptr)
+            conv_epilogue_pool_rows<Tr, MR, NR, MT, EPA, true, true>(p, rd, s_out_off, s_out2_off, row0, fh, bias_v, n_store);
+          else
+            conv_epilogue_pool_rows<Tr, MR, NR, MT, EPA, true, false>(p, rd, s_out_off, s_out2_off, row0, fh, bias_v, n_store);
+          return;
+        }
       } else {
-        conv_epilogue_pool_rows_rt<Tr, MR, NR, MT, EPA>(p, rd, s_out_off, s_out2_off, row0, fh, bias_v, n_store);
-      }
-      return;
-    }
-    // the combinations the graphs launch: ReLU layers (1), head logits in fp32 (4), the reverse connection's relu(x + residual) (3),
-    // plain (0); anything else through the run-time form
-    const int sw = Reader::kSpecialise ? ((p.relu ? 1 : 0) | (p.res != nullptr ? 2 : 0) | (p.out_f32 ? 4 : 0)) : -1;
+        const int sw = (p.relu ? 1 : 0) | (p.res != nullptr ? 2 : 0) | (p.out_f32 ? 4 : 0);
 #define RON_EPI_CASE(k_) \
-    case k_: conv_epilogue_rows<Tr, MR, NR, MT, EPA, ((k_) & 1) != 0, ((k_) & 2) != 0, ((k_) & 4) != 0>(p, rd, s_out_off, row0, fh, bias_v, n_store, tap_off); break;
-    switch (sw) {
-      RON_EPI_CASE(0) RON_EPI_CASE(1) RON_EPI_CASE(3) RON_EPI_CASE(4)
-      default: conv_epilogue_rows_rt<Tr, MR, NR, MT, EPA>(p, rd, s_out_off, row0, fh, bias_v, n_store, tap_off); break;
-    }
+        case k_: conv_epilogue_rows<Tr, MR, NR, MT, EPA, ((k_) & 1) != 0, ((k_) & 2) != 0, ((k_) & 4) != 0>(p, rd, s_out_off, row0, fh, bias_v, n_store, tap_off); return;
+        switch (sw) { RON_EPI_CASE(0) RON_EPI_CASE(1) RON_EPI_CASE(3) RON_EPI_CASE(4) default: break; }
 #undef RON_EPI_CASE
-    return;
+      }
+    }
   }
-  // lanes of a partial channel vector: element by element
+  // The run-time form (every combination of the switches, full and partial channel vectors): what the register-array tiles run -
+  // two waves per SIMD hide its per-row LDS round trips, and one copy of the row loop keeps those kernels small (45 instantiations)
   if (p.pool) {
+    const bool out2 = p.out2 != nullptr && s_out2_off != nullptr;
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
 #pragma unroll
@@ -501,32 +431,44 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
         float w[4][NR];
 #pragma unroll
         for (int u = 0; u < 4; ++u) rd.row(i, 4 * t + u, w[u]);
-        if (p.out2 != nullptr && s_out2_off != nullptr) {
+        if (out2) {
+          // the un-pooled map as well (s_out2_off[row] = element offset of the row's pixel in out2, channel slice included)
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int e = 4 * t + u;
             const int ooff = s_out2_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
             if (ooff < 0) continue;
+            float v[NR];
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
-              if (j < n_valid) {                 // (no run-time `break` in a loop that is to be unrolled: hipcc then refuses)
-                float x = fmaf(w[u][j], p.oscale, bias_v[j]);
-                if (p.relu) x = fmaxf(x, 0.f);
-                Tr::store(p.out2, ooff + n_store + j, x);
-              }
+              v[j] = fmaf(w[u][j], p.oscale, bias_v[j]);
+              if (p.relu) v[j] = fmaxf(v[j], 0.f);
+            }
+            const int o = ooff + n_store;
+            if (n_valid >= NR) {
+              Tr::template store_vec<NR>(p.out2, o, v);
+            } else {
+#pragma unroll
+              for (int j = 0; j < NR; ++j) if (j < n_valid) Tr::store(p.out2, o + j, v[j]);
             }
           }
         }
+        // max over the 2x2 window = max over registers 4t..4t+3; relu(max(x) + b) == max(relu(x + b))
         const int ooff = s_out_off[row0 + i * MT + 8 * t + 4 * fh];
         if (ooff < 0) continue;
+        float v[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-          if (j < n_valid) {
-            const float mx = fmaxf(fmaxf(w[0][j], w[1][j]), fmaxf(w[2][j], w[3][j]));
-            float x = fmaf(mx, p.oscale, bias_v[j]);
-            if (p.relu) x = fmaxf(x, 0.f);
-            Tr::store(p.out, ooff + n_store + j, x);
-          }
+          const float mx = fmaxf(fmaxf(w[0][j], w[1][j]), fmaxf(w[2][j], w[3][j]));
+          v[j] = fmaf(mx, p.oscale, bias_v[j]);
+          if (p.relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        const int o = ooff + n_store;
+        if (n_valid >= NR) {
+          Tr::template store_vec<NR>(p.out, o, v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NR; ++j) if (j < n_valid) Tr::store(p.out, o + j, v[j]);
         }
       }
     }
@@ -536,19 +478,34 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
   for (int i = 0; i < MR; ++i) {
 #pragma unroll
     for (int e = 0; e < EPA; ++e) {
-      float v[NR];
-      rd.row(i, e, v);
       const int ooff = s_out_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
       if (ooff < 0) continue;
       const int o = ooff + tap_off + n_store;
+      float v[NR];
+      rd.row(i, e, v);
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        if (j < n_valid) {
-          float x = fmaf(v[j], p.oscale, bias_v[j]);
-          if (p.relu) x = fmaxf(x, 0.f);
-          if (p.res != nullptr) x = fmaxf(x + Tr::load(p.res, o + j), 0.f);
-          if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = x;
-          else Tr::store(p.out, o + j, x);
+        v[j] = fmaf(v[j], p.oscale, bias_v[j]);
+        if (p.relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (n_valid >= NR) {
+        if (p.res != nullptr) {
+          float rv[NR];
+          Tr::template load_vec<NR>(p.res, o, rv);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j] + rv[j], 0.f);
+        }
+        if (p.out_f32) store_f32_vec<NR>(reinterpret_cast<float*>(p.out) + o, v);
+        else Tr::template store_vec<NR>(p.out, o, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          if (j < n_valid) {                 // (no run-time `break` in a loop that is to be unrolled: hipcc then refuses)
+            float x = v[j];
+            if (p.res != nullptr) x = fmaxf(x + Tr::load(p.res, o + j), 0.f);
+            if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = x;
+            else Tr::store(p.out, o + j, x);
+          }
         }
       }
     }

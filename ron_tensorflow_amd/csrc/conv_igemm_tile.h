@@ -144,7 +144,9 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   const unsigned tiles_m = (unsigned)p.tiles_total / (unsigned)p.tiles_n;
   int tile_n = (int)(p.m_fastest ? tile / tiles_m : tile % (unsigned)p.tiles_n);
   int tile_m = (int)(p.m_fastest ? tile % tiles_m : tile / (unsigned)p.tiles_n);
-  if (p.m_fastest == 2) {
+  if constexpr (kAsmLoop) if (p.m_fastest == 2) {
+    // (four-wave tiles only - the launches wide and tall enough are theirs; compiled into every tile the two divisions cost the
+    // small-batch launches 1-2 us each through the other tiles' register allocation: batch 4 1.24 -> 1.29 ms, measured round 5)
     // panels of kPanelCols column tiles, walked row by row: the 32 tiles an XCD runs at a time are 4 rows x 8 columns (12 operand
     // streams instead of 1 + 32 on a wide launch)
     const unsigned per_panel = tiles_m * kPanelCols, panel = tile / per_panel, r = tile - panel * per_panel;

@@ -117,7 +117,7 @@ int conv_pick_igemm_cfg(int M, int Npad, int taps, int K, bool may_split) {
 // 16 column tiles of 12.8 MB of weights each - N fastest makes every XCD stream all 205 MB: 1.66 GB fetched per launch, 0.65 GB
 // M fastest, 566 -> 541 us; fc7 113 -> 102 us).  Forced on every launch it costs the activation-heavy layers 2-4 %; walking the
 // column tiles of an XCD's rows in blocks of 1-3 instead changed nothing (both measured, not kept).
-static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int tiles_n, int splitk) {
+static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int tiles_n, int splitk, int panel_steps) {
   // split-K: the workgroups of one K slice are consecutive, an XCD's run then covers (nearly) every tile of its slices either way
   if (tiles_m < 2 || tiles_n < 2 || splitk > 1) return 0;
   const double esz = (double)dtype_size(c.dtype);
@@ -128,7 +128,11 @@ static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int 
   const double cost_n = (per_xcd / tiles_n + 1) * a_tile + std::min(tiles_n, per_xcd) * b_tile;
   const double cost_m = std::min(tiles_m, per_xcd) * a_tile + (per_xcd / tiles_m + 1) * b_tile;
   // 2: panels of kPanelCols column tiles (wide AND tall launches: plain GEMM shapes, fc7 at large batches)
-  if (tiles_n >= 2 * kPanelCols && tiles_m >= 8 && c.center_from == 0) {
+  // (not the transposed conv: its pixel-shuffle epilogue wants the four taps of a pixel block written close in time - measured at
+  // batch 4: the groups that carry block4 / block5_deconv_right 8-10 us slower in panel order)
+  // Only the four-wave tiles decode it (conv_igemm_tile): `panel_steps` = the K steps of a workgroup when the launch may go to
+  // them, 0 when it may not (members of a grouped launch).
+  if (BM == 256 && c.dtype != RON_DTYPE_F32 && panel_steps > 0 && asm_loop_ok(panel_steps) && tiles_n >= 2 * kPanelCols && tiles_m >= 8 && c.center_from == 0 && c.up == 0) {
     const double cost_p = std::min(tiles_m, per_xcd / kPanelCols + 1) * a_tile +
                           std::min(tiles_n, kPanelCols * (per_xcd / (tiles_m * kPanelCols) + 1)) * b_tile;
     if (cost_p < 0.9 * std::min(cost_n, cost_m)) return 2;
@@ -229,7 +233,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
     a.partial = (float*)c.scratch;
     if (a.splitk == 1) { a.kt_split = a.KT; a.partial = nullptr; }
   }
-  a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
+  a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk, a.KT);
   a.pos_major = pick_pos_major(c, cfg, BM);
   a.taps_inner = conv_cfg_taps_inner(cfg) ? 1 : 0;
   // the 256 x 128 tile: taps innermost by the rule of the other tiles (stride-1 filters that neither split K nor skip filter rows)
@@ -490,7 +494,7 @@ int launch_conv_group(const ConvLaunch* ls_in, int n, int cfg, void* scratch, in
       if (a.splitk == 1) { a.kt_split = a.KT; a.partial = nullptr; }
       else { used += need; any_split = true; }
     }
-    a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk);
+    a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk, 0);
     a.pos_major = pick_pos_major(c, mcfg, BM);
     // K order of the member, by the rules of a launch of its own (conv_pick_cfg): taps innermost for stride-1 filters that neither
     // split K nor skip filter rows - on the 256 x 256 tile where the long columns are at most two tiles wide, on 128 x 128 always
