@@ -57,6 +57,12 @@ struct ConvArgs {
   // un-pooled output view, written from the same accumulators; nullptr = pooled map only
   void* out2;
   int out2_Hp, out2_Wp, out2_cstride, out2_pad, out2_coff;
+  // Two fp32 head outputs from ONE convolution over a shared input (the loc and cls convolutions of an SSD feature layer,
+  // nets/ssd_vgg_300.py:403-431, packed side by side): columns [0, split_first) are channels of `out`, columns [split_n, Cout) are
+  // channels [0, Cout - split_n) of `out2` (split_n = split_first rounded up to 8, the columns between are padding).  Both views
+  // are un-haloed [n][Ho][Wo][C] tensors, so a row's offset in `out2` is its offset in `out` / out_cstride * out2_cstride.
+  // 0: one output.
+  int split_n, split_first;
   // tile order inside an XCD's run of workgroups: 0 = N fastest (the column tiles that re-read one activation tile share an L2),
   // 1 = M fastest (the row tiles that re-read one weight slice do: fc6's 205 MB of weights are then fetched once, not once per XCD),
   // 2 = panels of 8 column tiles walked row by row (launches that are both wide and tall)
@@ -396,10 +402,12 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
   float bias_v[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) bias_v[j] = p.bias[n_glob + j];
-  const int n_valid = p.Cout - n_glob;                 // channels of this lane's group that exist (may be <= 0)
+  // (ConvArgs::split_n: the lane's channels belong to the first output, or - from split_n on - to the second)
+  const bool second = p.split_n > 0 && n_glob >= p.split_n;
+  const int n_valid = (p.split_n > 0 && !second ? p.split_first : p.Cout) - n_glob;   // channels of this lane's group that exist (may be <= 0)
   if (n_valid <= 0) return;
   if constexpr (Reader::kSpecialise) {
-    if (n_valid >= NR) {
+    if (n_valid >= NR && p.split_n == 0) {
       // every channel of the lane's vector exists (all lanes but the last column tile's tail): the combinations the graphs launch -
       // ReLU layers (1), head logits in fp32 (4), the reverse connection's relu(x + residual) (3), plain (0), pooled ReLU layers -
       // as straight-line row loops; anything else through the run-time form below
@@ -480,7 +488,8 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
     for (int e = 0; e < EPA; ++e) {
       const int ooff = s_out_off[row0 + i * MT + (e & 3) + 8 * (e >> 2) + 4 * fh];
       if (ooff < 0) continue;
-      const int o = ooff + tap_off + n_store;
+      int o = ooff + tap_off + n_store;
+      if (second) o = (int)((unsigned)ooff / (unsigned)p.out_cstride) * p.out2_cstride + n_store - p.split_n;
       float v[NR];
       rd.row(i, e, v);
 #pragma unroll
@@ -495,7 +504,7 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
 #pragma unroll
           for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j] + rv[j], 0.f);
         }
-        if (p.out_f32) store_f32_vec<NR>(reinterpret_cast<float*>(p.out) + o, v);
+        if (p.out_f32) store_f32_vec<NR>(reinterpret_cast<float*>(second ? p.out2 : p.out) + o, v);
         else Tr::template store_vec<NR>(p.out, o, v);
       } else {
 #pragma unroll
@@ -503,7 +512,7 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
           if (j < n_valid) {                 // (no run-time `break` in a loop that is to be unrolled: hipcc then refuses)
             float x = v[j];
             if (p.res != nullptr) x = fmaxf(x + Tr::load(p.res, o + j), 0.f);
-            if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = x;
+            if (p.out_f32) reinterpret_cast<float*>(second ? p.out2 : p.out)[o + j] = x;
             else Tr::store(p.out, o + j, x);
           }
         }
@@ -539,6 +548,7 @@ inline void fill_conv_args(const ConvLaunch& c, ConvArgs* out) {
   a.Npad = c.Npad;
   a.splitk = 1; a.kt_split = a.KT; a.partial = nullptr;
   a.pool = c.pool;
+  a.split_n = c.split_n; a.split_first = c.split_first;
   a.out2 = c.out2.base;
   a.out2_Hp = c.out2.Hp(); a.out2_Wp = c.out2.Wp(); a.out2_cstride = c.out2.cstride; a.out2_pad = c.out2.pad; a.out2_coff = c.out2.coff;
   a.m_fastest = 0;

@@ -612,14 +612,20 @@ __device__ __forceinline__ void splitk_finalize_body(const ConvArgs& p) {
       oy = rem / p.Wo;
       ox = rem - oy * p.Wo;
     }
-    const int o = ((img * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cstride + p.out_coff + n;
+    int o = ((img * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cstride + p.out_coff + n;
+    int n_end = p.Cout;
+    void* dst = p.out;
+    if (p.split_n > 0) {                       // two fp32 outputs (ConvArgs::split_n)
+      if (n >= p.split_n) { o = ((img * p.out2_Hp + oy) * p.out2_Wp + ox) * p.out2_cstride + n - p.split_n; dst = p.out2; }
+      else n_end = p.split_first;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (n + j >= p.Cout) break;
+      if (n + j >= n_end) break;
       float v = fmaf(sum[j], p.oscale, p.bias[n + j]);
       if (p.relu) v = fmaxf(v, 0.f);
       if (p.res != nullptr) v = fmaxf(v + Tr::load(p.res, o + j), 0.f);
-      if (p.out_f32) reinterpret_cast<float*>(p.out)[o + j] = v;
+      if (p.out_f32) reinterpret_cast<float*>(dst)[o + j] = v;
       else Tr::store(p.out, o + j, v);
     }
   }

@@ -47,6 +47,9 @@ struct ConvLaunch {
   int Ho = 0, Wo = 0;            // GEMM rows = N*Ho*Wo (input grid for a transposed conv)
   int pool = 0;                  // fuse slim.max_pool2d [2,2] into the epilogue: `out` is the pooled map
   TensorView out2;               // with pool: the un-pooled map too (base == nullptr: none), same dtype, geometry Ho x Wo x Cout
+  // Two fp32 outputs from one convolution (ConvArgs::split_n): packed columns [0, split_first) -> `out`, [split_n, Cout) -> `out2`,
+  // both un-haloed fp32 views (out_f32 = 1).  Row-gather kernel only, a launch of its own, no split-K.  0: one output.
+  int split_n = 0, split_first = 0;
   int center_from = 0;           // > 0: output channels >= center_from have weights in the CENTRE tap only (a 1x1 branch packed beside
                                  // 3x3 ones: nets/ron_vgg_320.py:378-397); their column tiles run that tap's K steps alone
   int halo_skip = 1;             // position-major rows + per-tile skipping of filter rows that only see the halo, where it pays (0: never)

@@ -165,7 +165,7 @@ static int pick_pos_major(const ConvLaunch& c, int cfg, int BM) {
 // The halo-patch kernel (conv_patch.hip) where it applies and wins (conv_patch_pick), else the row-gather kernel.
 int conv_pick_cfg(const ConvLaunch& c) {
   const int M = c.in.N * c.Ho * c.Wo;
-  if (conv_c64_applicable(c)) return kCfgC64Resident;
+  if (c.split_n == 0 && conv_c64_applicable(c)) return kCfgC64Resident;
   if (c.out2.base == nullptr && conv_patch_applicable(c)) {
     const int cfg = conv_patch_pick(c);
     if (cfg >= 0) return cfg;
@@ -221,7 +221,16 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
                 "conv + fused pool: plain stride-1 conv on an even map only");
     RON_REQUIRE(c.out.H == c.Ho / 2 && c.out.W == c.Wo / 2, "conv + fused pool: output view must be the pooled map");
   }
-  if (c.out2.base != nullptr) {
+  if (c.split_n > 0) {
+    RON_REQUIRE(c.out_f32 && !c.pool && c.up == 0 && c.res == nullptr && c.center_from == 0, "conv: two head outputs from a plain fp32-output convolution only");
+    RON_REQUIRE(c.split_n % 8 == 0 && c.split_first > 0 && c.split_first <= c.split_n && c.split_n < c.Cout,
+                "conv: bad output split (first %d, second from %d, %d columns)", c.split_first, c.split_n, c.Cout);
+    RON_REQUIRE(c.out.pad == 0 && c.out.coff == 0 && c.out.cstride == c.out.C && c.out.C == c.split_first && c.out2.base != nullptr &&
+                c.out2.pad == 0 && c.out2.coff == 0 && c.out2.cstride == c.out2.C && c.out2.C == c.Cout - c.split_n &&
+                c.out2.H == c.Ho && c.out2.W == c.Wo && c.out2.N == c.in.N && c.out.H == c.Ho && c.out.W == c.Wo,
+                "conv: the two head outputs must be dense [n][Ho][Wo][C] tensors of %d and %d channels", c.split_first, c.Cout - c.split_n);
+    RON_REQUIRE(c.out2.pixels() * c.out2.cstride < (int64_t)1 << 31, "conv: second output too large for 32-bit offsets");
+  } else if (c.out2.base != nullptr) {
     RON_REQUIRE(c.pool && c.out2.H == c.Ho && c.out2.W == c.Wo && c.out2.C >= c.Cout && c.out2.N == c.in.N,
                 "conv: a second output is the un-pooled map of a fused-pool launch");
     RON_REQUIRE(c.out2.pixels() * c.out2.cstride < (int64_t)1 << 31, "conv: second output too large for 32-bit offsets");
@@ -435,6 +444,7 @@ void conv_group_plan(const ConvLaunch* ls, int n, int cfg, int* sk) {
 
 int launch_conv_group(const ConvLaunch* ls_in, int n, int cfg, void* scratch, int64_t scratch_bytes, hipStream_t stream, const int* sk_plan) {
   RON_REQUIRE(n >= 1 && n <= kMaxGroup, "conv group: %d launches (1..%d)", n, kMaxGroup);
+  for (int k = 0; k < n; ++k) RON_REQUIRE(ls_in[k].split_n == 0, "conv group: a two-output convolution is a launch of its own");
   if (cfg == kCfgPatch64) {
     // the two skinny heads of a scale: one launch of the patch kernel where it is the choice for both (dtype, map, batch),
     // otherwise each as the launch it would be on its own

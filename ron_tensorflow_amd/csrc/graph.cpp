@@ -58,6 +58,7 @@ struct PackedConv {
   float* d_bias = nullptr;
   float oscale = 1.f;         // accumulator scale of the epilogue (split-precision weights are stored times a power of two)
   int Npad = 0, Cout = 0;
+  int split_n = 0, split_first = 0;   // two head convolutions packed side by side (pack_box_pair): ConvLaunch::split_n
 };
 
 enum OpKind { OP_IM2COL, OP_CONV, OP_POOL, OP_STEM, OP_POOL3, OP_L2NORM, OP_STEM2 };
@@ -75,6 +76,7 @@ struct Op {
   int fuse_next_pool = 0;               // the next op is this conv's 2x2 pool and both maps are needed (conv4_3, conv5_3): one launch
                                         // with two outputs whenever the conv would not split K (decided per batch in ron_forward)
   int head_kind = -1, head_layer = -1;  // 0 cls, 1 obj, 2 loc
+  int head_kind2 = -1;                  // a second head output of the same layer from the same launch (pack_box_pair), or -1
   int Ho = 0, Wo = 0;
   int lane = 0;                         // 0 = the caller's stream; 1..3 = side streams (independent head branches)
   int group = -1;                       // >= 0: launched together with the neighbouring ops of the same group (launch_conv_group)
@@ -294,6 +296,25 @@ int pack_plain(ron_ctx* c, const std::string& scope, bool bn) {
   return upload(c, r, cout);
 }
 
+// The class and box convolutions of an SSD feature layer (nets/ssd_vgg_300.py:403-431: both 3x3 over the same map) as ONE
+// convolution: rows [0, A*classes) conv_cls, rows [split_n, split_n + 4A) conv_loc, split_n = A*classes rounded up to 8 (a lane's
+// vector of adjacent channels then never straddles the two outputs).  The input is staged once instead of twice and the box
+// columns ride in what would be padding of the class convolution's last column tile (block4: 84 + 16 -> 104 of 128 columns).
+int pack_box_pair(ron_ctx* c, const std::string& L) {
+  const Var& wc = c->var(L + "/conv_cls/weights");
+  const Var& wl = c->var(L + "/conv_loc/weights");
+  const int n_cls = (int)wc.shape[3], n_loc = (int)wl.shape[3], split_n = round_up(n_cls, 8);
+  Rows r;
+  r.init((int)wc.shape[0], (int)wc.shape[1], (int)wc.shape[2], split_n + n_loc, conv_n_tile(split_n + n_loc));
+  r.place(wc, 0);
+  r.add_bias(c->var(L + "/conv_cls/biases"), 0);
+  r.place(wl, split_n);
+  r.add_bias(c->var(L + "/conv_loc/biases"), split_n);
+  const int idx = upload(c, r, split_n + n_loc);
+  if (idx >= 0) { c->packed[idx].split_n = split_n; c->packed[idx].split_first = n_cls; }
+  return idx;
+}
+
 int pack_stem(ron_ctx* c, const std::string& scope) {
   const Var& w = c->var(scope + "/weights");
   const int cout = (int)w.shape[3], chunk = conv_k_chunk(c->cfg.dtype);
@@ -359,6 +380,9 @@ int pack_inception(ron_ctx* c, const std::string& I) {
 const char* kSsdFeat[7] = {"block4", "block7", "block8", "block9", "block10", "block11", "block12"};
 const int kSsdAnchors[7] = {4, 6, 6, 6, 6, 4, 4};       // len(sizes) + len(ratios), nets/ssd_vgg_512.py:86-99
 const int kSsdFeatC[7] = {512, 1024, 512, 256, 256, 256, 256};
+// Feature layers whose loc + cls convolutions run as one two-output launch (block4: 64 x 64, block7: 32 x 32).  The small maps'
+// heads stay two members of a grouped launch with the next block's 1x1 (plan_groups).
+const int kSsdPairedHeads = 2;
 
 void declare_variables_ssd(ron_ctx* c) {
   const int nc = c->cfg.num_classes;
@@ -466,8 +490,7 @@ void plan_groups(ron_ctx* c) {
       {T64, {"block10_box_conv_loc", "block10_box_conv_cls", "block11_conv1x1"}}, {-1, {"block11_conv3x3"}},
       {T64, {"block11_box_conv_loc", "block11_box_conv_cls", "block12_conv1x1"}}, {-1, {"block12_conv4x4"}},
       {T64, {"block12_box_conv_loc", "block12_box_conv_cls"}},
-      {-1, {"block4_l2norm"}}, {-1, {"block4_box_conv_loc"}}, {-1, {"block4_box_conv_cls"}},
-      {-1, {"block7_box_conv_loc"}}, {-1, {"block7_box_conv_cls"}},
+      {-1, {"block4_l2norm"}}, {-1, {"block4_box_conv_cls_loc"}}, {-1, {"block7_box_conv_cls_loc"}},
   };
   // RON heads.  Dependencies after the round-4 re-formulation of the reverse connection (the LEFT conv of a scale reads a backbone
   // map only; the transposed conv adds its half in place, ron_finalize_weights):
@@ -844,6 +867,15 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
     for (int i = 0; i < 7; ++i) {
       const std::string L = std::string(kSsdFeat[i]) + "_box";
       const int fh = c->feat_h[i], fw = c->feat_w[i];
+      if (i < kSsdPairedHeads) {
+        // the two large maps: loc and cls as one launch with two outputs (pack_box_pair)
+        PACK(pack_box_pair(c, L));
+        Op o = conv_op(L + "_conv_cls_loc", T(feat_src[i]), -2, rc, 3, 1, 0, fh, fw);
+        o.head_kind = 0; o.head_kind2 = 2; o.head_layer = i;
+        c->ops.push_back(o);
+        flops += conv_flops(c->var(L + "/conv_loc/weights"), fh * fw) + conv_flops(c->var(L + "/conv_cls/weights"), fh * fw); ATTR();
+        continue;
+      }
       PACK(pack_plain(c, L + "/conv_loc", false));
       { Op o = conv_op(L + "_conv_loc", T(feat_src[i]), -2, rc, 3, 1, 0, fh, fw); o.head_kind = 2; o.head_layer = i; c->ops.push_back(o); }
       flops += conv_flops(c->var(L + "/conv_loc/weights"), fh * fw); ATTR();
@@ -954,7 +986,7 @@ extern "C" int ron_finalize_weights(ron_ctx* c) {
     const double out_esz = o.out == -2 ? 4.0 : (double)c->esz();
     const int os = o.up > 0 ? o.up * o.up : 1;
     const double out_px = o.pool ? (double)o.Ho * o.Wo / 4 : (double)o.Ho * o.Wo * os;
-    const double out_ch = o.up > 0 ? (double)o.up_cout : (double)pk.Cout;
+    const double out_ch = o.up > 0 ? (double)o.up_cout : (double)(pk.Cout - (pk.split_n - pk.split_first));
     o.act_bytes = (double)ti.H * ti.W * cin * c->esz() + out_px * out_ch * out_esz + (o.res >= 0 ? out_px * out_ch * c->esz() : 0.0);
     o.wgt_bytes = (double)pk.w_bytes;
   }
@@ -985,6 +1017,22 @@ static int describe_conv(const ron_ctx* c, const Op& o, int n, const ron_heads* 
     v.bytes = (int64_t)n * v.H * v.W * v.C * 4;
     L.out = v;
     L.out_f32 = 1;
+    if (o.head_kind2 >= 0) {
+      // second head output of the launch (pack_box_pair): dense like the first
+      float* dst2 = nullptr;
+      if (heads != nullptr) {
+        const float* const* arr2 = o.head_kind2 == 0 ? heads->cls : (o.head_kind2 == 1 ? heads->obj : heads->loc);
+        dst2 = const_cast<float*>(arr2[o.head_layer]);
+        RON_REQUIRE(dst2 != nullptr, "ron_forward: head buffer (kind %d, layer %d) is NULL", o.head_kind2, o.head_layer);
+      }
+      TensorView v2 = v;
+      v2.base = dst2 != nullptr ? dst2 : reinterpret_cast<float*>(16);        // (geometry only: any non-null address)
+      v2.C = o.head_kind2 == 0 ? A * c->cfg.num_classes : (o.head_kind2 == 1 ? 2 * A : 4 * A);
+      v2.cstride = v2.C;
+      v2.bytes = (int64_t)n * v2.H * v2.W * v2.C * 4;
+      L.out2 = v2;
+      L.split_n = p.split_n; L.split_first = p.split_first;
+    }
   } else {
     L.out = c->view(o.out, n, o.out_coff, o.out_C > 0 ? o.out_C : -1);
   }
