@@ -39,6 +39,16 @@ python3 bench.py --no-cpu-baseline --no-parity-mode --batch 1 --in-flight 1 --st
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity-mode --in-flight 1 --batch 1 > $O/bench_cfg2_batch1_under_rocprof.json 2>> $O/err.txt
 f=$(ls $O/prof_b1/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_batch1.csv
 rm -rf $O/prof_b1
+# GEMM shapes beside hipBLASLt, and the same-box A/B against the previous round's library when one was left in tools/experiments
+python3 tools/gemm_vs_vendor.py > $O/gemm_vs_vendor.txt 2>> $O/err.txt
+if [ -n "${RON_PREV_LIB:-}" ] && [ -f "$RON_PREV_LIB" ]; then
+  for rep in 1 2; do
+    RON_HIP_LIB=$PWD/$RON_PREV_LIB python3 bench.py --no-cpu-baseline --no-parity-mode > $O/bench_cfg2_prevlib_$rep.json 2>> $O/err.txt
+    python3 bench.py --no-cpu-baseline --no-parity-mode > $O/bench_cfg2_thislib_$rep.json 2>> $O/err.txt
+  done
+  echo "# previous round's library ($RON_PREV_LIB)" >> $O/batch_sweep.txt
+  RON_HIP_LIB=$PWD/$RON_PREV_LIB BATCHES="1 2 4 8 16 32" bash tools/batch_sweep.sh >> $O/batch_sweep.txt 2>> $O/err.txt
+fi
 rm -rf $O/prof_if1 $O/prof_if2 $O/pmc_*/pmc_fetch $O/pmc_*/pmc_write $O/pmc_*/pmc_mfma
 ls -la $O
 tail -3 $O/pmc.log; tail -30 $O/pmc_mfma.log
