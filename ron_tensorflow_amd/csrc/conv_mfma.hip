@@ -82,7 +82,20 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
   int sk = slots / tiles;
   int min_steps = 8;
   if (sk > KT / min_steps) sk = KT / min_steps;
-  return sk < 1 ? 1 : sk;
+  if (sk <= 1) return 1;
+  // A split launch pays a second launch and writes, then reads, sk fp32 copies of its output: with many rows and a short K that
+  // costs more than the chain it shortens (SSD-512 block8_conv1x1, 16 384 rows x 256 over 16 steps, kernel trace of round 5:
+  // 20 us + a 16 us finalize pass for 33 MB of slabs).  Per K step of a workgroup ~1.1 us, ~5 us for the dependent launch,
+  // ~4 TB/s for the slab traffic; the split stays where the model says it wins.  Same box, with / without (RON_SPLITK_NO_VETO=1):
+  // SSD-512 batch 1 0.697 -> 0.685 ms, batch 4 1.157 -> 1.147, RON and the batch-16 / 32 / 64 benchmark configurations unchanged.
+  static const bool veto = getenv("RON_SPLITK_NO_VETO") == nullptr;
+  if (veto) {
+    const double step_us = 1.1, launch_us = 5.0, bytes_per_us = 4e6;
+    const double tile_bytes = slots <= 256 ? 256.0 * 256 * 4 : 128.0 * 128 * 4;
+    const double t_split = ((KT + sk - 1) / sk) * step_us + launch_us + 2.0 * sk * tiles * tile_bytes / bytes_per_us;
+    if (t_split >= KT * step_us) return 1;
+  }
+  return sk;
 }
 
 constexpr int kAsmLoopMaxStepsHost = detail::kAsmLoopMaxSteps;
