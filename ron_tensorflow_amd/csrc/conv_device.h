@@ -402,6 +402,12 @@ __device__ __forceinline__ void conv_epilogue_r(const ConvArgs& p, const Reader&
   float bias_v[NR];
 #pragma unroll
   for (int j = 0; j < NR; ++j) bias_v[j] = p.bias[n_glob + j];
+  // The bias values must have ARRIVED here, in front of the row loops.  Their first use is inside a row's `offset >= 0` branch; left to
+  // itself the compiler waits for them there, in every row, with `s_waitcnt vmcnt(0)` - and vmcnt counts the rows' STORES too, in order:
+  // each row then waited for the previous row's store to complete (32 rows x ~390 cycles = the 12.5 k cycles a 256 x 256 tile's
+  // epilogue took; found in the ISA, round 5).
+#pragma unroll
+  for (int j = 0; j < NR; ++j) asm volatile("" : "+v"(bias_v[j]));
   // (ConvArgs::split_n: the lane's channels belong to the first output, or - from split_n on - to the second)
   const bool second = p.split_n > 0 && n_glob >= p.split_n;
   const int n_valid = (p.split_n > 0 && !second ? p.split_first : p.Cout) - n_glob;   // channels of this lane's group that exist (may be <= 0)
