@@ -325,6 +325,18 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& p, const Read
   const float oscale = p.oscale;
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
+    // The residuals of the EPA rows of this block are loaded together and made to ARRIVE together (the empty asm), in front of the
+    // rows' stores: a load waited for inside a row's branch is waited for with `vmcnt(0)`, which is also the previous row's store
+    // (conv_epilogue_r, the bias values).  Rows that do not exist read element 0 (any valid address).
+    float rv[RES ? EPA : 1][NR];
+    if (RES) {
+#pragma unroll
+      for (int e = 0; e < EPA; ++e) Tr::template load_vec<NR>(p.res, ooff[i][e] < 0 ? 0 : ooff[i][e] + tap_off + n_store, rv[e]);
+#pragma unroll
+      for (int e = 0; e < EPA; ++e)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) asm volatile("" : "+v"(rv[e][j]));
+    }
 #pragma unroll
     for (int e = 0; e < EPA; ++e) {
       float v[NR];
@@ -337,10 +349,8 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& p, const Read
       }
       if (ooff[i][e] < 0) continue;
       if (RES) {
-        float rv[NR];
-        Tr::template load_vec<NR>(p.res, o, rv);
 #pragma unroll
-        for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j] + rv[j], 0.f);
+        for (int j = 0; j < NR; ++j) v[j] = fmaxf(v[j] + rv[e][j], 0.f);
       }
       if (F32) store_f32_vec<NR>(reinterpret_cast<float*>(p.out) + o, v);
       else Tr::template store_vec<NR>(p.out, o, v);
