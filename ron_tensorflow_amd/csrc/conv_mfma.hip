@@ -192,6 +192,16 @@ int conv_pick_cfg(const ConvLaunch& c) {
   if (c.dtype != RON_DTYPE_F32 && c.Npad % 256 == 128 && c.center_from == 0 && c.up == 0 && c.out2.base == nullptr &&
       ((M + 255) / 256) * (c.Npad / 128) >= 256 && KT <= kAsmLoopMaxStepsHost)
     return kCfgIgemm256x128;
+  // ... and any width where that tile makes the launch about ONE round of the chip (48 .. 320 tiles; below 129 with K split in two):
+  // the 128-row tiles the rules below fall back to when 256 x 256 would leave most CUs idle stage twice the bytes per MAC.  Sweep of every
+  // layer shape at batches 4 .. 64 (profiles/r05/sweep_256x128_all_layers_batches.txt): conv5_x at batch 32 / conv4_x at 8 / conv3_x at 4
+  // 75 -> 55 us (200 tiles), trio3 of the 20 x 20 scale at batch 16 122 -> 105 (300), fc7 at batch 16 65 -> 51 (224); from 400 tiles on
+  // the 256 x 256 tile wins by 10-15 %, below ~48 the launch is latency either way.
+  if (c.dtype != RON_DTYPE_F32 && c.Npad % 128 == 0 && c.center_from == 0 && c.up == 0 && KT <= kAsmLoopMaxStepsHost &&
+      asm_loop_ok(KT)) {
+    const int t = ((M + 255) / 256) * (c.Npad / 128);
+    if (t >= 48 && t <= 320) return kCfgIgemm256x128;
+  }
   const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, c.kh * c.kw * c.in.C, may_split);
   // taps innermost: only for the stride-1 convolutions it has been measured and tested on (the stride-2 3x3 convolutions of SSD-512's
   // extra blocks keep the tap-major order).  Centre-tap-only column tiles of such a launch keep the tap-major walk of their one tap.

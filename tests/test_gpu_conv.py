@@ -557,3 +557,36 @@ def test_tile_256x128_with_fused_maxpool_and_by_choice(ops, dev, dtype):
     _check(got[:1, :15], ref[:, :15], dtype)                        # (its last conv row lacks the strip's lower neighbour)
     full = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=10)
     assert np.array_equal(ops.maxpool2x2_nhwc(full, dtype=dtype).cpu().numpy(), got)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16x3'])
+def test_tile_256x128_split_k_and_one_round_launches(ops, dev, dtype):
+    """Tile configuration 10 beyond conv2_x: several column tiles (Cout 200 -> 256), K split over 2 / 3 / 5 slices (the slices' fp32 slabs
+    and the finalize pass behind the four-wave tile), and the launches conv_pick_cfg now gives it by itself - about one round of the
+    chip (48 .. 320 tiles of 256 x 128): the chosen launch equals the explicit one bit for bit."""
+    rs = np.random.RandomState(92)
+    rnd = ROUND[dtype]
+    x = rs.randn(3, 13, 11, 128).astype(np.float32)                # M = 429: two 256-row tiles, the second ragged
+    wt = (rs.randn(3, 3, 128, 200) * 0.03).astype(np.float32)      # Cout 200 -> 256: two column tiles, the second with partial vectors
+    b = (rs.randn(200) * 0.1).astype(np.float32)
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0)
+    xd = torch.from_numpy(x).to(dev)
+    one = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=10, splitk=1).cpu().numpy()
+    _check(one, ref, dtype)
+    for sk in (2, 3, 5, -1):
+        got = ops.conv2d_nhwc(xd, wt, b, relu=True, dtype=dtype, tile_cfg=10, splitk=sk).cpu().numpy()
+        _check(got, ref, dtype)
+        _check(got, one, dtype)
+    # a launch of 50 x 4 = 200 such tiles (conv5_x at batch 32: 20 x 20 x 32 rows, 512 -> 512): the picker's own choice
+    x2 = rs.randn(32, 20, 20, 512).astype(np.float32) * 0.5
+    w2 = (rs.randn(3, 3, 512, 512) * 0.02).astype(np.float32)
+    b2 = (rs.randn(512) * 0.1).astype(np.float32)
+    x2d = torch.from_numpy(x2).to(dev)
+    auto = ops.conv2d_nhwc(x2d, w2, b2, relu=True, dtype=dtype, tile_cfg=-1).cpu().numpy()
+    explicit = ops.conv2d_nhwc(x2d, w2, b2, relu=True, dtype=dtype, tile_cfg=10).cpu().numpy()
+    assert np.array_equal(auto, explicit)
+    ref2 = np.maximum(orf.conv2d_np(rnd(x2[:1]), rnd(w2)) + b2, 0)
+    _check(auto[:1], ref2, dtype)
+    # ... and with the fused 2x2 max-pool
+    pooled = ops.conv2d_nhwc(x2d, w2, b2, relu=True, dtype=dtype, tile_cfg=-1, pool=True)
+    assert np.array_equal(pooled.cpu().numpy(), ops.maxpool2x2_nhwc(torch.from_numpy(auto).to(dev), dtype=dtype).cpu().numpy())
