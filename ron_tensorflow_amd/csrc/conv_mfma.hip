@@ -112,7 +112,7 @@ int conv_pick_igemm_cfg(int M, int Npad, int taps, int K, bool may_split) {
     // taps innermost: worth 1-6 % of the run time up to two column tiles, time-neutral on wider layers (trio3: six long column tiles,
     // 669 vs 660 us) where it still cuts the fabric reads by a fifth (profiles/r04/sweep_taps_inner_all.txt); conv_pick_cfg takes it
     // back where skipping halo filter rows is worth more (fc6: 514 us tap-major with skipping, 567 us taps-innermost)
-    if (t256 >= 160) return (taps > 1 && Npad <= kTapsInnerMaxN) ? kCfgIgemm256TapsInner : kCfgIgemm256;
+    if (t256 >= 144) return (taps > 1 && Npad <= kTapsInnerMaxN) ? kCfgIgemm256TapsInner : kCfgIgemm256;      // (round 5: 160 -> 144, sweep_all_cfgs)
     // few fat tiles with a long K (in elements: the split-precision and fp32 forms take twice the steps for the same K): split-K
     // fills the chip with them too, at twice the arithmetic per staged byte of the 128 x 128 tiles (tools/sweep_conv.py, round 3:
     // block6_conv_left 26 tiles x 36 864 132 -> 126 us, fc6 at batch 8 214 -> 191, cls_pred / inception2 shapes of 50-100 tiles x 9 216
@@ -192,20 +192,22 @@ int conv_pick_cfg(const ConvLaunch& c) {
   if (c.dtype != RON_DTYPE_F32 && c.Npad % 256 == 128 && c.center_from == 0 && c.up == 0 && c.out2.base == nullptr &&
       ((M + 255) / 256) * (c.Npad / 128) >= 256 && KT <= kAsmLoopMaxStepsHost)
     return kCfgIgemm256x128;
-  // ... and any width where that tile makes the launch about ONE round of the chip (48 .. 320 tiles; below 129 with K split in two):
-  // the 128-row tiles the rules below fall back to when 256 x 256 would leave most CUs idle stage twice the bytes per MAC.  Sweep of every
-  // layer shape at batches 4 .. 64 (profiles/r05/sweep_256x128_all_layers_batches.txt): conv5_x at batch 32 / conv4_x at 8 / conv3_x at 4
-  // 75 -> 55 us (200 tiles), trio3 of the 20 x 20 scale at batch 16 122 -> 105 (300), fc7 at batch 16 65 -> 51 (224); from 400 tiles on
-  // the 256 x 256 tile wins by 10-15 %, below ~48 the launch is latency either way.
-  if (c.dtype != RON_DTYPE_F32 && c.Npad % 128 == 0 && c.center_from == 0 && c.up == 0 && KT <= kAsmLoopMaxStepsHost &&
-      asm_loop_ok(KT)) {
-    const int t = ((M + 255) / 256) * (c.Npad / 128);
-    if (t >= 48 && t <= 320) return kCfgIgemm256x128;
-  }
   const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, c.kh * c.kw * c.in.C, may_split);
   // taps innermost: only for the stride-1 convolutions it has been measured and tested on (the stride-2 3x3 convolutions of SSD-512's
   // extra blocks keep the tap-major order).  Centre-tap-only column tiles of such a launch keep the tap-major walk of their one tap.
   if (cfg == kCfgIgemm256TapsInner && (c.stride != 1 || pick_pos_major(c, kCfgIgemm256, 256))) return kCfgIgemm256;
+  if (cfg == kCfgIgemm128Early && c.dtype != RON_DTYPE_F32 && c.center_from == 0) {
+    // Where 256 x 256 tiles would leave most CUs idle (and K is not long enough to split them, above) the fallback used to be the
+    // 128-row tiles: two workgroups per CU, twice the staged bytes per MAC.  Every tile configuration against this function's choice,
+    // every layer shape, batches 4 .. 64 (profiles/r05/sweep_256x128_all_layers_batches.txt, sweep_all_cfgs_all_layers_batches.txt):
+    // the 256 x 128 four-wave tile where it makes the launch about ONE round of the chip (48 .. 287 tiles; below 129 with K split in
+    //    two): conv5_x at batch 32 / conv4_x at 8 / conv3_x at 4 75 -> 55 us (200 tiles), fc7 at batch 16 65 -> 51 (224); from 288
+    //    (= 144 tiles of 256 x 256) on that tile wins by 13-17 %, below ~48 the launch is latency either way;
+    const int t = ((M + 255) / 256) * (c.Npad / 128);
+    if (c.up == 0 && KT <= kAsmLoopMaxStepsHost && asm_loop_ok(KT) && t >= 48 && t < 288) return kCfgIgemm256x128;
+    // (The 128 x 64 tile for the smallest launches - SSD-512's tail convolutions 13.5 -> 11.5 us stand-alone - was tried as a third
+    // rule: SSD-512 batch 1 -0.8 %, RON batch 2 +0.6 %; not kept.)
+  }
   if (cfg == kCfgIgemm128Early && c.kh * c.kw > 1 && c.up == 0 && c.stride == 1) {
     // taps innermost for the 128 x 128 tile too (consecutive steps re-read almost the same input lines): 3-6 % on launches that do
     // not split K (with split-K it loses: conv5_1 at batch 4 +10 %), and where no filter rows can be skipped instead
