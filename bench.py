@@ -39,6 +39,7 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_F16X3_TFLOPS = 2500.0 / 3   # split precision: three f16 MFMAs per algorithmic product
 PROFILED_STEPS = 3
 PARITY_WARMUP = 10
+SUSTAINED_WINDOW = 100         # steps per window of the sustained leg
 
 
 def parse():
@@ -57,6 +58,9 @@ def parse():
                     help='skip the second, untimed-by-the-headline leg that runs the same workload in the arithmetic that meets '
                          'north_star\'s 1e-4 clause (dtype f16x3) and reports it as "parity_mode"')
     ap.add_argument('--parity-steps', type=int, default=20)
+    ap.add_argument('--sustained-seconds', type=float, default=3.0,
+                    help='after the timed region: the same loop for at least this long without a host wait inside it ("sustained" in the '
+                         'JSON line: overall rate and the rate of every window of %d steps); the same for parity_mode.  0 = skip' % SUSTAINED_WINDOW)
     ap.add_argument('--cpu-images', type=int, default=6, help='images run one by one (batch 1) in the bounded CPU-baseline sample; '
                     'one batch of up to --batch images follows')
     ap.add_argument('--multi-stream', action='store_true',
@@ -194,6 +198,28 @@ def load_mfma_busy(args):
     return val, src
 
 
+def sustained_leg(pipe, images, ms_per_step_estimate, seconds, in_flight, detect_args, top_k, batch, burst_images_per_s, **loop_args):
+    """The timed loop again, for >= `seconds` (a whole number of windows of SUSTAINED_WINDOW steps, at least three), no warm-up of its
+    own and no host wait inside: the clock a serving loop holds, which a 20-step timed region (75 ms) cannot show (the chip lowers its
+    clock under seconds of load: MI355X_MICROARCH.md, DVFS give-back).  Rates per window from timing events on the consuming stream."""
+    from ron_tensorflow_amd import parallel
+    w = SUSTAINED_WINDOW
+    steps = max(3, int(np.ceil(seconds * 1e3 / max(ms_per_step_estimate, 1e-3) / w))) * w
+    res = parallel.bench_loop(pipe, images, steps, 0, in_flight, detect_args, top_k, check_gather=False, window=w, measure_gather=False,
+                              **loop_args)
+    dt, win = res['dt'], res['window_ms']
+    # the first mark stands in front of the first submission, every later one behind the consumption of batch i - (F - 1)
+    rates = [(w - (in_flight - 1 if i == 0 else 0)) * batch / (ms * 1e-3) for i, ms in enumerate(win)]
+    overall = batch * steps / dt
+    return {'seconds': dt, 'steps': steps, 'images_per_s': overall, 'ms_per_step': dt / steps * 1e3, 'window_steps': w,
+            'window_images_per_s': {'first': rates[0], 'last': rates[-1], 'min': min(rates), 'median': float(np.median(rates)),
+                                    'max': max(rates), 'all': [round(r, 1) for r in rates]},
+            'last_over_first_window': rates[-1] / rates[0],
+            'burst_over_sustained': burst_images_per_s / overall,
+            'note': 'same pipeline, images and loop as the timed region, started right after it; whole job (rank 0\'s marks); burst = the '
+                    'timed region of this line'}
+
+
 def parity_mode_leg(args, ron_class, ron_params, weights, images, dev, detect_args, top_k, ref_dets):
     """The same workload in the arithmetic that meets north_star's float tolerance (split precision, dtype f16x3: detections
     within 1e-4 of the fp32 CPU reference), AFTER the headline's timed region and outside its clock: a second context over the
@@ -216,12 +242,20 @@ def parity_mode_leg(args, ron_class, ron_params, weights, images, dev, detect_ar
     # (the GPU idled through the cpu_baseline leg: enough warm-up steps for the clocks to come back up before the timed ones)
     res = parallel.bench_loop(pipe, images, steps, PARITY_WARMUP, in_flight, detect_args, top_k, device=dev)
     dt, det = res['dt'], res['det']
+    sustained = None
+    if args.sustained_seconds > 0:
+        sustained = sustained_leg(pipe, images, dt / steps * 1e3, args.sustained_seconds, in_flight, detect_args, top_k, args.batch,
+                                  args.batch * steps / dt, device=dev)
     tflops = net.flops_per_image() * args.batch * steps / dt / 1e12
     out = {'dtype': dtype, 'images_per_s': args.batch * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'warmup': PARITY_WARMUP,
            'batches_in_flight': in_flight, 'conv_stack_tflops': tflops, 'peak_tflops': PEAK_F16X3_TFLOPS,
            'roofline_frac_of_833': tflops / PEAK_F16X3_TFLOPS,
            'note': 'same weights, images, pipeline and loop as the headline, run after its timed region; three f16 MFMAs per '
                    'algorithmic product, hence the peak of 2500 / 3 TFLOP/s'}
+    if sustained is not None:
+        out['sustained'] = sustained
+        out['sustained']['conv_stack_tflops'] = net.flops_per_image() * sustained['images_per_s'] / 1e12
+        out['sustained']['roofline_frac_of_833'] = out['sustained']['conv_stack_tflops'] / PEAK_F16X3_TFLOPS
     if ref_dets is not None:
         got = det.to_lists()
         agr = [detection_agreement(got[i], ref_dets[i], tol=1e-4) for i in range(len(ref_dets))]
@@ -308,6 +342,13 @@ def main():
                               use_dist=use_dist, device=dev, check_gather=args.check_gather, consumer_stream=io_stream,
                               before_timed=before_timed, after_timed=after_timed)
     dt, det, gather_check = res['dt'], res['det'], res['gather_check']
+    # ---- the sustained leg: the same loop for >= --sustained-seconds, right behind the timed region (every rank takes part;
+    # with a process group the gather stays in the loop)
+    sustained = None
+    if args.sustained_seconds > 0:
+        sustained = sustained_leg(pipe, images, dt / args.steps * 1e3, args.sustained_seconds, in_flight, detect_args, top_k,
+                                  world * args.batch, world * args.batch * args.steps / dt, rank=rank, world=world,
+                                  use_dist=use_dist, device=dev, consumer_stream=io_stream)
     ranks_seen = None
     if use_dist:
         # who took part: the process group's size and the distinct GPUs behind its ranks (one process per GPU: they must be equal)
@@ -418,6 +459,10 @@ def main():
                          'profiled_steps': profiled_steps,
                          'kernel_time_share': conv_ms / max(profiled_steps, 1) / (dt / args.steps * 1e3)},
         }
+        if sustained is not None:
+            sustained['conv_stack_tflops_per_gpu'] = net.flops_per_image() * sustained['images_per_s'] / world / 1e12
+            sustained['roofline_frac'] = sustained['conv_stack_tflops_per_gpu'] / peak
+            out['sustained'] = sustained
         if gather_check is not None:
             out['gather_check'] = gather_check
         if use_dist:

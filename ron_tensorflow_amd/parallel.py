@@ -106,7 +106,7 @@ def gather_detections(rec, group=None, out=None):
 
 def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=0, world=1, use_dist=False, device=None,
                check_gather=True, pack=pack_detections, synchronize=None, consumer_stream=None, before_timed=None,
-               after_timed=None):
+               after_timed=None, window=0, make_mark=None, mark_ms=None, measure_gather=True):
     """The step / consume / gather / check sequence bench.py times, with the pipeline as an argument (bench.py passes a
     DetectPipeline on the GPU; tests/test_parallel_gloo.py a CPU stub at world size 2).
 
@@ -117,8 +117,14 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
     After the timed region every rank compares the slice of `gathered` that is its own with its local records and checks
     every rank's counts; the verdict is the MIN over ranks, so one bad rank makes it 'MISMATCH' everywhere.
 
+    `window` > 0 (bench.py's sustained leg): a mark goes onto the consuming stream in front of the timed steps and after every `window`
+    of them (a timing event behind the consumption of the batch that has just been waited for: with F batches in flight the mark of step
+    i stands behind batch i - F + 1, so consecutive marks are exactly `window` batches apart), and `window_ms` holds the time between
+    consecutive marks - how the rate develops over a run of seconds without the host ever waiting inside it.  `make_mark()` /
+    `mark_ms(a, b)` default to torch timing events (the gloo test passes host clocks).
+
     Returns dict(dt, det (this rank's last detections), gathered, gather_check ('ok' | 'MISMATCH' | None), rank_dt (every rank's own
-    time of the timed region), gather_ms (one all-gather of the records alone, after the timed region))."""
+    time of the timed region), gather_ms (one all-gather of the records alone, after the timed region), window_ms (list, or None))."""
     import contextlib
     import time
     if synchronize is None:
@@ -153,6 +159,20 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
             consume(pending.pop(0))
         return last[0]
 
+    if make_mark is None:
+        def make_mark():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            return ev
+
+        def mark_ms(a, b):
+            return a.elapsed_time(b)
+    marks = []
+
+    def mark():
+        with consumer():
+            marks.append(make_mark())
+
     for _ in range(warmup):
         step()
     drain()
@@ -163,8 +183,12 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
         before_timed()
     synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if window > 0:
+        mark()
+    for i in range(steps):
         step()
+        if window > 0 and (i + 1) % window == 0:
+            mark()
     det = drain()
     synchronize()
     if use_dist:
@@ -184,8 +208,13 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
         flag = torch.tensor([1 if (same and sane) else 0], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         gather_check = 'ok' if int(flag.item()) == 1 else 'MISMATCH'
+    window_ms = [mark_ms(a, b) for a, b in zip(marks[:-1], marks[1:])] if window > 0 else None
     rank_dt, gather_ms = [dt], None
-    if use_dist:
+    if use_dist and not measure_gather:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    elif use_dist:
         # every rank's own time (the reported one is their MAX) and what ONE gather of the records costs on its own
         mine = torch.tensor([dt], dtype=torch.float64, device=device)
         every = torch.empty((world,), dtype=torch.float64, device=device)
@@ -204,4 +233,4 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
                 gather_detections(rec, out=scratch)
         synchronize()
         gather_ms = (time.perf_counter() - g0) / 5 * 1e3
-    return dict(dt=dt, det=det, gathered=gathered, gather_check=gather_check, rank_dt=rank_dt, gather_ms=gather_ms)
+    return dict(dt=dt, det=det, gathered=gathered, gather_check=gather_check, rank_dt=rank_dt, gather_ms=gather_ms, window_ms=window_ms)

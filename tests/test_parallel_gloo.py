@@ -116,7 +116,15 @@ def _bench_worker(rank, world, port, corrupt_rank, ret, sleep_s=0.02):
         for r in range(world):
             want = parallel.pack_records(*_fake_detections(1000 * r + warmup + steps - 1, n, k))
             found.append(bool(torch.equal(res['gathered'][r], want)))
+        # bench.py's sustained leg: the same loop without warm-up, a mark every `window` steps, no gather check / gather timing
+        import time
+        sus = parallel.bench_loop(pipe, images, 6, 0, in_flight, dict(select_threshold=0.01, nms_threshold=0.45), k,
+                                  rank=rank, world=world, use_dist=True, device='cpu', pack=_pack_cpu, synchronize=lambda: None,
+                                  check_gather=False, window=2, make_mark=time.perf_counter, mark_ms=lambda a, b: (b - a) * 1e3,
+                                  measure_gather=False)
         ret[rank] = dict(dt=res['dt'], gather_check=res['gather_check'], found=found, rank_dt=res['rank_dt'], gather_ms=res['gather_ms'],
+                         sustained=dict(dt=sus['dt'], window_ms=sus['window_ms'], gather_check=sus['gather_check'], gather_ms=sus['gather_ms'],
+                                        steps=pipe.step - warmup - steps),
                          det_is_last=bool(torch.equal(res['det'].count, _fake_detections(1000 * rank + warmup + steps - 1, n, k)[4])))
     finally:
         dist.destroy_process_group()
@@ -137,6 +145,14 @@ def test_bench_loop_world2(corrupt_rank):
     assert r0['dt'] >= 4 * 0.02                                               # ... and it is the slow rank's (4 steps x 20 ms)
     want = 'ok' if corrupt_rank < 0 else 'MISMATCH'
     assert r0['gather_check'] == want and r1['gather_check'] == want          # one bad rank fails the check on every rank
+    # the sustained leg: 6 steps in windows of 2 -> 3 window times that add up to (almost) the leg's time; MAX over ranks; nothing else
+    for r in (r0, r1):
+        s = r['sustained']
+        assert s['steps'] == 6 and len(s['window_ms']) == 3 and all(w >= 0 for w in s['window_ms'])
+        assert s['gather_check'] is None and s['gather_ms'] is None
+        assert sum(s['window_ms']) * 1e-3 <= s['dt'] + 1e-3
+    assert r0['sustained']['dt'] == r1['sustained']['dt'] and r1['sustained']['dt'] >= 6 * 0.02
+    assert sum(r1['sustained']['window_ms']) >= 4 * 20 - 1                    # rank 1 sleeps 20 ms per submission
 
 
 def test_bench_loop_world8():
