@@ -199,17 +199,17 @@ def load_mfma_busy(args):
 
 
 def sustained_leg(pipe, images, ms_per_step_estimate, seconds, in_flight, detect_args, top_k, batch, burst_images_per_s, **loop_args):
-    """The timed loop again, for >= `seconds` (a whole number of windows of SUSTAINED_WINDOW steps, at least three), no warm-up of its
+    """The timed loop again, for >= `seconds` (a whole number of windows of SUSTAINED_WINDOW steps, at least four), no warm-up of its
     own and no host wait inside: the clock a serving loop holds, which a 20-step timed region (75 ms) cannot show (the chip lowers its
-    clock under seconds of load: MI355X_MICROARCH.md, DVFS give-back).  Rates per window from timing events on the consuming stream."""
+    clock under seconds of load: MI355X_MICROARCH.md, DVFS give-back).  Rates per window from timing events on the consuming stream;
+    the first window's steps lead up to the first event (parallel.bench_loop), so N windows of steps give N - 1 window rates."""
     from ron_tensorflow_amd import parallel
     w = SUSTAINED_WINDOW
-    steps = max(3, int(np.ceil(seconds * 1e3 / max(ms_per_step_estimate, 1e-3) / w))) * w
+    steps = max(4, int(np.ceil(seconds * 1e3 / max(ms_per_step_estimate, 1e-3) / w))) * w
     res = parallel.bench_loop(pipe, images, steps, 0, in_flight, detect_args, top_k, check_gather=False, window=w, measure_gather=False,
                               **loop_args)
     dt, win = res['dt'], res['window_ms']
-    # the first mark stands in front of the first submission, every later one behind the consumption of batch i - (F - 1)
-    rates = [(w - (in_flight - 1 if i == 0 else 0)) * batch / (ms * 1e-3) for i, ms in enumerate(win)]
+    rates = [w * batch / (ms * 1e-3) for ms in win]
     overall = batch * steps / dt
     return {'seconds': dt, 'steps': steps, 'images_per_s': overall, 'ms_per_step': dt / steps * 1e3, 'window_steps': w,
             'window_images_per_s': {'first': rates[0], 'last': rates[-1], 'min': min(rates), 'median': float(np.median(rates)),

@@ -188,6 +188,16 @@ int ron_bboxes_decode_layer(const float* loc, int n, int feat_h, int feat_w, int
  * With pick >= 0 only channel `pick` is written: y [rows, 1] (objness_pred, :576). */
 int ron_softmax_last(const float* x, int64_t rows, int c, int pick, float* y, void* stream);
 
+/* RONNet.bboxes_filter_min (nets/ron_vgg_320.py:196-233) as an operator of its own: per list the rows with
+ * w = xmax - xmin > minsize and h = ymax - ymin > minsize, in their order (tf.boolean_mask), zeros behind them
+ * (tfe_tensors.pad_axis, tf_extended/tensors.py:59-86).
+ *   scores [num_lists, rows], bboxes [num_lists, rows, 4] (ymin, xmin, ymax, xmax)  ->  out_scores [num_lists, out_rows],
+ *   out_bboxes [num_lists, out_rows, 4] (out_rows >= rows; every row written), counts [num_lists] = rows that passed.
+ * The reference returns max(count, top_k) rows of a list: the caller slices (ops.bboxes_filter_min).  (ron_post_tfe applies the
+ * same filter inside detected_bboxes, ron_tfe_cfg.min_size.) */
+int ron_bboxes_filter_min(const float* scores, const float* bboxes, int num_lists, int rows, float minsize,
+                          float* out_scores, float* out_bboxes, int out_rows, int32_t* counts, void* stream);
+
 /* Detection records for the multi-GPU exchange: one float32 tensor [n, capacity + 1, 7] per rank, rows
  * 0..capacity-1 = (class, score, ymin, xmin, ymax, xmax, anchor_index), zero padded past `count`; row `capacity` = the
  * count replicated.  The only thing that crosses xGMI: one RCCL all-gather of these. */
@@ -228,6 +238,11 @@ int ron_post_tfe(const ron_heads* heads, int n, const ron_tfe_cfg* cfg,
  *   overlap 'union' (what main() passes) or 'min' -> tfe.bboxes_resize(bbox_img).
  *   nms_mode | 2: tf_bboxes_nms_by_class_v1 instead (ron_eval.py:282-366, the variant behind the commented call of :474): a kept
  *   box suppresses boxes of its own label only; the first keep_top_k kept rows in score order are returned.
+ *   nms_mode | 4: tf_bboxes_nms_by_class (ron_eval.py:212-280, the other variant of that commented call): every score COLUMN
+ *   (objectness * probability of class c, the background column included) is a list of its own - rows with score[c] >
+ *   select_threshold, sorted by score[c], greedy with at most keep_top_k picks; a row some list kept is returned with the largest of
+ *   its kept scores and that score's class (lowest class among equals), rows in the flattened anchor order (NOT score order), at most
+ *   num_classes * keep_top_k of them: `out` needs that capacity, and the workspace ron_post_eval_workspace_bytes_mode() gives.
  * min_sizes: device [n], filter_boxes' min_size of every image (max(1e-4, 0.03 * sqrt(h * w / (320 * 320)))).
  * Output: ron_detections (classes = labels), capacity >= keep_top_k, kept rows in score order, zero padded.
  * The 1024 highest scores that pass the filters are the NMS candidates (the reference considers all of them; with its
@@ -238,12 +253,13 @@ typedef struct {
   float select_threshold;   /* 0.6  */
   float nms_threshold;      /* 0.4  */
   int32_t keep_top_k;       /* nms_topk = 20 */
-  int32_t nms_mode;         /* 1 = 'union', 0 = 'min'; + 2 = by class (tf_bboxes_nms_by_class_v1) */
+  int32_t nms_mode;         /* 1 = 'union', 0 = 'min'; + 2 = by class (tf_bboxes_nms_by_class_v1); + 4 = tf_bboxes_nms_by_class */
   float bbox_img[4];
   float prior_scaling[4];
   uint32_t input_flags;
 } ron_eval_cfg;
-int64_t ron_post_eval_workspace_bytes(const ron_heads* heads, int n);
+int64_t ron_post_eval_workspace_bytes(const ron_heads* heads, int n);                      /* nms_mode 0 .. 3 */
+int64_t ron_post_eval_workspace_bytes_mode(const ron_heads* heads, int n, int nms_mode);   /* any nms_mode */
 int ron_post_eval(const ron_heads* heads, int n, const float* min_sizes, const ron_eval_cfg* cfg,
                   void* workspace, int64_t workspace_bytes, ron_detections* out, void* stream);
 
@@ -399,6 +415,13 @@ typedef struct {
 } ron_conv_desc;
 int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const float* w, const float* bias,
                     const float* residual, float* y, void* stream);
+/* Two fp32 head tensors from one convolution over a shared input - the class and the box convolution of an SSD feature layer
+ * (nets/ssd_vgg_300.py:403-431), which the SSD-512 graph runs as one launch: w HWIO [kh,kw,cin,cout], its first `split_first`
+ * output channels go to y_first [n,h,w,split_first], the other cout - split_first to y_second [n,h,w,cout - split_first]
+ * (both fp32, device).  d: a plain stride-1 convolution (no transpose / pool); tile_cfg and splitk select the launch as in
+ * ron_conv2d_nhwc. */
+int ron_conv2d_heads_nhwc(const ron_conv_desc* d, int split_first, const float* x, const float* w, const float* bias,
+                          float* y_first, float* y_second, void* stream);
 int ron_maxpool2x2_nhwc(const float* x, int n, int h, int w, int c, int dtype, float* y, void* stream);
 /* Tooling: time the conv kernel alone on random data (ms per launch, HIP events, default stream, synchronises). */
 int ron_conv2d_bench(const ron_conv_desc* d, int warmup, int iters, float* ms_per_launch);

@@ -8,6 +8,9 @@
                                          greedy, all classes together, at most keep_top_k kept
   tf_bboxes_nms_by_class_v1   ron_eval.py:282-366   (the variant behind the commented call of :474) per label: greedy among the rows of
                                          that label; the union, cut to the first keep_top_k kept rows in score order
+  tf_bboxes_nms_by_class      ron_eval.py:212-280   (the function that commented call names) per score COLUMN, background included:
+                                         rows with score[c] > select_threshold sorted by score[c], greedy with at most keep_top_k picks;
+                                         a row any column kept is returned with max / argmax of its kept scores, rows in input order
   resize           tfe.bboxes_resize     tf_extended/bboxes.py:147-171
 
 TensorFlow graph code: **parity unpinned** (hand case in tests/test_oracle_ron_eval.py).
@@ -36,6 +39,19 @@ def flaten_predict(predictions, objness_pred, bboxes, objectness_thres):
     mask = (labels > 0) & (obj > F32(objectness_thres))
     idx = np.flatnonzero(mask)
     return cls_pred[idx].max(-1), labels[idx], box[idx], idx
+
+
+def flaten_predict_columns(predictions, objness_pred, bboxes, objectness_thres):
+    """flaten_predict as main() uses it (ron_eval.py:466): scores [M, C] = objectness * every class probability, with the same mask."""
+    C = predictions[0].shape[-1]
+    pred = np.concatenate([np.asarray(p, F32).reshape(-1, C) for p in predictions], 0)
+    obj = np.concatenate([np.asarray(o, F32).reshape(-1) for o in objness_pred], 0)
+    box = np.concatenate([np.asarray(b, F32).reshape(-1, 4) for b in bboxes], 0)
+    cls_pred = obj[:, None] * pred
+    labels = np.argmax(cls_pred, -1)
+    mask = (labels > 0) & (obj > F32(objectness_thres))
+    idx = np.flatnonzero(mask)
+    return cls_pred[idx], labels[idx], box[idx], idx
 
 
 def filter_boxes(scores, labels, bboxes, extra, min_size):
@@ -95,13 +111,47 @@ def tf_bboxes_nms_by_class_v1(scores, labels, bboxes, extra, select_threshold, n
     return scores[total], labels[total], bboxes[total], extra[total]
 
 
+def tf_bboxes_nms_by_class(scores, labels, bboxes, extra, select_threshold, nms_threshold, keep_top_k, mode):
+    """ron_eval.py:212-280.  scores [M, C]: nms_proc (:215-258) once per column - tf.nn.top_k over all M rows (stable: lower index first
+    among equals), alive = score > select_threshold (:226), greedy (:251-257: pick the first live row in sorted order, mark the ORIGINAL
+    row kept, :247-248, drop the live rows it overlaps), at most keep_top_k picks (:240); then (:266-274) keep_scores = scores * mask,
+    max / argmax over the columns, rows with max > 0, in input order."""
+    n, C = scores.shape
+    if n < 1:
+        return scores.reshape(-1)[:0], labels, bboxes, extra
+    total = np.zeros((n, C), bool)
+    for c in range(C):
+        col = scores[:, c]
+        order = np.argsort(-col, kind='stable')
+        sb = bboxes[order]
+        alive = col[order] > F32(select_threshold)
+        it = 0
+        while alive.any() and it < keep_top_k:
+            i = int(np.flatnonzero(alive)[0])
+            total[order[i], c] = True
+            alive[i] = False
+            ov = tfe_post.overlap_scores(sb[i], sb, mode) * alive.astype(F32)
+            alive &= ov < F32(nms_threshold)
+            it += 1
+    keep_scores = scores * total.astype(F32)
+    mx = keep_scores.max(-1)
+    new_labels = np.argmax(keep_scores, -1)
+    keep = mx > 0
+    return mx[keep], new_labels[keep], bboxes[keep], extra[keep]
+
+
 def post_eval_image(predictions, objness_pred, bboxes, image_hw, objectness_thres=0.95, select_threshold=0.6, nms_threshold=0.4,
                     keep_top_k=20, nms_mode='union', bbox_img=(0., 0., 1., 1.), min_size_ratio=0.03, nms_by_class=False):
     """ron_eval.py:466-477 for one image (decoded boxes in): dict classes / scores / bboxes / anchor_index."""
-    s, l, b, idx = flaten_predict(predictions, objness_pred, bboxes, objectness_thres)
+    if nms_by_class == 'scores':
+        s, l, b, idx = flaten_predict_columns(predictions, objness_pred, bboxes, objectness_thres)
+    else:
+        s, l, b, idx = flaten_predict(predictions, objness_pred, bboxes, objectness_thres)
     b = tfe_post.clip_with_repair(bbox_img, b)
     s, l, b, idx = filter_boxes(s, l, b, idx, filter_min_size(image_hw, min_size_ratio=min_size_ratio))
-    if nms_by_class:
+    if nms_by_class == 'scores':
+        s, l, b, idx = tf_bboxes_nms_by_class(s, l, b, idx, select_threshold, nms_threshold, keep_top_k, nms_mode)
+    elif nms_by_class:
         s, l, b, idx = tf_bboxes_nms_by_class_v1(s, l, b, idx, select_threshold, nms_threshold, keep_top_k, nms_mode, predictions[0].shape[-1])
     else:
         s, l, b, idx = tf_bboxes_nms(s, l, b, idx, select_threshold, nms_threshold, keep_top_k, nms_mode)

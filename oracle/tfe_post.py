@@ -63,6 +63,21 @@ def overlap_scores(box, boxes, mode):
     return out
 
 
+def bboxes_filter_min(scores, bboxes, top_k, minsize=0.03):
+    """RONNet.bboxes_filter_min on tensors (nets/ron_vgg_320.py:217-233): scores [1, N], bboxes [1, N, 4] -> squeeze axis 0, keep the
+    rows with w > minsize and h > minsize (tf.boolean_mask: order preserving), pad_axis(…, 0, top_k) = zeros up to top_k rows, never
+    shorter than what passed (tf_extended/tensors.py:59-86), expand_dims back."""
+    s, b = np.asarray(scores, F32)[0], np.asarray(bboxes, F32)[0]
+    h = b[:, 2] - b[:, 0]
+    w = b[:, 3] - b[:, 1]
+    m = (w > F32(minsize)) & (h > F32(minsize))
+    s, b = s[m], b[m]
+    pad = max(int(top_k) - s.shape[0], 0)
+    s = np.concatenate([s, np.zeros((pad,), F32)])
+    b = np.concatenate([b, np.zeros((pad, 4), F32)])
+    return s[None], b[None]
+
+
 def nms_one_class(scores, bboxes, nms_threshold, keep_top_k, mode='min'):
     """Sorted lists in, (scores [keep_top_k], bboxes [keep_top_k, 4]) zero padded out."""
     n = scores.shape[0]

@@ -104,6 +104,8 @@ SIGNATURES = {
                                           C.POINTER(C.c_float), _P, _P]),
     'ron_softmax_last': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P]),
     'ron_post_eval_workspace_bytes': (C.c_int64, [C.POINTER(Heads), C.c_int]),
+    'ron_post_eval_workspace_bytes_mode': (C.c_int64, [C.POINTER(Heads), C.c_int, C.c_int]),
+    'ron_bboxes_filter_min': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P]),
     'ron_post_eval': (C.c_int, [C.POINTER(Heads), C.c_int, _P, C.POINTER(EvalCfg), _P, C.c_int64, C.POINTER(Detections), _P]),
     'ron_post_tfe_workspace_bytes': (C.c_int64, [C.POINTER(Heads), C.c_int]),
     'ron_preprocess_eval': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P, _P]),
@@ -131,6 +133,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'ron_profile_reset': (C.c_int, [_P]),
     'ron_conv2d_nhwc': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    'ron_conv2d_heads_nhwc': (C.c_int, [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P, _P]),
     'ron_maxpool2x2_nhwc': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'ron_conv2d_bench': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int, C.POINTER(C.c_float)]),
     'ron_conv_num_tile_cfgs': (C.c_int, []),

@@ -18,7 +18,9 @@ one (tensorflow/core/util/tensor_bundle + tensorflow/core/lib/io/table, the Leve
   <prefix>.data-SSSSS-of-NNNNN  the tensors' raw little-endian bytes at [offset, offset + size)
 
 Only what such checkpoints contain is supported: uncompressed index blocks (what BundleWriter emits), little endian,
-dense numeric tensors, no partitioned-variable slices.  Anything else raises with the reason.
+dense numeric tensors, any number of data shards, no partitioned-variable slices.  Anything else raises with the reason.
+tests/test_checkpoint_tf_layout.py reads files assembled by a second, independent encoder (protobuf runtime + the table builder's
+rules, shortened separator keys, two shards): no TensorFlow-written file exists in this environment.
 """
 import os
 import struct
@@ -260,7 +262,18 @@ def read_index(prefix):
         raise ValueError('%s: no bundle header entry' % path)
     if header.get(2, 0) != 0:
         raise NotImplementedError('big-endian checkpoint')
-    return {'num_shards': header.get(1, 1)}, entries
+    # VersionDef {1: producer, 2: min_consumer, 3: bad_consumers}: tensor_bundle.cc refuses a file whose min_consumer is above its
+    # kTensorBundleVersion (1), so does this reader (it implements version 1)
+    version = {'producer': 0, 'min_consumer': 0}
+    if isinstance(header.get(3), bytes):
+        for f, _, v in _parse_message(header[3]):
+            if f == 1:
+                version['producer'] = v
+            elif f == 2:
+                version['min_consumer'] = v
+    if version['min_consumer'] > 1:
+        raise NotImplementedError('%s: written for tensor-bundle consumers >= %d, this reader implements version 1' % (path, version['min_consumer']))
+    return {'num_shards': header.get(1, 1), 'version': version}, entries
 
 
 class TensorBundleReader(object):

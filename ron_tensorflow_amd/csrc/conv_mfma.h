@@ -48,7 +48,8 @@ struct ConvLaunch {
   int pool = 0;                  // fuse slim.max_pool2d [2,2] into the epilogue: `out` is the pooled map
   TensorView out2;               // with pool: the un-pooled map too (base == nullptr: none), same dtype, geometry Ho x Wo x Cout
   // Two fp32 outputs from one convolution (ConvArgs::split_n): packed columns [0, split_first) -> `out`, [split_n, Cout) -> `out2`,
-  // both un-haloed fp32 views (out_f32 = 1).  Row-gather kernel only, a launch of its own, no split-K.  0: one output.
+  // both un-haloed fp32 views (out_f32 = 1).  Row-gather kernel only, a launch of its own; split-K allowed (the finalize pass routes the
+  // columns the same way: block4 of SSD-512 at small batches splits).  0: one output.
   int split_n = 0, split_first = 0;
   int center_from = 0;           // > 0: output channels >= center_from have weights in the CENTRE tap only (a 1x1 branch packed beside
                                  // 3x3 ones: nets/ron_vgg_320.py:378-397); their column tiles run that tap's K steps alone
@@ -96,7 +97,7 @@ int conv_k_chunk(int dtype);
 int conv_n_tile(int cout);       // granularity Cout is padded to (64 or 128)
 int conv_num_cfgs();
 int conv_pick_cfg(const ConvLaunch& c);
-int conv_pick_splitk(int tiles, int KT, int slots);
+int conv_pick_splitk(int tiles, int KT, int slots, int tile_elems);      // tile_elems = BM x BN of the configuration (slab bytes of the cost model)
 int64_t conv_scratch_bytes(const ConvLaunch& c);   // fp32 split-K slabs this launch can ask for (0: none)
 // Several mutually independent convolutions as ONE launch of the row-gather kernel (tile kCfgIgemm128x64, kCfgIgemm128 or kGroupMixed)
 // sk_plan: the members' split-K factors from conv_group_plan (depends on the members' geometry and the batch only: callers cache it;

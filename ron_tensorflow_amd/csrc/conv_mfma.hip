@@ -77,7 +77,7 @@ static int igemm_slots(int cfg) { return (igemm_is256(cfg) || cfg == kCfgIgemm25
 
 // Split-K factor for grids that leave most CUs idle: such launches are a serial chain of KT dependent
 // HBM round trips per workgroup, so the K loop is spread over enough workgroups to fill the chip (>= 8 steps each).
-int conv_pick_splitk(int tiles, int KT, int slots) {
+int conv_pick_splitk(int tiles, int KT, int slots, int tile_elems) {
   if (tiles < 1 || tiles * 2 > slots || KT < 16) return 1;
   int sk = slots / tiles;
   int min_steps = 8;
@@ -91,7 +91,7 @@ int conv_pick_splitk(int tiles, int KT, int slots) {
   static const bool veto = getenv("RON_SPLITK_NO_VETO") == nullptr;
   if (veto) {
     const double step_us = 1.1, launch_us = 5.0, bytes_per_us = 4e6;
-    const double tile_bytes = slots <= 256 ? 256.0 * 256 * 4 : 128.0 * 128 * 4;
+    const double tile_bytes = 4.0 * tile_elems;       // fp32 slab of one tile (BM x BN of the configuration: 256 x 128 is half of 256 x 256)
     const double t_split = ((KT + sk - 1) / sk) * step_us + launch_us + 2.0 * sk * tiles * tile_bytes / bytes_per_us;
     if (t_split >= KT * step_us) return 1;
   }
@@ -190,7 +190,7 @@ int conv_pick_cfg(const ConvLaunch& c) {
   // Cout = 128 (conv2_x) on maps large enough to fill the chip with 256 x 128 tiles: the four-wave assembly loop at 48 KB staged per
   // K step instead of two 128 x 128 workgroups per CU at 64 KB (sweep: profiles/r05/sweep_256x128.txt)
   if (c.dtype != RON_DTYPE_F32 && c.Npad % 256 == 128 && c.center_from == 0 && c.up == 0 && c.out2.base == nullptr &&
-      ((M + 255) / 256) * (c.Npad / 128) >= 256 && KT <= kAsmLoopMaxStepsHost)
+      ((M + 255) / 256) * (c.Npad / 128) >= 256 && KT <= kAsmLoopMaxStepsHost && asm_loop_ok(KT))
     return kCfgIgemm256x128;
   const int cfg = conv_pick_igemm_cfg(M, c.center_from > 0 ? c.center_from : c.Npad, c.kh * c.kw, c.kh * c.kw * c.in.C, may_split);
   // taps innermost: only for the stride-1 convolutions it has been measured and tested on (the stride-2 3x3 convolutions of SSD-512's
@@ -212,7 +212,7 @@ int conv_pick_cfg(const ConvLaunch& c) {
     // taps innermost for the 128 x 128 tile too (consecutive steps re-read almost the same input lines): 3-6 % on launches that do
     // not split K (with split-K it loses: conv5_1 at batch 4 +10 %), and where no filter rows can be skipped instead
     const int tiles = ((M + 127) / 128) * (c.Npad / 128);
-    const bool splits = may_split && conv_pick_splitk(tiles, KT, igemm_slots(kCfgIgemm128Early)) > 1;
+    const bool splits = may_split && conv_pick_splitk(tiles, KT, igemm_slots(kCfgIgemm128Early), 128 * 128) > 1;
     if (!splits && !pick_pos_major(c, kCfgIgemm128Early, 128)) return kCfgIgemm128EarlyTapsInner;
   }
   return cfg;
@@ -260,7 +260,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
                 "conv: a second output is the un-pooled map of a fused-pool launch");
     RON_REQUIRE(c.out2.pixels() * c.out2.cstride < (int64_t)1 << 31, "conv: second output too large for 32-bit offsets");
   }
-  const int sk = c.splitk >= 0 ? c.splitk : conv_pick_splitk(a.tiles_total, a.KT, igemm_slots(cfg));
+  const int sk = c.splitk >= 0 ? c.splitk : conv_pick_splitk(a.tiles_total, a.KT, igemm_slots(cfg), BM * BN);
   if (sk > 1 && c.up == 0 && !c.pool && c.scratch != nullptr && (int64_t)sk * M * c.Npad * 4 <= c.scratch_bytes) {
     a.kt_split = (a.KT + sk - 1) / sk;
     a.splitk = (a.KT + a.kt_split - 1) / a.kt_split;      // no empty split
@@ -574,7 +574,7 @@ int64_t conv_scratch_bytes(const ConvLaunch& c) {
   const int M = c.in.N * c.Ho * c.Wo;
   const int KT = c.kh * c.kw * c.in.C / conv_k_chunk(c.dtype);
   const int tiles = ((M + igemm_bm(cfg) - 1) / igemm_bm(cfg)) * (c.Npad / igemm_bn(cfg));
-  const int sk = c.splitk >= 0 ? c.splitk : conv_pick_splitk(tiles, KT, igemm_slots(cfg));
+  const int sk = c.splitk >= 0 ? c.splitk : conv_pick_splitk(tiles, KT, igemm_slots(cfg), igemm_bm(cfg) * igemm_bn(cfg));
   return sk > 1 ? (int64_t)sk * M * c.Npad * 4 : 0;
 }
 

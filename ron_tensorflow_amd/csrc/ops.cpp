@@ -174,6 +174,58 @@ extern "C" int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const flo
   return RON_OK;
 }
 
+// Two fp32 head tensors from ONE convolution over a shared input (ConvLaunch::split_n; the graph's pack_box_pair for the class and box
+// convolutions of an SSD feature layer): the same packing - first head's columns, the second's from the next multiple of 8 - and
+// the same launch, with the tile configuration and the split-K factor the caller's to force.
+extern "C" int ron_conv2d_heads_nhwc(const ron_conv_desc* d, int split_first, const float* x, const float* w, const float* bias,
+                                     float* y_first, float* y_second, void* stream) {
+  using namespace ron;
+  RON_REQUIRE(d && x && w && y_first && y_second, "NULL argument");
+  RON_REQUIRE(!d->transpose && !d->pool && d->center_from == 0 && d->stride == 1 && d->cin % conv_k_chunk(d->dtype) == 0,
+              "two-output convolution: a plain stride-1 convolution");
+  RON_REQUIRE(split_first > 0 && split_first < d->cout, "two-output convolution: %d of %d channels in the first output", split_first, d->cout);
+  hipStream_t s = (hipStream_t)stream;
+  const int n_second = d->cout - split_first, split_n = round_up(split_first, 8);
+  // the packed convolution: `split_n + n_second` columns, the ones between the two heads zero
+  ron_conv_desc dp = *d;
+  dp.cout = split_n + n_second;
+  const int K = d->kh * d->kw * d->cin;
+  std::vector<float> wp((size_t)K * dp.cout, 0.f), bp(dp.cout, 0.f);
+  for (int k = 0; k < K; ++k) {
+    for (int n = 0; n < split_first; ++n) wp[(size_t)k * dp.cout + n] = w[(size_t)k * d->cout + n];
+    for (int n = 0; n < n_second; ++n) wp[(size_t)k * dp.cout + split_n + n] = w[(size_t)k * d->cout + split_first + n];
+  }
+  if (bias) {
+    for (int n = 0; n < split_first; ++n) bp[n] = bias[n];
+    for (int n = 0; n < n_second; ++n) bp[split_n + n] = bias[split_first + n];
+  }
+  ConvSetup S;
+  int rc;
+  if ((rc = setup_conv(&dp, wp.data(), bp.data(), false, &S))) return rc;
+  ConvLaunch& c = S.c;
+  TensorView v;
+  v.base = y_first; v.N = d->n; v.H = S.ho; v.W = S.wo; v.pad = 0; v.coff = 0; v.C = split_first; v.cstride = split_first;
+  v.bytes = (int64_t)d->n * S.ho * S.wo * split_first * 4;
+  c.out = v;
+  v.base = y_second; v.C = n_second; v.cstride = n_second;
+  v.bytes = (int64_t)d->n * S.ho * S.wo * n_second * 4;
+  c.out2 = v;
+  c.out_f32 = 1;
+  c.split_n = split_n; c.split_first = split_first;
+  // (setup_conv sized the split-K scratch for a one-output launch, which may have gone to a kernel that never splits)
+  DevBuf scratch2;
+  const int64_t sb = conv_scratch_bytes(c);
+  if (sb > c.scratch_bytes) {
+    if ((rc = scratch2.alloc(sb, false))) return rc;
+    c.scratch = scratch2.p;
+    c.scratch_bytes = sb;
+  }
+  if ((rc = launch_pack_input(x, c.in, d->dtype, s))) return rc;
+  if ((rc = launch_conv(c, s))) return rc;
+  RON_HIP_CHECK(hipStreamSynchronize(s));
+  return RON_OK;
+}
+
 // Times the conv kernel alone on random data (tools/sweep_conv.py): ms per launch over `iters` launches.
 extern "C" int ron_conv2d_bench(const ron_conv_desc* d, int warmup, int iters, float* ms_per_launch) {
   using namespace ron;

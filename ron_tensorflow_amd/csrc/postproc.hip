@@ -1240,6 +1240,18 @@ __global__ __launch_bounds__(kSelectThreads) void eval_select_kernel(HeadsDev hd
   const float xc = box[1] + ws / 2.f, yc = box[0] + hs / 2.f;
   const float ms = pc.min_size[img];
   if (!(ws > ms && hs > ms && xc > 0.f && yc > 0.f && xc < 1.f && yc < 1.f)) return;
+  if (pc.nms_mode & 4) {
+    // tf_bboxes_nms_by_class (ron_eval.py:212-280): one list per score column, background included; a row is a candidate of every
+    // class whose score passes select_threshold (:226)
+    for (int c = 0; c < C; ++c) {
+      const float sc = objp * (is_prob ? row[c] : expf(row[c] - mx) / sum);
+      if (!(sc > pc.sel_thr)) continue;
+      const size_t list = (size_t)img * C + c;
+      const int pos = atomicAdd(&counts[list * kCountStride], 1);
+      if (pos < cap) keys[list * cap + pos] = make_key(sc, (unsigned)(hd.anchor_base[layer] + local) * (unsigned)kMaxClasses + (unsigned)c);
+    }
+    return;
+  }
   const int pos = atomicAdd(&counts[img * kCountStride], 1);
   if (pos < cap) keys[(size_t)img * cap + pos] = make_key(best, (unsigned)(hd.anchor_base[layer] + local) * (unsigned)kMaxClasses + (unsigned)label);
 }
@@ -1250,13 +1262,19 @@ constexpr int kEvalCand = 1024;     // NMS candidates of the ron_eval.py variant
 // in score order, so they are taken kEvalCand at a time: a pass sorts the next kEvalCand highest keys, drops the ones a
 // box kept by an earlier pass overlaps, and continues the greedy scan; it ends when keep_top_k rows are kept or the
 // candidates run out.  One pass in practice (the reference's thresholds let a few dozen through), exact for any count.
+// nms_mode | 4 (tf_bboxes_nms_by_class, ron_eval.py:212-280): the grid's y dimension walks the score columns; a list's kept rows go to
+// `best[img][anchor]` = max over the classes that kept the anchor of (score, lowest class first) - keep_scores' reduce_max / argmax of
+// :268-272 - and eval_merge_kernel writes the records in anchor order.
 __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, EvalDev pc, const u64* keys, const int* counts,
-                                                                int cap, DetDev out) {
+                                                                int cap, DetDev out, u64* best) {
   static_assert(kEvalCand == kTopkThreads && kSortCap >= kEvalCand + kEvalCand * 2 + kEvalCand / 2,
                 "one thread per candidate; boxes and labels live behind the keys");
   __shared__ ImageLds lds;
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = min(counts[img * kCountStride], cap);
+  const bool per_class_lists = (pc.nms_mode & 4) != 0;
+  const size_t list = per_class_lists ? (size_t)img * hd.num_classes + blockIdx.y : (size_t)img;
+  keys += list * cap - (size_t)img * cap;
+  const int m = min(counts[list * kCountStride], cap);
   float* box = reinterpret_cast<float*>(&lds.sort[kEvalCand]);              // [kEvalCand][4]
   int* lab = reinterpret_cast<int*>(&lds.sort[kEvalCand + kEvalCand * 2]);  // [kEvalCand] labels of this pass's candidates
   u64* words = reinterpret_cast<u64*>(lds.hist);                            // alive bits, one word per wave
@@ -1265,7 +1283,7 @@ __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, Eva
   // so one greedy pass in score order with the label test is the reference's loop over the classes, and "the first keep_top_k of the
   // kept rows in score order" (its final cut) is where this scan stops anyway
   const bool by_class = (pc.nms_mode & 2) != 0;
-  const int max_keep = min(pc.keep_top_k, out.capacity);
+  const int max_keep = per_class_lists ? pc.keep_top_k : min(pc.keep_top_k, out.capacity);
   int n_kept = 0;                                                           // kept records: lds.box / score / cls / anchor
   u64 below = ~0ull;
   for (int consumed = 0; consumed < m && n_kept < max_keep; consumed += kEvalCand) {
@@ -1318,6 +1336,12 @@ __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, Eva
   }
   __syncthreads();
   const int total = n_kept;
+  if (per_class_lists) {
+    // score > 0 (it passed select_threshold >= 0): a zero word is "not kept"; among equal scores the lowest class wins (argmax)
+    for (int i = tid; i < total; i += blockDim.x)
+      atomicMax(&best[(size_t)img * cap + lds.anchor[i]], ((u64)__float_as_uint(lds.score[i]) << 8) | (u64)(255 - lds.cls[i]));
+    return;
+  }
   const float sy = pc.ref[2] - pc.ref[0], sx = pc.ref[3] - pc.ref[1];
   for (int i = tid; i < out.capacity; i += blockDim.x) {
     const size_t o = (size_t)img * out.capacity + i;
@@ -1337,27 +1361,151 @@ __global__ __launch_bounds__(kTopkThreads) void eval_nms_kernel(HeadsDev hd, Eva
   if (tid == 0) out.count[img] = total;
 }
 
+// tf_bboxes_nms_by_class, :268-274: the anchors some class kept, in the flattened anchor order (boolean_mask), each with its best
+// kept score and that score's class; boxes clipped like the candidates', then tfe.bboxes_resize.  One workgroup per image.
+__global__ __launch_bounds__(kTopkThreads) void eval_merge_kernel(HeadsDev hd, EvalDev pc, const u64* best, int cap, DetDev out) {
+  __shared__ int wave_sum[kTopkThreads / 64];
+  __shared__ int base_s;
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float sy = pc.ref[2] - pc.ref[0], sx = pc.ref[3] - pc.ref[1];
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int a0 = 0; a0 < cap; a0 += kTopkThreads) {
+    const int anchor = a0 + tid;
+    const u64 v = anchor < cap ? best[(size_t)img * cap + anchor] : 0ull;
+    const bool has = v != 0ull;
+    const u64 bal = __ballot(has);
+    if (lane == 0) wave_sum[wave] = __popcll(bal);
+    __syncthreads();
+    int pos = base_s + __popcll(bal & ((1ull << lane) - 1ull));
+    int all = 0;
+#pragma unroll
+    for (int w = 0; w < kTopkThreads / 64; ++w) {
+      if (w < wave) pos += wave_sum[w];
+      all += wave_sum[w];
+    }
+    if (has && pos < out.capacity) {
+      int layer = 0;
+#pragma unroll
+      for (int l = 1; l < RON_MAX_LAYERS; ++l)
+        if (l < hd.num_layers && anchor >= hd.anchor_base[l]) layer = l;
+      float b[4];
+      eval_box(hd, pc, img, layer, anchor - hd.anchor_base[layer], b);
+      const size_t o = (size_t)img * out.capacity + pos;
+      out.classes[o] = 255 - (int)(v & 0xFFull);
+      out.scores[o] = __uint_as_float((unsigned)(v >> 8));
+      out.anchor_index[o] = anchor;
+      out.bboxes[o * 4 + 0] = (b[0] - pc.ref[0]) / sy;
+      out.bboxes[o * 4 + 1] = (b[1] - pc.ref[1]) / sx;
+      out.bboxes[o * 4 + 2] = (b[2] - pc.ref[0]) / sy;
+      out.bboxes[o * 4 + 3] = (b[3] - pc.ref[1]) / sx;
+    }
+    __syncthreads();
+    if (tid == 0) base_s += all;
+    __syncthreads();
+  }
+  const int total = min(base_s, out.capacity);
+  for (int i = total + tid; i < out.capacity; i += blockDim.x) {
+    const size_t o = (size_t)img * out.capacity + i;
+    out.classes[o] = 0; out.scores[o] = 0.f; out.anchor_index[o] = 0;
+    out.bboxes[o * 4 + 0] = 0.f; out.bboxes[o * 4 + 1] = 0.f; out.bboxes[o * 4 + 2] = 0.f; out.bboxes[o * 4 + 3] = 0.f;
+  }
+  if (tid == 0) out.count[img] = total;
+}
+
+// RONNet.bboxes_filter_min (nets/ron_vgg_320.py:196-233) on its own: per list, the rows with w > minsize and h > minsize in their
+// order (tf.boolean_mask), zeros behind them (pad_axis).  One workgroup per list.
+__global__ __launch_bounds__(kTopkThreads) void filter_min_kernel(const float* scores, const float* bboxes, int rows, float minsize,
+                                                                  float* out_scores, float* out_bboxes, int out_rows, int* counts) {
+  __shared__ int wave_sum[kTopkThreads / 64];
+  __shared__ int base_s;
+  const int list = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* sc = scores + (size_t)list * rows;
+  const float* bb = bboxes + (size_t)list * rows * 4;
+  float* os = out_scores + (size_t)list * out_rows;
+  float* ob = out_bboxes + (size_t)list * out_rows * 4;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < rows; r0 += kTopkThreads) {
+    const int r = r0 + tid;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool has = false;
+    if (r < rows) {
+      b = *reinterpret_cast<const float4*>(bb + (size_t)r * 4);
+      const float h = b.z - b.x, w = b.w - b.y;                  // (ymin, xmin, ymax, xmax)
+      has = (w > minsize) && (h > minsize);
+    }
+    const u64 bal = __ballot(has);
+    if (lane == 0) wave_sum[wave] = __popcll(bal);
+    __syncthreads();
+    int pos = base_s + __popcll(bal & ((1ull << lane) - 1ull));
+    int all = 0;
+#pragma unroll
+    for (int w = 0; w < kTopkThreads / 64; ++w) {
+      if (w < wave) pos += wave_sum[w];
+      all += wave_sum[w];
+    }
+    if (has) {
+      os[pos] = sc[r];
+      *reinterpret_cast<float4*>(ob + (size_t)pos * 4) = b;
+    }
+    __syncthreads();
+    if (tid == 0) base_s += all;
+    __syncthreads();
+  }
+  const int total = base_s;
+  for (int i = total + tid; i < out_rows; i += blockDim.x) {
+    os[i] = 0.f;
+    *reinterpret_cast<float4*>(ob + (size_t)i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (tid == 0) counts[list] = total;
+}
+
 }  // namespace
 
-extern "C" int64_t ron_post_eval_workspace_bytes(const ron_heads* heads, int n) {
-  HeadsDev hd;
-  if (build_heads_dev(heads, &hd, false) != RON_OK || n <= 0) return -1;
-  return ron::align_up((int64_t)n * kCountStride * 4, 256) + (int64_t)n * hd.anchor_base[RON_MAX_LAYERS] * 8;
+extern "C" int ron_bboxes_filter_min(const float* scores, const float* bboxes, int num_lists, int rows, float minsize,
+                                     float* out_scores, float* out_bboxes, int out_rows, int32_t* counts, void* stream) {
+  RON_REQUIRE(scores != nullptr && bboxes != nullptr && out_scores != nullptr && out_bboxes != nullptr && counts != nullptr, "bad argument");
+  RON_REQUIRE(num_lists > 0 && rows >= 0 && out_rows >= rows, "bboxes_filter_min: %d lists of %d rows into %d rows", num_lists, rows, out_rows);
+  RON_REQUIRE(((uintptr_t)bboxes & 15) == 0 && ((uintptr_t)out_bboxes & 15) == 0, "bboxes_filter_min: box arrays must be 16-byte aligned");
+  RON_LAUNCH(filter_min_kernel, dim3(num_lists), dim3(kTopkThreads), 0, (hipStream_t)stream, scores, bboxes, rows, minsize, out_scores,
+             out_bboxes, out_rows, counts);
+  RON_HIP_CHECK(ron::launch_error());
+  return RON_OK;
 }
+
+static int64_t eval_lists(const ron_heads* heads, int n, int nms_mode) { return (nms_mode & 4) ? (int64_t)n * heads->num_classes : (int64_t)n; }
+
+// workspace: [counters, one 128-byte line per list][keys: lists x anchors][nms_mode | 4: best, n x anchors]
+extern "C" int64_t ron_post_eval_workspace_bytes_mode(const ron_heads* heads, int n, int nms_mode) {
+  HeadsDev hd;
+  if (heads == nullptr || build_heads_dev(heads, &hd, false) != RON_OK || n <= 0) return -1;
+  const int64_t lists = eval_lists(heads, n, nms_mode);
+  return ron::align_up(lists * kCountStride * 4, 256) + lists * hd.anchor_base[RON_MAX_LAYERS] * 8 +
+         ((nms_mode & 4) ? (int64_t)n * hd.anchor_base[RON_MAX_LAYERS] * 8 : 0);
+}
+
+extern "C" int64_t ron_post_eval_workspace_bytes(const ron_heads* heads, int n) { return ron_post_eval_workspace_bytes_mode(heads, n, 0); }
 
 extern "C" int ron_post_eval(const ron_heads* heads, int n, const float* min_sizes, const ron_eval_cfg* cfg, void* workspace,
                              int64_t workspace_bytes, ron_detections* out, void* stream) {
   RON_REQUIRE(cfg != nullptr && n > 0 && out != nullptr && min_sizes != nullptr, "bad argument");
   RON_REQUIRE(cfg->keep_top_k >= 1 && cfg->keep_top_k <= kMaxTopK, "keep_top_k %d not in [1, %d]", cfg->keep_top_k, kMaxTopK);
-  RON_REQUIRE(cfg->nms_mode >= 0 && cfg->nms_mode <= 3, "unknown mode to use for nms.");
+  RON_REQUIRE(cfg->nms_mode >= 0 && cfg->nms_mode <= 5, "unknown mode to use for nms.");
   RON_REQUIRE(heads != nullptr && heads->num_classes <= RON_MAX_CLASSES, "num_classes must be <= %d", RON_MAX_CLASSES);
+  const bool per_class_lists = (cfg->nms_mode & 4) != 0;
+  if (per_class_lists) {
+    RON_REQUIRE(cfg->select_threshold >= 0.f, "tf_bboxes_nms_by_class: select_threshold must be >= 0");
+    RON_REQUIRE((int64_t)out->capacity >= (int64_t)heads->num_classes * cfg->keep_top_k,
+                "tf_bboxes_nms_by_class: every class may keep keep_top_k rows: capacity %d < %d x %d", out->capacity, heads->num_classes, cfg->keep_top_k);
+  }
   HeadsDev hd;
   int rc = build_heads_dev(heads, &hd, (cfg->input_flags & RON_IN_LOC_DECODED) == 0);
   if (rc != RON_OK) return rc;
   for (int i = 0; i < hd.num_layers; ++i) RON_REQUIRE(hd.obj[i] != nullptr, "ron_post_eval needs the objectness tensors");
   DetDev d_out;
   if ((rc = to_det_dev(out, &d_out, cfg->keep_top_k, "out", false))) return rc;
-  const int64_t need = ron_post_eval_workspace_bytes(heads, n);
+  const int64_t need = ron_post_eval_workspace_bytes_mode(heads, n, cfg->nms_mode);
   RON_REQUIRE(workspace != nullptr && workspace_bytes >= need, "workspace too small: %lld < %lld", (long long)workspace_bytes, (long long)need);
   EvalDev pc;
   pc.obj_thr = cfg->objectness_thres; pc.sel_thr = cfg->select_threshold; pc.nms_thr = cfg->nms_threshold;
@@ -1365,17 +1513,21 @@ extern "C" int ron_post_eval(const ron_heads* heads, int n, const float* min_siz
   for (int i = 0; i < 4; ++i) { pc.ref[i] = cfg->bbox_img[i]; pc.ps[i] = cfg->prior_scaling[i]; }
   hipStream_t s = (hipStream_t)stream;
   int* counts = (int*)workspace;
-  const int64_t cbytes = ron::align_up((int64_t)n * kCountStride * 4, 256);
+  const int64_t lists = eval_lists(heads, n, cfg->nms_mode);
+  const int64_t cbytes = ron::align_up(lists * kCountStride * 4, 256);
   u64* keys = (u64*)((char*)workspace + cbytes);
   const int cap = hd.anchor_base[RON_MAX_LAYERS];
+  u64* best = per_class_lists ? keys + lists * cap : nullptr;
   RON_HIP_CHECK(hipMemsetAsync(counts, 0, cbytes, s));
+  if (per_class_lists) RON_HIP_CHECK(hipMemsetAsync(best, 0, (size_t)n * cap * 8, s));
   const size_t lds = (size_t)kSelectThreads * hd.num_classes * sizeof(float);
   if (lds > 48 * 1024) {          // beyond ~48 classes the staging tile needs the dynamic-LDS limit raised (128 classes: 128 KB of the CU's 160)
     static ron::PerDeviceOnce once;
     RON_HIP_CHECK(once.max_dynamic_lds(reinterpret_cast<const void*>(&eval_select_kernel), (int)lds));
   }
   RON_LAUNCH(eval_select_kernel, dim3(hd.block_base[RON_MAX_LAYERS], n), dim3(kSelectThreads), lds, s, hd, pc, keys, counts, cap);
-  RON_LAUNCH(eval_nms_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, d_out);
+  RON_LAUNCH(eval_nms_kernel, dim3(n, per_class_lists ? hd.num_classes : 1), dim3(kTopkThreads), 0, s, hd, pc, keys, counts, cap, d_out, best);
+  if (per_class_lists) RON_LAUNCH(eval_merge_kernel, dim3(n), dim3(kTopkThreads), 0, s, hd, pc, best, cap, d_out);
   RON_HIP_CHECK(ron::launch_error());
   return RON_OK;
 }

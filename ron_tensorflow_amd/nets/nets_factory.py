@@ -3,6 +3,18 @@ import functools
 
 from . import ron_vgg_320, ssd_vgg_512
 
+# nets/nets_factory.py:34-52, the entries of the two networks this package builds (vgg_a / vgg_16 / vgg_19 classifiers and SSD-300
+# are outside SURVEY.md section 8)
+networks_map = {'ron_320_vgg': ron_vgg_320.ron_net,
+                'ssd_512_vgg': ssd_vgg_512.ssd_net,
+                'ssd_512_vgg_caffe': ssd_vgg_512.ssd_net,
+                }
+
+arg_scopes_map = {'ron_320_vgg': ron_vgg_320.ron_arg_scope,
+                  'ssd_512_vgg': ssd_vgg_512.ssd_arg_scope,
+                  'ssd_512_vgg_caffe': ssd_vgg_512.ssd_arg_scope_caffe,
+                  }
+
 networks_obj = {'ron_320_vgg': ron_vgg_320.RONNet,
                 'ssd_512_vgg': ssd_vgg_512.SSDNet}
 

@@ -24,6 +24,26 @@ RONParams = namedtuple('SSDParameters', ['img_shape', 'num_classes', 'no_annotat
                                          'anchor_steps', 'anchor_offset', 'prior_scaling'])
 
 
+class _DataFormatScope(object):
+    """What `arg_scope(data_format=...)` returns: inside the `with`, the networks it was made for take / return that layout."""
+
+    def __init__(self, nets, data_format):
+        if data_format not in ('NHWC', 'NCHW'):
+            raise ValueError('data_format must be NHWC or NCHW, not %r' % (data_format,))
+        self.nets, self.data_format, self._saved = nets, data_format, []
+
+    def __enter__(self):
+        self._saved = [getattr(n, '_data_format', 'NHWC') for n in self.nets]
+        for n in self.nets:
+            n._data_format = self.data_format
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in zip(self.nets, self._saved):
+            n._data_format = f
+        return False
+
+
 class RONNet(object):
     """RON VGG-based 320 network: conv4 -> 40x40, conv5 -> 20x20, fc6 -> 10x10, fc7 -> 5x5."""
     default_params = RONParams(
@@ -205,12 +225,17 @@ class RONNet(object):
         `reuse` / `scope` are accepted for signature compatibility (the reference's dropout is commented out,
         :480, and BatchNorm runs on its moving statistics).  Returns the reference's 6-tuple
         (predictions, logits, objness_pred, objness_logits, localisations, end_points)."""
+        nchw = getattr(self, '_data_format', 'NHWC') == 'NCHW'
+        if nchw:                                       # images as preprocess_for_eval(..., data_format='NCHW') hands them over
+            inputs = inputs.permute(0, 2, 3, 1)
         logits, objness_logits, localisations = self.forward_heads(inputs)
         fn = prediction_fn if prediction_fn is not None else ops.softmax_last
         predictions = [fn(l) for l in logits]
         objness_pred = [ops.softmax_last(o, pick=1) if prediction_fn is None else fn(o)[..., 1:2] for o in objness_logits]
         names = [n for n in (end_points or ()) if not (self.fuse_pools and n in ('block1', 'block2', 'block3'))]
         eps = {name: self.end_point(name, inputs.shape[0]) for name in names}
+        if nchw:                                       # the feature maps in the caller's layout; the heads are channel-last either way (:401, :412)
+            eps = {k: v.permute(0, 3, 1, 2).contiguous() for k, v in eps.items()}
         return predictions, logits, objness_pred, objness_logits, localisations, eps
 
     def end_point(self, name, n):
@@ -223,11 +248,11 @@ class RONNet(object):
         return out
 
     def arg_scope(self, weight_decay=0.0005, is_training=True, data_format='NHWC'):
-        """Network arg_scope (nets/ron_vgg_320.py:156-159).  Layer defaults are baked into the HIP graph;
-        returned object is a no-op context manager so `with slim.arg_scope(net.arg_scope(...))`-style code runs."""
-        if data_format != 'NHWC':
-            raise ValueError('only NHWC is supported')
-        return contextlib.nullcontext()
+        """Network arg_scope (nets/ron_vgg_320.py:156-159).  Layer defaults are baked into the HIP graph; the returned object is a
+        context manager so `with slim.arg_scope(net.arg_scope(...))`-style code runs.  `data_format='NCHW'` (ron_eval.py:34 offers it):
+        inside the context `net()` takes [N, 3, H, W] images and returns its end points as [N, C, H, W]; the kernels stay NHWC (the
+        layout the MFMA tiles gather rows from), the image is re-laid on the way in."""
+        return _DataFormatScope([self], data_format)
 
     def anchors(self, img_shape, dtype=np.float32):
         """Default anchor boxes (nets/ron_vgg_320.py:162-171): list of (y, x, h, w) per layer."""
@@ -245,6 +270,16 @@ class RONNet(object):
         adev = ops.anchors_to_device(anchors, self.device)
         return [ops.bboxes_decode_layer(l, a, tuple(self.params.prior_scaling)) for l, a in zip(feat_localizations, adev)]
 
+    def bboxes_filter_min(self, scores, bboxes, top_k, minsize=0.03, scope=None):
+        """nets/ron_vgg_320.py:196-233: drop the boxes with w <= minsize or h <= minsize, keeping the order, zero-pad to top_k.
+        Tensors ([1, N] / [1, N, 4]) or dicts class -> tensors, like the reference."""
+        if isinstance(scores, dict) or isinstance(bboxes, dict):
+            d_scores, d_bboxes = {}, {}
+            for c in scores.keys():
+                d_scores[c], d_bboxes[c] = self.bboxes_filter_min(scores[c], bboxes[c], top_k, minsize=minsize)
+            return d_scores, d_bboxes
+        return ops.bboxes_filter_min(scores, bboxes, top_k, minsize=minsize)
+
     def detected_bboxes(self, predictions, localisations, select_threshold=None, nms_threshold=0.5,
                         clipping_bbox=None, top_k=400, keep_top_k=200, nms_mode='min'):
         """nets/ron_vgg_320.py:234-256: per-class select -> clip -> filter_min -> sort -> NMS (TF semantics).
@@ -260,6 +295,8 @@ class RONNet(object):
                bbox_img=(0., 0., 1., 1.), out=None):
         """forward + np_methods post-processing in one enqueue (ron_detect).  Returns DetectionBuffers
         (`out`, when given, is reused: n and capacity must match)."""
+        if getattr(self, '_data_format', 'NHWC') == 'NCHW':
+            inputs = inputs.permute(0, 2, 3, 1)
         inputs = inputs.to(self.device, torch.float32).contiguous()
         n = inputs.shape[0]
         cfg = _lib.PostCfg()
@@ -274,3 +311,80 @@ class RONNet(object):
         oc = out.c_struct()
         check(lib().ron_detect(self._context(), ptr(inputs), n, C.byref(cfg), C.byref(oc), current_stream()))
         return out
+
+
+# ---------------------------------------------------------------------- the reference's function entries
+# nets_factory.networks_map / arg_scopes_map point at module-level functions (nets/nets_factory.py:34-52): ron_net builds the graph
+# under a variable scope, `reuse=True` finds the variables of an earlier call.  Here a scope name owns one network object (its packed
+# weights are the scope's variables): the first call of a scope needs `weights=` (dict by TF variable name), later calls reuse it.
+_SCOPES = {}
+
+
+def _scoped_net(key, make, weights, reuse):
+    net = _SCOPES.get(key)
+    if net is None:
+        if reuse:
+            raise ValueError('Variable scope %s does not exist (reuse=True before the first call)' % (key[0],))
+        if weights is None:
+            raise ValueError('the first call of scope %r needs weights= (a dict keyed by TF variable names)' % (key[0],))
+        net = _SCOPES[key] = make()
+        net.load_weights(weights)
+    elif weights is not None and not reuse:
+        net.load_weights(weights)
+    return net
+
+
+def _ron_net_fn(variant, inputs, num_classes, feat_layers, anchor_sizes, anchor_ratios, is_training, dropout_keep_prob, prediction_fn,
+                reuse, scope, weights, dtype, max_batch):
+    d = RONNet.default_params
+    params = d._replace(num_classes=num_classes, feat_layers=list(feat_layers), anchor_sizes=list(anchor_sizes), anchor_ratios=list(anchor_ratios))
+    dev = inputs.device if inputs.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    key = (scope, variant, num_classes, dtype, str(dev))
+    net = _scoped_net(key, lambda: RONNet(params, variant=variant, dtype=dtype, max_batch=max(max_batch, inputs.shape[0]), device=dev), weights, reuse)
+    fmt = _ARG_SCOPE_FORMAT[-1] if _ARG_SCOPE_FORMAT else 'NHWC'
+    with _DataFormatScope([net], fmt):
+        return net.net(inputs, is_training=is_training, dropout_keep_prob=dropout_keep_prob, prediction_fn=prediction_fn, reuse=reuse, scope=scope)
+
+
+def ron_net(inputs, num_classes=RONNet.default_params.num_classes, feat_layers=RONNet.default_params.feat_layers,
+            anchor_sizes=RONNet.default_params.anchor_sizes, anchor_ratios=RONNet.default_params.anchor_ratios, is_training=True,
+            dropout_keep_prob=0.5, prediction_fn=None, reuse=None, scope='ron_320_vgg', weights=None, dtype='bf16', max_batch=32):
+    """RON net definition, full VGG-16 fc6 / fc7 (nets/ron_vgg_320.py:434-508): the reference's 6-tuple."""
+    return _ron_net_fn('full', inputs, num_classes, feat_layers, anchor_sizes, anchor_ratios, is_training, dropout_keep_prob,
+                       prediction_fn, reuse, scope, weights, dtype, max_batch)
+
+
+def ron_net_reducedfc(inputs, num_classes=RONNet.default_params.num_classes, feat_layers=RONNet.default_params.feat_layers,
+                      anchor_sizes=RONNet.default_params.anchor_sizes, anchor_ratios=RONNet.default_params.anchor_ratios, is_training=True,
+                      dropout_keep_prob=0.5, prediction_fn=None, reuse=None, scope='ron_320_vgg', weights=None, dtype='bf16', max_batch=32):
+    """RON net definition with the reduced fc6 / fc7 (nets/ron_vgg_320.py:510-580)."""
+    return _ron_net_fn('reducedfc', inputs, num_classes, feat_layers, anchor_sizes, anchor_ratios, is_training, dropout_keep_prob,
+                       prediction_fn, reuse, scope, weights, dtype, max_batch)
+
+
+ron_net.default_image_size = 320
+
+_ARG_SCOPE_FORMAT = []       # data formats of the arg scopes entered, innermost last
+
+
+class _ArgScope(object):
+    """ron_arg_scope / ssd_arg_scope: the layer defaults (SAME padding, ReLU, BN eps 1e-5, ...; nets/ron_vgg_320.py:595-629) are what
+    the HIP graph implements and are not configurable; the scope carries the one thing a caller can choose, the data format."""
+
+    def __init__(self, weight_decay=0.0005, is_training=True, data_format='NHWC'):
+        if data_format not in ('NHWC', 'NCHW'):
+            raise ValueError('data_format must be NHWC or NCHW, not %r' % (data_format,))
+        self.weight_decay, self.is_training, self.data_format = weight_decay, is_training, data_format
+
+    def __enter__(self):
+        _ARG_SCOPE_FORMAT.append(self.data_format)
+        return self
+
+    def __exit__(self, *exc):
+        _ARG_SCOPE_FORMAT.pop()
+        return False
+
+
+def ron_arg_scope(weight_decay=0.0005, is_training=True, data_format='NHWC'):
+    """Defines the RON arg scope (nets/ron_vgg_320.py:595-629)."""
+    return _ArgScope(weight_decay, is_training, data_format)

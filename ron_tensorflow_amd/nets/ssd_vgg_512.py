@@ -12,6 +12,7 @@ import torch
 
 from .. import _lib, ops
 from .._lib import check, current_stream, lib, ptr
+from . import ron_vgg_320
 from .ron_vgg_320 import RONNet
 
 # same field names as the reference namedtuple (nets/ssd_vgg_512.py:44-60)
@@ -69,10 +70,15 @@ class SSDNet(RONNet):
     def net(self, inputs, is_training=True, update_feat_shapes=True, dropout_keep_prob=0.5, prediction_fn=None, reuse=None,
             scope='ssd_512_vgg', end_points=('block4', 'block7', 'block8', 'block9', 'block10', 'block11', 'block12')):
         """nets/ssd_vgg_512.py:108-133 -> (predictions, localisations, logits, end_points)."""
+        nchw = getattr(self, '_data_format', 'NHWC') == 'NCHW'
+        if nchw:
+            inputs = inputs.permute(0, 2, 3, 1)
         logits, _, localisations = self.forward_heads(inputs)
         fn = prediction_fn if prediction_fn is not None else ops.softmax_last
         predictions = [fn(l) for l in logits]
         eps = {name: self.end_point(name, inputs.shape[0]) for name in (end_points or ())}
+        if nchw:
+            eps = {k: v.permute(0, 3, 1, 2).contiguous() for k, v in eps.items()}
         if update_feat_shapes:                       # nets/ssd_vgg_512.py:134-136: the feature shapes follow the predictions
             self.update_feature_shapes(predictions)
         return predictions, localisations, logits, eps
@@ -113,3 +119,35 @@ class SSDNet(RONNet):
         """forward + np_methods post-processing (no objectness gate for SSD)."""
         return RONNet.detect(self, inputs, objectness_thres=0.0, select_threshold=select_threshold,
                              nms_threshold=nms_threshold, top_k=top_k, bbox_img=bbox_img, out=out)
+
+
+# ---------------------------------------------------------------------- the reference's function entries (nets_factory.networks_map)
+def ssd_net(inputs, num_classes=SSDNet.default_params.num_classes, feat_layers=SSDNet.default_params.feat_layers,
+            anchor_sizes=SSDNet.default_params.anchor_sizes, anchor_ratios=SSDNet.default_params.anchor_ratios,
+            normalizations=SSDNet.default_params.normalizations, is_training=True, dropout_keep_prob=0.5, prediction_fn=None,
+            reuse=None, scope='ssd_512_vgg', weights=None, dtype='bf16', max_batch=16):
+    """SSD net definition (nets/ssd_vgg_512.py:364-460): (predictions, localisations, logits, end_points).  A scope name owns one
+    network object, like ron_vgg_320.ron_net: the first call needs `weights=`."""
+    params = SSDNet.default_params._replace(num_classes=num_classes, feat_layers=list(feat_layers), anchor_sizes=list(anchor_sizes),
+                                            anchor_ratios=list(anchor_ratios), normalizations=list(normalizations))
+    dev = inputs.device if inputs.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    key = (scope, 'ssd512', num_classes, dtype, str(dev))
+    net = ron_vgg_320._scoped_net(key, lambda: SSDNet(params, dtype=dtype, max_batch=max(max_batch, inputs.shape[0]), device=dev), weights, reuse)
+    fmt = ron_vgg_320._ARG_SCOPE_FORMAT[-1] if ron_vgg_320._ARG_SCOPE_FORMAT else 'NHWC'
+    with ron_vgg_320._DataFormatScope([net], fmt):
+        return net.net(inputs, is_training=is_training, update_feat_shapes=False, dropout_keep_prob=dropout_keep_prob,
+                       prediction_fn=prediction_fn, reuse=reuse, scope=scope)
+
+
+ssd_net.default_image_size = 512
+
+
+def ssd_arg_scope(weight_decay=0.0005, data_format='NHWC'):
+    """Defines the VGG arg scope (nets/ssd_vgg_512.py:463-487)."""
+    return ron_vgg_320._ArgScope(weight_decay, True, data_format)
+
+
+def ssd_arg_scope_caffe(caffe_scope):
+    """nets/ssd_vgg_512.py:490-513 takes the Caffe weight initialisers from `caffe_scope`; initialisers have no meaning for an
+    inference graph whose weights are loaded: the scope is the plain one."""
+    return ron_vgg_320._ArgScope()

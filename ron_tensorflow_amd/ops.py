@@ -196,6 +196,24 @@ def bboxes_decode_layer(loc, anchor_dev, prior_scaling=(0.1, 0.1, 0.2, 0.2)):
     return out
 
 
+def bboxes_filter_min(scores, bboxes, top_k, minsize=0.03):
+    """RONNet.bboxes_filter_min on tensors (nets/ron_vgg_320.py:217-233): scores [B, N], bboxes [B, N, 4] -> per list the rows with
+    w > minsize and h > minsize in their order (tf.boolean_mask), zero padded to top_k rows - or to the longest list's count when that
+    is larger (tfe_tensors.pad_axis only ever pads).  The reference squeezes axis 0, i.e. takes B = 1; any B works here.
+    The output length depends on the data, so this call reads the counts back (one host synchronisation), like a TF session run."""
+    scores = scores.to(torch.float32).contiguous()
+    bboxes = bboxes.to(torch.float32).contiguous()
+    assert scores.dim() == 2 and bboxes.shape == scores.shape + (4,), 'scores [B, N], bboxes [B, N, 4]'
+    b, n = scores.shape
+    rows = max(n, int(top_k))
+    out_s = torch.empty((b, rows), dtype=torch.float32, device=scores.device)
+    out_b = torch.empty((b, rows, 4), dtype=torch.float32, device=scores.device)
+    counts = torch.empty((b,), dtype=torch.int32, device=scores.device)
+    check(lib().ron_bboxes_filter_min(ptr(scores), ptr(bboxes), b, n, float(minsize), ptr(out_s), ptr(out_b), rows, ptr(counts), current_stream()))
+    keep = max(int(counts.max().item()), int(top_k))
+    return out_s[:, :keep], out_b[:, :keep]
+
+
 def softmax_last(x, pick=-1):
     """slim.softmax over the last axis; pick >= 0 keeps only that channel (shape [..., 1])."""
     x = x.contiguous()
@@ -226,6 +244,21 @@ def conv2d_nhwc(x, w, bias=None, residual=None, stride=1, dilation=1, relu=True,
     r = None if residual is None else residual.contiguous()
     check(lib().ron_conv2d_nhwc(C.byref(d), ptr(x), ptr(w), ptr(b), ptr(r), ptr(y), current_stream()))
     return y
+
+
+def conv2d_heads_nhwc(x, w, split_first, bias=None, dilation=1, relu=False, dtype='bf16', tile_cfg=-1, splitk=-1):
+    """One convolution, two fp32 head tensors (ron_conv2d_heads_nhwc: what the SSD-512 graph does with the class and box convolutions of
+    a feature layer, nets/ssd_vgg_300.py:403-431): w HWIO with cout = both heads' channels, the first `split_first` of them -> y_first."""
+    x = x.contiguous()
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    n, h, wd, cin = x.shape
+    kh, kw, _, cout = w.shape
+    d = _lib.ConvDesc(n, h, wd, cin, cout, kh, kw, 1, dilation, int(relu), 0, _lib.DTYPES[dtype], tile_cfg, 0, 0, 0, splitk, 0)
+    y1 = torch.empty((n, h, wd, split_first), dtype=torch.float32, device=x.device)
+    y2 = torch.empty((n, h, wd, cout - split_first), dtype=torch.float32, device=x.device)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    check(lib().ron_conv2d_heads_nhwc(C.byref(d), int(split_first), ptr(x), ptr(w), ptr(b), ptr(y1), ptr(y2), current_stream()))
+    return y1, y2
 
 
 def maxpool2x2_nhwc(x, dtype='bf16'):

@@ -117,11 +117,12 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
     After the timed region every rank compares the slice of `gathered` that is its own with its local records and checks
     every rank's counts; the verdict is the MIN over ranks, so one bad rank makes it 'MISMATCH' everywhere.
 
-    `window` > 0 (bench.py's sustained leg): a mark goes onto the consuming stream in front of the timed steps and after every `window`
-    of them (a timing event behind the consumption of the batch that has just been waited for: with F batches in flight the mark of step
-    i stands behind batch i - F + 1, so consecutive marks are exactly `window` batches apart), and `window_ms` holds the time between
-    consecutive marks - how the rate develops over a run of seconds without the host ever waiting inside it.  `make_mark()` /
-    `mark_ms(a, b)` default to torch timing events (the gloo test passes host clocks).
+    `window` > 0 (bench.py's sustained leg): a mark goes onto the consuming stream after every `window` timed steps (a timing event
+    behind the consumption of the batch that has just been waited for: with F batches in flight the mark of step i stands behind batch
+    i - F + 1, so consecutive marks are exactly `window` batches apart), and `window_ms` holds the time between consecutive marks - how
+    the rate develops over a run of seconds without the host ever waiting inside it; the first `window` steps lead up to the first mark
+    and have no entry (a mark in front of the first submission sits on an idle stream: its timestamp came 0.15 s late when tried).
+    `make_mark()` / `mark_ms(a, b)` default to torch timing events (the gloo test passes host clocks).
 
     Returns dict(dt, det (this rank's last detections), gathered, gather_check ('ok' | 'MISMATCH' | None), rank_dt (every rank's own
     time of the timed region), gather_ms (one all-gather of the records alone, after the timed region), window_ms (list, or None))."""
@@ -183,8 +184,6 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
         before_timed()
     synchronize()
     t0 = time.perf_counter()
-    if window > 0:
-        mark()
     for i in range(steps):
         step()
         if window > 0 and (i + 1) % window == 0:

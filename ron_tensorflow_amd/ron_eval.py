@@ -30,15 +30,21 @@ def post_eval(cls, obj, loc, anchors_dev, image_shapes, num_classes=21, objectne
               loc_decoded=True, nms_by_class=False):
     """Per-layer lists of GPU tensors in (the outputs of ``RONNet.net`` + ``bboxes_decode`` by default), DetectionBuffers
     out: ``classes`` = labels, rows in score order, ``count`` <= keep_top_k.  Defaults are ron_eval.py's flags (:82-92).
-    ``nms_by_class``: ``tf_bboxes_nms_by_class_v1`` (ron_eval.py:282-366, the variant behind the commented call of :474) instead of
-    ``tf_bboxes_nms``: a kept box only suppresses boxes of its own label."""
+    ``nms_by_class``: True or 'v1' = ``tf_bboxes_nms_by_class_v1`` (ron_eval.py:282-366) instead of ``tf_bboxes_nms``: a kept box
+    only suppresses boxes of its own label.  'scores' = ``tf_bboxes_nms_by_class`` (ron_eval.py:212-280, the function the commented call
+    of :474 names): every score column (objectness x class probability, background included) runs its own greedy NMS with at most
+    ``keep_top_k`` picks; a row some column kept comes back with the largest of its kept scores and that column as its class, rows in
+    the flattened ANCHOR order, up to num_classes * keep_top_k of them (the buffers get that capacity)."""
+    if nms_by_class not in (False, True, 'v1', 'scores'):
+        raise ValueError("nms_by_class must be False, True / 'v1' or 'scores'")
+    per_column = nms_by_class == 'scores'
     if nms_mode not in NMS_MODES:
         raise ValueError('unknown mode to use for nms.')          # ron_eval.py:188
     n, dev = cls[0].shape[0], cls[0].device
     heads, keep = _fill_heads(cls, obj, loc, None if loc_decoded else anchors_dev, num_classes)
     cfg = EvalCfg()
     cfg.objectness_thres, cfg.select_threshold, cfg.nms_threshold = objectness_thres, select_threshold, nms_threshold
-    cfg.keep_top_k, cfg.nms_mode = keep_top_k, NMS_MODES[nms_mode] | (2 if nms_by_class else 0)
+    cfg.keep_top_k, cfg.nms_mode = keep_top_k, NMS_MODES[nms_mode] | (4 if per_column else 2 if nms_by_class else 0)
     for i in range(4):
         cfg.bbox_img[i] = bbox_img[i]
         cfg.prior_scaling[i] = prior_scaling[i]
@@ -46,11 +52,11 @@ def post_eval(cls, obj, loc, anchors_dev, image_shapes, num_classes=21, objectne
                        (_lib.RON_IN_LOC_DECODED if loc_decoded else 0))
     ms = torch.from_numpy(filter_min_size(image_shapes, net_input_shape, min_size_ratio)).to(dev)
     assert ms.shape[0] == n, 'one (height, width) per image'
-    nbytes = lib().ron_post_eval_workspace_bytes(C.byref(heads), n)
+    nbytes = lib().ron_post_eval_workspace_bytes_mode(C.byref(heads), n, cfg.nms_mode)
     if nbytes < 0:
         check(-1)
     ws = _workspace(dev, nbytes)
-    out = DetectionBuffers(n, keep_top_k, dev)
+    out = DetectionBuffers(n, num_classes * keep_top_k if per_column else keep_top_k, dev)
     oc = out.c_struct()
     check(lib().ron_post_eval(C.byref(heads), n, ptr(ms), C.byref(cfg), ptr(ws), nbytes, C.byref(oc), current_stream()))
     del keep

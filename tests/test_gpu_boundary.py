@@ -1,0 +1,119 @@
+"""GPU: the rest of the reference's interface for the path - RONNet.bboxes_filter_min as a method,
+nets_factory.networks_map / arg_scopes_map with the module-level network functions, data_format='NCHW'."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import tfe_post  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def weights_reduced():
+    from ron_tensorflow_amd.weights import synthetic_weights
+    return synthetic_weights('reducedfc', seed=1)
+
+
+@pytest.mark.parametrize('n,top_k,minsize', [(21250, 400, 0.03), (1500, 400, 0.03), (300, 400, 0.03), (5000, 200, 0.2), (777, 50, 2.0),
+                                             (1024, 10, 0.0), (1, 4, 0.03)])
+def test_bboxes_filter_min_matches_oracle(dev, n, top_k, minsize):
+    """nets/ron_vgg_320.py:196-233 vs oracle/tfe_post.bboxes_filter_min: same rows in the same order, zero padded to top_k, not
+    truncated when more pass; tensors and dicts."""
+    from ron_tensorflow_amd.nets import nets_factory
+    rs = np.random.RandomState(n + top_k)
+    ymin, xmin = rs.uniform(0, .9, (n,)).astype(np.float32), rs.uniform(0, .9, (n,)).astype(np.float32)
+    h = rs.uniform(-.02, .12, (n,)).astype(np.float32)                     # some inverted, many under 0.03
+    w = rs.uniform(-.02, .12, (n,)).astype(np.float32)
+    b = np.stack([ymin, xmin, ymin + h, xmin + w], -1)[None]
+    s = rs.uniform(0, 1, (1, n)).astype(np.float32)
+    net = nets_factory.get_network('ron_320_vgg')(variant='reducedfc', dtype='fp32', max_batch=1, device=dev)
+    gs, gb = net.bboxes_filter_min(torch.from_numpy(s).to(dev), torch.from_numpy(b).to(dev), top_k, minsize=minsize)
+    rs_, rb = tfe_post.bboxes_filter_min(s, b, top_k, minsize=minsize)
+    assert tuple(gs.shape) == rs_.shape and tuple(gb.shape) == rb.shape
+    assert np.array_equal(gs.cpu().numpy(), rs_) and np.array_equal(gb.cpu().numpy(), rb)
+    # dictionaries: every key a class (:208-216)
+    ds = {1: torch.from_numpy(s).to(dev), 7: torch.from_numpy(s[:, ::-1].copy()).to(dev)}
+    db = {1: torch.from_numpy(b).to(dev), 7: torch.from_numpy(b[:, ::-1].copy()).to(dev)}
+    os_, ob = net.bboxes_filter_min(ds, db, top_k, minsize=minsize)
+    assert sorted(os_.keys()) == [1, 7]
+    r7 = tfe_post.bboxes_filter_min(s[:, ::-1], b[:, ::-1], top_k, minsize=minsize)
+    assert np.array_equal(os_[1].cpu().numpy(), rs_) and np.array_equal(os_[7].cpu().numpy(), r7[0]) and np.array_equal(ob[7].cpu().numpy(), r7[1])
+
+
+def test_bboxes_filter_min_batched_lists(dev):
+    """More than one list per call (the reference squeezes axis 0, i.e. takes one): every list is filtered on its own and the result is
+    as long as the longest one needs."""
+    from ron_tensorflow_amd import ops
+    rs = np.random.RandomState(5)
+    n = 3000
+    b = rs.uniform(0, 1, (3, n, 4)).astype(np.float32)
+    b[..., 2:] = b[..., :2] + rs.uniform(0, .06, (3, n, 2)).astype(np.float32)
+    b[2, :, 2:] = b[2, :, :2] + 0.5                                        # every row of list 2 passes: longer than top_k
+    s = rs.uniform(0, 1, (3, n)).astype(np.float32)
+    gs, gb = ops.bboxes_filter_min(torch.from_numpy(s).to(dev), torch.from_numpy(b).to(dev), 400)
+    assert gs.shape[1] == n
+    for i in range(3):
+        r_s, r_b = tfe_post.bboxes_filter_min(s[i:i + 1], b[i:i + 1], n)
+        assert np.array_equal(gs[i].cpu().numpy(), r_s[0]) and np.array_equal(gb[i].cpu().numpy(), r_b[0])
+
+
+def test_networks_map_and_arg_scopes_map(dev, weights_reduced):
+    """nets/nets_factory.py:34-52: the function entries.  networks_map['ron_320_vgg'] is ron_net (full fc6 / fc7); ron_net_reducedfc is the
+    module function RONNet.net builds (:144).  A scope name owns the variables: the first call loads them, reuse=True finds them."""
+    from ron_tensorflow_amd.nets import nets_factory, ron_vgg_320, ssd_vgg_512
+    from ron_tensorflow_amd.weights import synthetic_images
+    assert nets_factory.networks_map['ron_320_vgg'] is ron_vgg_320.ron_net
+    assert nets_factory.networks_map['ssd_512_vgg'] is ssd_vgg_512.ssd_net and nets_factory.networks_map['ssd_512_vgg_caffe'] is ssd_vgg_512.ssd_net
+    assert nets_factory.arg_scopes_map['ron_320_vgg'] is ron_vgg_320.ron_arg_scope
+    assert nets_factory.arg_scopes_map['ssd_512_vgg'] is ssd_vgg_512.ssd_arg_scope
+    assert ron_vgg_320.ron_net.default_image_size == 320 and ssd_vgg_512.ssd_net.default_image_size == 512
+    x = torch.from_numpy(synthetic_images(1, seed=0)).to(dev)
+    with pytest.raises(ValueError):
+        ron_vgg_320.ron_net_reducedfc(x, scope='never_made', reuse=True)
+    with pytest.raises(ValueError):
+        ron_vgg_320.ron_net_reducedfc(x, scope='no_weights_yet')
+    with nets_factory.arg_scopes_map['ron_320_vgg'](is_training=False):
+        out = ron_vgg_320.ron_net_reducedfc(x, num_classes=21, is_training=False, scope='t_map', weights=weights_reduced, dtype='fp32', max_batch=1)
+    assert len(out) == 6 and tuple(out[0][3].shape) == (1, 40, 40, 10, 21) and tuple(out[2][0].shape) == (1, 5, 5, 10, 1)
+    again = ron_vgg_320.ron_net_reducedfc(x, num_classes=21, is_training=False, scope='t_map', reuse=True, dtype='fp32', max_batch=1)
+    for a, b in zip(out[1], again[1]):
+        assert torch.equal(a, b)
+    # the same numbers as the class interface
+    cls = nets_factory.get_network('ron_320_vgg')
+    net = cls(cls.default_params, variant='reducedfc', dtype='fp32', max_batch=1, device=dev)
+    net.load_weights(weights_reduced)
+    ref = net.net(x, is_training=False)
+    for a, b in zip(out[1], ref[1]):
+        assert torch.equal(a, b)
+    net.close()
+
+
+def test_data_format_nchw(dev, weights_reduced):
+    """arg_scope(data_format='NCHW') (nets/ron_vgg_320.py:156-159, ron_eval.py:34): [N, 3, H, W] images in, the same heads out
+    (channel-last either way, :401 / :412), end points as [N, C, H, W]; outside the context the network is NHWC again."""
+    from ron_tensorflow_amd.nets import nets_factory
+    from ron_tensorflow_amd.weights import synthetic_images
+    cls = nets_factory.get_network('ron_320_vgg')
+    net = cls(cls.default_params, variant='reducedfc', dtype='fp32', max_batch=2, device=dev)
+    net.load_weights(weights_reduced)
+    x = torch.from_numpy(synthetic_images(2, seed=0)).to(dev)
+    ref = net.net(x, is_training=False, end_points=('block5',))
+    with net.arg_scope(is_training=False, data_format='NCHW'):
+        got = net.net(x.permute(0, 3, 1, 2).contiguous(), is_training=False, end_points=('block5',))
+        det_nchw = net.detect(x.permute(0, 3, 1, 2).contiguous())
+    for a, b in zip(got[1] + got[3] + got[4], ref[1] + ref[3] + ref[4]):
+        assert torch.equal(a, b)
+    assert tuple(got[5]['block5'].shape) == (2, 512, 20, 20)
+    assert torch.equal(got[5]['block5'].permute(0, 2, 3, 1), ref[5]['block5'])
+    det = net.detect(x)
+    assert torch.equal(det.count, det_nchw.count) and torch.equal(det.anchor_index, det_nchw.anchor_index)
+    with pytest.raises(ValueError):
+        net.arg_scope(data_format='NCWH')
+    net.close()

@@ -590,3 +590,35 @@ def test_tile_256x128_split_k_and_one_round_launches(ops, dev, dtype):
     # ... and with the fused 2x2 max-pool
     pooled = ops.conv2d_nhwc(x2d, w2, b2, relu=True, dtype=dtype, tile_cfg=-1, pool=True)
     assert np.array_equal(pooled.cpu().numpy(), ops.maxpool2x2_nhwc(torch.from_numpy(auto).to(dev), dtype=dtype).cpu().numpy())
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'f16x3'])
+@pytest.mark.parametrize('splitk', [1, 3, -1])
+@pytest.mark.parametrize('cfg', [-1, 1, 0, 10])
+@pytest.mark.parametrize('heads', [(84, 16), (486, 24), (21, 4), (126, 24)], ids=lambda h: '%d+%d' % h)
+def test_two_head_outputs_from_one_convolution(ops, dev, heads, cfg, splitk, dtype):
+    """ConvArgs::split_n (the class + box convolutions of an SSD feature layer as one launch, nets/ssd_vgg_300.py:403-431; only the SSD-512
+    graph reached it before): against two separate convolutions of the oracle, over tile configurations, forced split-K (the finalize
+    pass routes the columns too) and class counts whose first head is NOT a multiple of 8 columns (81 classes x 6 anchors = 486,
+    21 x 4 = 84, 21 x 1 = 21; 126 = 6 x 21)."""
+    from ron_tensorflow_amd._lib import RonError
+    n_cls, n_loc = heads
+    if cfg == 10 and dtype == 'fp32':
+        pytest.skip('the 256 x 128 tile is the assembly loop of the 16-bit types')
+    rs = np.random.RandomState(n_cls + 7 * max(cfg, 0))
+    cin = 128
+    x = rs.randn(2, 8, 8, cin).astype(np.float32)
+    wt = (rs.randn(3, 3, cin, n_cls + n_loc) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rs.randn(n_cls + n_loc) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = orf.conv2d_np(rnd(x), rnd(wt)) + b
+    npad = -(-((-(-n_cls // 8) * 8) + n_loc) // 128) * 128
+    try:
+        y1, y2 = ops.conv2d_heads_nhwc(torch.from_numpy(x).to(dev), wt, n_cls, bias=b, dtype=dtype, tile_cfg=cfg, splitk=splitk)
+    except RonError:
+        # a forced tile must divide the packed width (256-wide tiles: Npad % 256)
+        assert (cfg == 0 and npad % 256 != 0) or (cfg == 10 and npad % 128 != 0)
+        return
+    assert tuple(y1.shape) == (2, 8, 8, n_cls) and tuple(y2.shape) == (2, 8, 8, n_loc)
+    _check(y1.cpu().numpy(), ref[..., :n_cls], dtype)
+    _check(y2.cpu().numpy(), ref[..., n_cls:], dtype)

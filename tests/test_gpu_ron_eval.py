@@ -27,10 +27,11 @@ CASES = [  # seed, batch, bg, ob, obj_thr, sel_thr, nms_thr, keep_top_k, mode
 ]
 
 
-@pytest.mark.parametrize('by_class', [False, True], ids=['agnostic', 'by_class'])
+@pytest.mark.parametrize('by_class', [False, True, 'scores'], ids=['agnostic', 'by_class', 'by_class_scores'])
 @pytest.mark.parametrize('case', CASES, ids=lambda c: 'seed%d' % c[0])
 def test_post_eval_matches_oracle(case, by_class):
-    """by_class: tf_bboxes_nms_by_class_v1 (ron_eval.py:282-366) instead of tf_bboxes_nms (:146-206)."""
+    """by_class True: tf_bboxes_nms_by_class_v1 (ron_eval.py:282-366) instead of tf_bboxes_nms (:146-206); 'scores': tf_bboxes_nms_by_class
+    (:212-280), one NMS per score column, rows back in anchor order."""
     from ron_tensorflow_amd import ops, ron_eval
     seed, batch, bg, ob, obj_thr, sel_thr, nms_thr, keep, mode = case
     dev = torch.device('cuda:0')
@@ -75,3 +76,21 @@ def test_unknown_mode_raises():
     from ron_tensorflow_amd import ron_eval
     with pytest.raises(ValueError):
         ron_eval.post_eval([torch.zeros((1, 1, 1, 1, 21), device='cuda')], None, None, None, [(1, 1)], nms_mode='iou')
+
+
+def test_by_class_scores_hand_case_on_device():
+    """The hand case of tests/test_oracle_ron_eval.py::test_by_class_scores_variant_hand_case through ron_post_eval (nms_mode | 4): a row
+    relabelled by the column that kept it, a row kept by the background column, rows in anchor order."""
+    from ron_tensorflow_amd import ron_eval
+    dev = torch.device('cuda:0')
+    pred = np.array([[.10, .50, .40], [.10, .45, .45], [.05, .15, .80], [.40, .45, .15], [.30, .55, .15]], np.float32).reshape(1, 1, 1, 5, 3)
+    obj = np.array([.99, .98, .97, .96, .995], np.float32).reshape(1, 1, 1, 5, 1)
+    box = np.array([[.1, .1, .5, .5], [.12, .1, .5, .5], [.6, .6, .9, .9], [.1, .6, .4, .9], [.11, .6, .4, .9]], np.float32).reshape(1, 1, 1, 5, 4)
+    det = ron_eval.post_eval(_to_dev([pred], dev), _to_dev([obj], dev), _to_dev([box], dev), None, [(320, 320)], num_classes=3,
+                             objectness_thres=0.95, select_threshold=0.3, nms_threshold=0.4, keep_top_k=20, nms_by_class='scores')
+    g = det.to_lists()[0]
+    ref = rp.post_eval_image([pred[0]], [obj[0]], [box[0]], (320, 320), objectness_thres=0.95, select_threshold=0.3, nms_threshold=0.4,
+                             keep_top_k=20, nms_by_class='scores')
+    assert g['anchor_index'].tolist() == [0, 1, 2, 3, 4] and g['classes'].tolist() == [1, 2, 2, 0, 1]
+    assert np.array_equal(g['scores'], ref['scores']) and np.array_equal(g['bboxes'], ref['bboxes'])
+    assert det.capacity == 3 * 20

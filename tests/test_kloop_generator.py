@@ -72,3 +72,6 @@ def test_loop_properties():
                 used_s.update(range(int(a), int(b) + 1))
         declared_s = set(int(x) for x in re.findall(r'"s(\d+)"', clob)) | set(range(36, 45))
         assert used_s <= declared_s, (name, sorted(used_s - declared_s))
+        # ... M0 included: the loop rewrites it for every LDS-DMA piece
+        assert any(re.search(r'\bm0\b', l) and l.split()[0] in ('s_mov_b32', 's_add_u32') for l in lines), name
+        assert '"m0"' in clob, 'the loop writes M0: it must be among the clobbers'

@@ -145,14 +145,14 @@ def test_bench_loop_world2(corrupt_rank):
     assert r0['dt'] >= 4 * 0.02                                               # ... and it is the slow rank's (4 steps x 20 ms)
     want = 'ok' if corrupt_rank < 0 else 'MISMATCH'
     assert r0['gather_check'] == want and r1['gather_check'] == want          # one bad rank fails the check on every rank
-    # the sustained leg: 6 steps in windows of 2 -> 3 window times that add up to (almost) the leg's time; MAX over ranks; nothing else
+    # the sustained leg: 6 steps in windows of 2 -> 3 marks, 2 window times, within the leg's time; MAX over ranks; nothing else
     for r in (r0, r1):
         s = r['sustained']
-        assert s['steps'] == 6 and len(s['window_ms']) == 3 and all(w >= 0 for w in s['window_ms'])
+        assert s['steps'] == 6 and len(s['window_ms']) == 2 and all(w >= 0 for w in s['window_ms'])
         assert s['gather_check'] is None and s['gather_ms'] is None
         assert sum(s['window_ms']) * 1e-3 <= s['dt'] + 1e-3
     assert r0['sustained']['dt'] == r1['sustained']['dt'] and r1['sustained']['dt'] >= 6 * 0.02
-    assert sum(r1['sustained']['window_ms']) >= 4 * 20 - 1                    # rank 1 sleeps 20 ms per submission
+    assert sum(r1['sustained']['window_ms']) >= 3 * 20 - 1                    # rank 1 sleeps 20 ms per submission
 
 
 def test_bench_loop_world8():

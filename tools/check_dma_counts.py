@@ -15,7 +15,10 @@ Round 3 found the compiler merging identical placeholder instructions of the pat
 left the first step's wait two short and showed only as run-to-run differences.  This tool compiles the two files to assembly
 (about a minute) and checks every instantiation; tests/test_isa_protocol.py runs it in the CPU suite, so a ROCm bump that changes
 the emitted counts fails a test, not a soak run.
-    python tools/check_dma_counts.py"""
+    python tools/check_dma_counts.py
+    python tools/check_dma_counts.py --asm <device .s kept by hipcc -save-temps> conv_mfma4w.hip     (what `make` runs on the four-wave tiles:
+        their epilogue reads accumulation registers the K loop's assembly only declares as clobbers, so "compiler code touches no
+        accumulation register behind the loop" is a property every build has to re-establish, not just the test suite)"""
 import os
 import re
 import subprocess
@@ -206,9 +209,14 @@ def describe(name):
     return '%-5s %-26s <%s%s>' % (tr, kind, ', '.join(str(i) for i in template_ints(name)), extra)
 
 
-def check_file(source):
-    """[(description, [problems])] for every conv kernel instantiation of csrc/<source>."""
-    ks = kernels(compile_asm(source))
+def check_file(source, asm_path=None):
+    """[(description, [problems])] for every conv kernel instantiation of csrc/<source> (compiled here, or the device assembly the
+    build kept: `asm_path`)."""
+    if asm_path is not None:
+        with open(asm_path) as f:
+            ks = kernels(f.read())
+    else:
+        ks = kernels(compile_asm(source))
     out = []
     for name, lines in sorted(ks.items()):
         fn = check_patch if 'conv3x3_patch' in name else check_igemm
@@ -223,8 +231,13 @@ EXPECTED = {'conv_patch.hip': 4 * (3 + 3), 'conv_mfma.hip': 4 * (4 + 3 + 1), 'co
 
 def main():
     bad = 0
-    for source in ('conv_patch.hip', 'conv_mfma.hip', 'conv_mfma4w.hip'):
-        res = check_file(source)
+    asm = None
+    sources = ('conv_patch.hip', 'conv_mfma.hip', 'conv_mfma4w.hip')
+    if len(sys.argv) == 4 and sys.argv[1] == '--asm':
+        # the Makefile's build step: check the device assembly of the object being built (hipcc -save-temps), one source
+        asm, sources = sys.argv[2], (sys.argv[3],)
+    for source in sources:
+        res = check_file(source, asm)
         for desc, problems in res:
             print('%s: %s' % (desc, 'ok' if not problems else '; '.join(problems)))
             bad += len(problems)

@@ -278,7 +278,9 @@ def main():
         # touches no accumulation register between the loop and the last of those reads
         clob = ['"s%d"' % r for r in range(48, 65)] + ['"v%d"' % r for r in list(range(84, 100)) + list(range(121, 256))]
         clob_a = ['"a%d"' % r for r in range(256)]
-        f.write('#define RON_KLOOP4W_CLOBBERS "memory", "scc", %s, %s\n' % (', '.join(clob), ', '.join(clob_a)))
+        # m0: every LDS-DMA piece's LDS destination goes through it (s_mov_b32 m0 / s_add_u32 m0), and the compiler may hold a value of
+        # its own there across an asm statement that does not name it
+        f.write('#define RON_KLOOP4W_CLOBBERS "memory", "scc", "m0", %s, %s\n' % (', '.join(clob), ', '.join(clob_a)))
     print('wrote', out)
 
 

@@ -92,7 +92,7 @@ def main():
     steps = int(np.ceil(a.seconds * 1e3 / ms / 100)) * 100
     res = parallel.bench_loop(pipe, images, steps, 0, a.in_flight, args, 400, device=dev, window=100)
     s = summarize(ring.cpu().numpy(), 'sustained: last steps of %d (%.2f s)' % (steps, res['dt']), a.batch * steps / res['dt'])
-    s['window_images_per_s'] = [round(100 * a.batch / (w * 1e-3), 1) for w in res['window_ms']]
+    s["window_images_per_s"] = [round(100 * a.batch / (w * 1e-3), 1) for w in res['window_ms']]
     phases.append(s)
     lib.ron_debug_stamps(C.c_void_p(0))
     out = {'dtype': a.dtype, 'batch': a.batch, 'in_flight': a.in_flight, 'library': os.environ.get('RON_HIP_LIB', ''), 'phases': phases,
