@@ -96,7 +96,15 @@ __device__ __forceinline__ void igemm_finish(const ConvArgs& p, const Reader& rd
 // launch: wave-uniform bookkeeping of a few scalar instructions per step.
 // One tile of launch `p`: workgroup `bid` of the `nwg` that launch consists of (a launch of its own, or a range of the
 // workgroups of a grouped launch).
-constexpr int kPanelCols = 8;      // ConvArgs::m_fastest == 2
+// ConvArgs::m_fastest >= 2 = the width of a panel in column tiles (four-wave tiles only)
+// tile index inside a run of `cols` column tiles x `tiles_m` row tiles -> (row tile, column tile), panels of `P` columns walked row by
+// row: the 32 tiles an XCD runs at a time are 32 / P rows x P columns
+__device__ __forceinline__ void panel_tile(unsigned t, unsigned tiles_m, unsigned cols, unsigned P, int* tile_m, int* tile_n) {
+  const unsigned per_panel = tiles_m * P, panel = t / per_panel, r = t - panel * per_panel;
+  const unsigned width = min(P, cols - panel * P);
+  *tile_m = (int)(r / width);
+  *tile_n = (int)(panel * P + r - (r / width) * width);
+}
 
 template <class Tr, int BM, int BN, int WM, int WN, int S, int SPREAD>
 __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigned bid, const unsigned nwg, char* smem) {
@@ -144,15 +152,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
   const unsigned tiles_m = (unsigned)p.tiles_total / (unsigned)p.tiles_n;
   int tile_n = (int)(p.m_fastest ? tile / tiles_m : tile % (unsigned)p.tiles_n);
   int tile_m = (int)(p.m_fastest ? tile % tiles_m : tile / (unsigned)p.tiles_n);
-  if constexpr (kAsmLoop) if (p.m_fastest == 2) {
+  if constexpr (kAsmLoop) if (p.m_fastest >= 2) {
     // (four-wave tiles only - the launches wide and tall enough are theirs; compiled into every tile the two divisions cost the
     // small-batch launches 1-2 us each through the other tiles' register allocation: batch 4 1.24 -> 1.29 ms, measured round 5)
-    // panels of kPanelCols column tiles, walked row by row: the 32 tiles an XCD runs at a time are 4 rows x 8 columns (12 operand
-    // streams instead of 1 + 32 on a wide launch)
-    const unsigned per_panel = tiles_m * kPanelCols, panel = tile / per_panel, r = tile - panel * per_panel;
-    const unsigned width = min((unsigned)kPanelCols, (unsigned)p.tiles_n - panel * kPanelCols);
-    tile_m = (int)(r / width);
-    tile_n = (int)(panel * kPanelCols + r - (r / width) * width);
+    // panels of m_fastest column tiles, walked row by row: with 8 the 32 tiles an XCD runs at a time are 4 rows x 8 columns (12
+    // operand streams instead of 1 + 32 on a wide launch), with 2 they are 16 x 2 (the weights of two column tiles stream per round)
+    panel_tile(tile, tiles_m, (unsigned)p.tiles_n, (unsigned)p.m_fastest, &tile_m, &tile_n);
   }
   if (p.center_from_n > 0 && p.splitk == 1) {
     // Column tiles that run the centre tap only (a 1x1 branch beside 3x3 ones) are short: a ninth of the K steps plus a whole
@@ -166,6 +171,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& p, const unsigne
       const unsigned xq = n_long >> 3, xr = n_long & 7u;
       const unsigned t = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
       tile_m = (int)(t / cols_long); tile_n = (int)(t % cols_long);
+      if constexpr (kAsmLoop) if (p.m_fastest >= 2) panel_tile(t, tiles_m, cols_long, (unsigned)p.m_fastest, &tile_m, &tile_n);
     } else {
       const unsigned b2 = bid - n_long, n_short = nwg - n_long;
       const unsigned x2 = b2 & 7u, xq = n_short >> 3, xr = n_short & 7u;

@@ -130,6 +130,7 @@ int conv_pick_igemm_cfg(int M, int Npad, int taps, int K, bool may_split) {
 // 16 column tiles of 12.8 MB of weights each - N fastest makes every XCD stream all 205 MB: 1.66 GB fetched per launch, 0.65 GB
 // M fastest, 566 -> 541 us; fc7 113 -> 102 us).  Forced on every launch it costs the activation-heavy layers 2-4 %; walking the
 // column tiles of an XCD's rows in blocks of 1-3 instead changed nothing (both measured, not kept).
+constexpr int kPanelCols = 8;      // the panel width of wide and tall launches (plain GEMM shapes)
 static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int tiles_n, int splitk, int panel_steps) {
   // split-K: the workgroups of one K slice are consecutive, an XCD's run then covers (nearly) every tile of its slices either way
   if (tiles_m < 2 || tiles_n < 2 || splitk > 1) return 0;
@@ -145,10 +146,18 @@ static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int 
   // batch 4: the groups that carry block4 / block5_deconv_right 8-10 us slower in panel order)
   // Only the four-wave tiles decode it (conv_igemm_tile): `panel_steps` = the K steps of a workgroup when the launch may go to
   // them, 0 when it may not (members of a grouped launch).
-  if (BM == 256 && c.dtype != RON_DTYPE_F32 && panel_steps > 0 && asm_loop_ok(panel_steps) && tiles_n >= 2 * kPanelCols && tiles_m >= 8 && c.center_from == 0 && c.up == 0) {
+  const bool panels_ok = BM == 256 && c.dtype != RON_DTYPE_F32 && panel_steps > 0 && asm_loop_ok(panel_steps) && c.up == 0;
+  // experiments (tools/experiments/r06_calls/r06_panels.sh): RON_PANEL_COLS = P forces panels of P column tiles on every launch that
+  // can decode them (P = 1: row tiles fastest, 0: column tiles fastest)
+  static const char* force = getenv("RON_PANEL_COLS");
+  if (force != nullptr && panels_ok) {
+    const int P = atoi(force), cols = c.center_from > 0 ? c.center_from / BN : tiles_n;     // (centre-tap-only columns: panels among the long ones)
+    return P >= cols ? 0 : P;
+  }
+  if (panels_ok && tiles_n >= 2 * kPanelCols && tiles_m >= 8 && c.center_from == 0) {
     const double cost_p = std::min(tiles_m, per_xcd / kPanelCols + 1) * a_tile +
                           std::min(tiles_n, kPanelCols * (per_xcd / (tiles_m * kPanelCols) + 1)) * b_tile;
-    if (cost_p < 0.9 * std::min(cost_n, cost_m)) return 2;
+    if (cost_p < 0.9 * std::min(cost_n, cost_m)) return kPanelCols;
   }
   return cost_m < 0.95 * cost_n ? 1 : 0;
 }
@@ -503,6 +512,12 @@ int launch_conv_group(const ConvLaunch* ls_in, int n, int cfg, void* scratch, in
   }
   ConvLaunch ls[kMaxConvGroup];
   for (int k = 0; k < n; ++k) { ls[k] = ls_in[order[k]]; sks[k] = sks_in[order[k]]; }
+  // the 256 x 256 group runs on the four-wave tiles (which decode panel tile orders) when every member's K chain fits their step table
+  bool group_4w = cfg == kCfgIgemm256 && ls[0].dtype != RON_DTYPE_F32;
+  for (int k = 0; k < n && group_4w; ++k) {
+    const int KT = ls[k].kh * ls[k].kw * ls[k].in.C / conv_k_chunk(ls[k].dtype);
+    group_4w = asm_loop_ok((KT + sks[k] - 1) / std::max(sks[k], 1));
+  }
   for (int k = 0; k < n; ++k) {
     const ConvLaunch& c = ls[k];
     const int esz = (int)dtype_size(c.dtype), chunk = conv_k_chunk(c.dtype);
@@ -529,7 +544,7 @@ int launch_conv_group(const ConvLaunch* ls_in, int n, int cfg, void* scratch, in
       if (a.splitk == 1) { a.kt_split = a.KT; a.partial = nullptr; }
       else { used += need; any_split = true; }
     }
-    a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk, 0);
+    a.m_fastest = pick_m_fastest(c, BM, BN, a.tiles_total / a.tiles_n, a.tiles_n, a.splitk, group_4w ? a.kt_split : 0);
     a.pos_major = pick_pos_major(c, mcfg, BM);
     // K order of the member, by the rules of a launch of its own (conv_pick_cfg): taps innermost for stride-1 filters that neither
     // split K nor skip filter rows - on the 256 x 256 tile where the long columns are at most two tiles wide, on 128 x 128 always

@@ -13,8 +13,8 @@ export GPU_MAX_HW_QUEUES=8
 OUT=$1; shift
 mkdir -p $OUT
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_layers.txt
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --layers $OUT/pmc_layers.txt "$@" > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode "$@" > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 --layers $OUT/pmc_layers.txt "$@" > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 "$@" > $OUT/pmc_write.log 2>&1
 python3 - "$OUT" "$@" <<'PY'
 import csv, glob, json, os, sys
 out = sys.argv[1]
@@ -36,7 +36,7 @@ for which in ('fetch', 'write'):
     seq[which] = [(k, v) for _, k, v in rows if any(c in k for c in CONV + STEM)]
 fetch_kib, n1 = tot['fetch']
 write_kib, n2 = tot['write']
-res = {'command': 'bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode ' + ' '.join(args), 'commit': os.environ.get('RON_COMMIT'),
+res = {'command': 'bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 ' + ' '.join(args), 'commit': os.environ.get('RON_COMMIT'),
        'conv_launches_sampled': [n1, n2],
        'FETCH_SIZE_KiB_per_launch_raw': fetch_kib, 'WRITE_SIZE_KiB_per_launch': write_kib,
        'correction': 'FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B)',

@@ -9,7 +9,7 @@ export GPU_MAX_HW_QUEUES=8
 OUT=$1; shift
 mkdir -p $OUT
 rm -rf $OUT/pmc_mfma          # one run per call: never add another call's dispatches (see pmc_bench.sh)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --in-flight 1 "$@" > $OUT/pmc_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 --in-flight 1 "$@" > $OUT/pmc_mfma.log 2>&1
 python3 - "$OUT" "$@" <<'PY'
 import collections, csv, glob, json, os, sys
 out = sys.argv[1]
@@ -53,7 +53,7 @@ def entry(d, ns, cnt):
         # dispatches occupied: comparable with TFLOP/s-by-time / 2500 of the same dispatches when every MFMA is algorithmic work
         e['mfma_busy_x_clock_over_nominal'] = e['mfma_busy_fraction'] * e['clock_ghz'] / NOMINAL_GHZ
     return e
-res = {'command': 'bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --in-flight 1 ' + ' '.join(args), 'commit': os.environ.get('RON_COMMIT'),
+res = {'command': 'bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 --in-flight 1 ' + ' '.join(args), 'commit': os.environ.get('RON_COMMIT'),
        'formula': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), all dispatches of the run (7 steps) summed; '
                   'clock_ghz = GRBM_GUI_ACTIVE / 8 / dispatch duration (timestamps of the same counter pass)',
        'whole_run': entry(tot, sum(dur.values()), sum(n.values())),

@@ -17,8 +17,8 @@ python3 bench.py --dtype fp32 --steps 10 --warmup 3 --layers $O/layers_cfg2_fp32
 python3 bench.py --no-cpu-baseline --no-parity-mode --variant reducedfc --dtype fp16 --batch 64 --layers $O/layers_cfg4.txt > $O/bench_cfg4.json 2>> $O/err.txt
 python3 bench.py --no-cpu-baseline --no-parity-mode --variant ssd512 --batch 16 --layers $O/layers_cfg5.txt > $O/bench_cfg5.json 2>> $O/err.txt
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --no-cpu-baseline --no-parity-mode --check-gather > $O/bench_cfg2_torchrun_1rank.json 2>> $O/err.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode > $O/bench_cfg2_under_rocprof_inflight2.json 2>> $O/err.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --in-flight 1 > $O/bench_cfg2_under_rocprof_inflight1.json 2>> $O/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 > $O/bench_cfg2_under_rocprof_inflight2.json 2>> $O/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 --in-flight 1 > $O/bench_cfg2_under_rocprof_inflight1.json 2>> $O/err.txt
 for d in if1 if2; do f=$(ls $O/prof_$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$d.csv; done
 # PMC passes: ONE output directory per dtype (round 3's f16x3 files summed both dtypes' dispatches: same directory, globbed twice);
 # the scripts also remove their counter directories before each pass
@@ -36,7 +36,7 @@ BATCHES="1 2 4 8" EXTRA="--head-plan batch" bash tools/batch_sweep.sh >> $O/batc
 echo "# --head-plan level" >> $O/batch_sweep.txt
 BATCHES="1 2 4 8" EXTRA="--head-plan level" bash tools/batch_sweep.sh >> $O/batch_sweep.txt 2>> $O/err.txt
 python3 bench.py --no-cpu-baseline --no-parity-mode --batch 1 --in-flight 1 --steps 200 --warmup 20 --layers $O/layers_cfg2_batch1.txt > $O/bench_cfg2_batch1.json 2>> $O/err.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity-mode --in-flight 1 --batch 1 > $O/bench_cfg2_batch1_under_rocprof.json 2>> $O/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 --in-flight 1 --batch 1 > $O/bench_cfg2_batch1_under_rocprof.json 2>> $O/err.txt
 f=$(ls $O/prof_b1/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_batch1.csv
 rm -rf $O/prof_b1
 # GEMM shapes beside hipBLASLt, and the same-box A/B against the previous round's library when one was left in tools/experiments
