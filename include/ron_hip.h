@@ -202,6 +202,13 @@ int ron_bboxes_filter_min(const float* scores, const float* bboxes, int num_list
  * 0..capacity-1 = (class, score, ymin, xmin, ymax, xmax, anchor_index), zero padded past `count`; row `capacity` = the
  * count replicated.  The only thing that crosses xGMI: one RCCL all-gather of these. */
 int ron_pack_records(const ron_detections* det, int n, float* records, void* stream);
+/* ... and that all-gather (SURVEY.md 8e names ncclAllGather): every rank's `records` [n, capacity + 1, 7] into `gathered`
+ * [world, n, capacity + 1, 7] on every rank, enqueued on `stream`.  nccl_comm: an ncclComm_t (rccl.h) the caller created with one
+ * rank per GPU; RCCL is looked up at the first call (the host's own librccl, or one already loaded, or librccl.so.1) and is not a
+ * link-time dependency of this library: RON_ERR_UNSUPPORTED when the process has none.  `records` may be the slice of `gathered`
+ * that belongs to this rank (in place).  The reference has no inference data parallelism (eval_ron_network.py:93-94: batch 1, one
+ * device); the Python host does the same exchange through torch.distributed (ron_tensorflow_amd/parallel.py). */
+int ron_gather_records(const float* records, int n, int capacity, float* gathered, void* nccl_comm, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * TF evaluation variant of the post-processing (what eval_ron_network.py:226-236 runs):

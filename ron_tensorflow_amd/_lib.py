@@ -111,6 +111,7 @@ SIGNATURES = {
     'ron_preprocess_eval': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P, _P]),
     'ron_preprocess_eval_geom': (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P, _P]),
     'ron_pack_records': (C.c_int, [C.POINTER(Detections), C.c_int, _P, _P]),
+    'ron_gather_records': (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     'ron_bboxes_matching': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, _P]),
     'ron_post_tfe': (C.c_int, [C.POINTER(Heads), C.c_int, C.POINTER(TfeCfg), _P, C.c_int64, _P, _P, _P]),
     'ron_create': (C.c_int, [C.POINTER(_P), C.POINTER(Config)]),
