@@ -422,6 +422,10 @@ typedef struct {
 } ron_conv_desc;
 int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const float* w, const float* bias,
                     const float* residual, float* y, void* stream);
+/* How ron_conv2d_nhwc would run `d`, without running it (tests, tools): out = {tile configuration (csrc/conv_mfma.h kCfg*),
+ * split-K factor, tile order (0 = column tiles fastest inside an XCD's run, 1 = row tiles fastest, P >= 2 = panels of P column tiles
+ * walked row by row), K order (1 = taps innermost)}.  Allocates and frees the operands like ron_conv2d_nhwc does. */
+int ron_conv_plan(const ron_conv_desc* d, int32_t out[4]);
 /* Two fp32 head tensors from one convolution over a shared input - the class and the box convolution of an SSD feature layer
  * (nets/ssd_vgg_300.py:403-431), which the SSD-512 graph runs as one launch: w HWIO [kh,kw,cin,cout], its first `split_first`
  * output channels go to y_first [n,h,w,split_first], the other cout - split_first to y_second [n,h,w,cout - split_first]

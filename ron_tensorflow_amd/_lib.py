@@ -134,6 +134,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'ron_profile_reset': (C.c_int, [_P]),
     'ron_conv2d_nhwc': (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    'ron_conv_plan': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     'ron_conv2d_heads_nhwc': (C.c_int, [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P, _P]),
     'ron_maxpool2x2_nhwc': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     'ron_conv2d_bench': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int, C.POINTER(C.c_float)]),

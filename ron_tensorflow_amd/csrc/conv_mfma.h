@@ -81,6 +81,8 @@ inline bool conv_cfg_taps_inner(int cfg) { return cfg == kCfgIgemm256TapsInner |
 inline bool conv_cfg_is_patch(int cfg) { return cfg >= kCfgPatch256 && cfg <= kCfgPatch64; }
 
 int launch_conv(const ConvLaunch& c, hipStream_t stream);
+// what launch_conv would do with `c`: out = {tile configuration (kCfg*), split-K factor, tile order (ConvArgs::m_fastest), K order (taps_inner)}
+int conv_describe(const ConvLaunch& c, int out[4]);
 // 3x3 / stride 1 / pad 1 on a 64-channel map, weights resident in LDS (conv_c64.hip); pack_conv_c64_weights builds wgt_c64
 bool conv_c64_applicable(const ConvLaunch& c);
 int launch_conv_c64(const ConvLaunch& c, hipStream_t stream);

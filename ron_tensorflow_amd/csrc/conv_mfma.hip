@@ -154,12 +154,40 @@ static int pick_m_fastest(const ConvLaunch& c, int BM, int BN, int tiles_m, int 
     const int P = atoi(force), cols = c.center_from > 0 ? c.center_from / BN : tiles_n;     // (centre-tap-only columns: panels among the long ones)
     return P >= cols ? 0 : P;
   }
+  int pick = cost_m < 0.95 * cost_n ? 1 : 0;
   if (panels_ok && tiles_n >= 2 * kPanelCols && tiles_m >= 8 && c.center_from == 0) {
     const double cost_p = std::min(tiles_m, per_xcd / kPanelCols + 1) * a_tile +
                           std::min(tiles_n, kPanelCols * (per_xcd / (tiles_m * kPanelCols) + 1)) * b_tile;
-    if (cost_p < 0.9 * std::min(cost_n, cost_m)) return kPanelCols;
+    if (cost_p < 0.9 * std::min(cost_n, cost_m)) pick = kPanelCols;
   }
-  return cost_m < 0.95 * cost_n ? 1 : 0;
+  // Round 6: the width of the panel from what an XCD's CUs fetch PER ROUND.  Its 32 workgroups run in step through K; with panels of P
+  // column tiles they are 32 / P row tiles x P column tiles, and a round streams those row tiles' input lines and those column tiles'
+  // weights through a 4 MB L2 that keeps neither for the next round (the weights of ONE 256 x 4608 column tile are 2.4 MB).  Measured
+  // (profiles/r06/panel_width_sweep.txt, FETCH_SIZE x 2 + WRITE_SIZE per launch at batch 32): block4 trio3 group 1482 MB with its six long
+  // columns fastest, 1002 with P = 2, 1133 / 1166 with 3 / 4; block5 trio3 group 667 -> 547; fc7 group 606 (P = 8) -> 514 (P = 4);
+  // 7.40 -> 6.71 GB per step with P = 2 everywhere.  The launches' TIMES did not move (560.4 vs 560.7 us, the step 4.291 vs 4.279 ms):
+  // these launches are not short of fabric bandwidth, and the bytes saved did not come back as clock either - the choice is made for the
+  // traffic alone, and only where the model sees a clear difference.  A row tile's unique input lines: ~1.3 x its own rows for a 3 x 3
+  // filter on these maps (the halo rows), not the 2 x of the column / row estimate above.
+  const int cols = c.center_from > 0 ? c.center_from / BN : tiles_n;
+  if (panels_ok && cols >= 3) {
+    const double a_round = (double)BM * c.in.C * esz * (c.stride > 1 ? taps : (taps > 1 ? 1.3 : 1.0));
+    const int resident = std::min(32, std::max(1, tiles_m * cols / 8));
+    auto per_round = [&](int P) {
+      P = std::max(1, std::min(P, cols));
+      return ((resident + P - 1) / P) * a_round + P * b_tile;
+    };
+    const double now = per_round(pick == 0 ? cols : pick);
+    int best = pick;
+    double best_cost = now;
+    for (int P : {2, 3, 4, 8}) {
+      if (P >= cols) break;
+      const double t = per_round(P);
+      if (t < 0.95 * best_cost) { best = P; best_cost = t; }
+    }
+    if (best_cost < 0.95 * now) pick = best;
+  }
+  return pick;
 }
 
 // Position-major rows + per-tile skipping of filter rows that only see the zero halo (ConvArgs::pos_major): where the K steps a
@@ -227,11 +255,45 @@ int conv_pick_cfg(const ConvLaunch& c) {
   return cfg;
 }
 
+// Everything launch_conv decides before it launches: the tile configuration and the kernel arguments (split-K, tile order, K order).
+static int plan_conv(const ConvLaunch& c, int* cfg_out, ConvArgs* a_out);
+
+int conv_describe(const ConvLaunch& c, int out[4]) {
+  int cfg = -1;
+  ConvArgs a = ConvArgs();
+  const int rc = plan_conv(c, &cfg, &a);
+  if (rc != RON_OK) return rc;
+  out[0] = cfg;
+  const bool gather = !conv_cfg_is_patch(cfg) && cfg != kCfgC64Resident;
+  out[1] = gather ? a.splitk : 1; out[2] = gather ? a.m_fastest : 0; out[3] = gather ? a.taps_inner : 0;
+  return RON_OK;
+}
+
 int launch_conv(const ConvLaunch& c, hipStream_t stream) {
-  int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg(c);
-  RON_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "conv: tile config %d out of range [0, %d)", cfg, kNumCfgs);
+  int cfg = -1;
+  ConvArgs a = ConvArgs();
+  int rc = plan_conv(c, &cfg, &a);
+  if (rc != RON_OK) return rc;
   if (conv_cfg_is_patch(cfg)) return launch_conv_patch(c, cfg, stream);
   if (cfg == kCfgC64Resident) return launch_conv_c64(c, stream);
+  if (c.dtype == RON_DTYPE_BF16) rc = launch_cfg<TraitsBF16S>(cfg, a, stream);
+  else if (c.dtype == RON_DTYPE_F16) rc = launch_cfg<TraitsF16S>(cfg, a, stream);
+  else if (c.dtype == RON_DTYPE_F32) rc = launch_cfg<TraitsF32S>(cfg, a, stream);
+  else if (c.dtype == RON_DTYPE_F16X3) rc = launch_cfg<TraitsF16X3S>(cfg, a, stream);
+  else { ron::set_error("conv: unknown dtype %d", c.dtype); return RON_ERR_INVALID; }
+  if (rc != RON_OK || a.splitk == 1) return rc;
+  if (c.dtype == RON_DTYPE_BF16) return launch_finalize<TraitsBF16S>(a, stream);
+  if (c.dtype == RON_DTYPE_F16) return launch_finalize<TraitsF16S>(a, stream);
+  if (c.dtype == RON_DTYPE_F16X3) return launch_finalize<TraitsF16X3S>(a, stream);
+  return launch_finalize<TraitsF32S>(a, stream);
+}
+
+static int plan_conv(const ConvLaunch& c, int* cfg_out, ConvArgs* a_out) {
+  ConvArgs& a = *a_out;
+  int cfg = c.cfg >= 0 ? c.cfg : conv_pick_cfg(c);
+  *cfg_out = cfg;
+  RON_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "conv: tile config %d out of range [0, %d)", cfg, kNumCfgs);
+  if (conv_cfg_is_patch(cfg) || cfg == kCfgC64Resident) return RON_OK;      // kernels of their own: nothing more to plan here
   RON_REQUIRE(!conv_cfg_taps_inner(cfg) || c.up == 0, "conv: the taps-innermost order is for plain convolutions");
   const int esz = (int)dtype_size(c.dtype);
   const int chunk = conv_k_chunk(c.dtype);
@@ -245,7 +307,6 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
   const int BN = igemm_bn(cfg), BM = igemm_bm(cfg);
   RON_REQUIRE(c.Npad % BN == 0, "conv: Npad %d not a multiple of the N tile %d", c.Npad, BN);
   if (c.up > 0) RON_REQUIRE(c.up_cout % BN == 0, "transposed conv: channels per tap %d not a multiple of %d", c.up_cout, BN);
-  ConvArgs a;
   fill_conv_args(c, &a);
   a.tiles_n = c.Npad / BN;
   a.tiles_total = ((M + BM - 1) / BM) * a.tiles_n;
@@ -285,17 +346,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t stream) {
     RON_REQUIRE(c.center_from % BN == 0 && (c.kh & 1) && (c.kw & 1) && c.up == 0,
                 "conv: centre-tap-only columns need an odd filter and a boundary on the N tile (%d)", BN);
   RON_REQUIRE((int64_t)c.Npad * K * esz == c.wgt_bytes, "conv: packed weight size mismatch");
-  int rc;
-  if (c.dtype == RON_DTYPE_BF16) rc = launch_cfg<TraitsBF16S>(cfg, a, stream);
-  else if (c.dtype == RON_DTYPE_F16) rc = launch_cfg<TraitsF16S>(cfg, a, stream);
-  else if (c.dtype == RON_DTYPE_F32) rc = launch_cfg<TraitsF32S>(cfg, a, stream);
-  else if (c.dtype == RON_DTYPE_F16X3) rc = launch_cfg<TraitsF16X3S>(cfg, a, stream);
-  else { ron::set_error("conv: unknown dtype %d", c.dtype); return RON_ERR_INVALID; }
-  if (rc != RON_OK || a.splitk == 1) return rc;
-  if (c.dtype == RON_DTYPE_BF16) return launch_finalize<TraitsBF16S>(a, stream);
-  if (c.dtype == RON_DTYPE_F16) return launch_finalize<TraitsF16S>(a, stream);
-  if (c.dtype == RON_DTYPE_F16X3) return launch_finalize<TraitsF16X3S>(a, stream);
-  return launch_finalize<TraitsF32S>(a, stream);
+  return RON_OK;
 }
 
 // ---- grouped launches ---------------------------------------------------------------------------------------------

@@ -174,6 +174,22 @@ extern "C" int ron_conv2d_nhwc(const ron_conv_desc* d, const float* x, const flo
   return RON_OK;
 }
 
+// How ron_conv2d_nhwc would launch `d` (no launch): the decisions of launch_conv for the same ConvLaunch.
+extern "C" int ron_conv_plan(const ron_conv_desc* d, int32_t out[4]) {
+  using namespace ron;
+  RON_REQUIRE(d != nullptr && out != nullptr, "NULL argument");
+  RON_REQUIRE(!(d->cin == 3), "the 3-channel stem has a kernel of its own");
+  const size_t wn = (size_t)d->kh * d->kw * d->cin * d->cout;
+  std::vector<float> w(wn, 0.f);
+  ConvSetup S;
+  int rc;
+  if ((rc = setup_conv(d, w.data(), nullptr, false, &S))) return rc;
+  int o[4];
+  if ((rc = conv_describe(S.c, o))) return rc;
+  for (int i = 0; i < 4; ++i) out[i] = o[i];
+  return RON_OK;
+}
+
 // Two fp32 head tensors from ONE convolution over a shared input (ConvLaunch::split_n; the graph's pack_box_pair for the class and box
 // convolutions of an SSD feature layer): the same packing - first head's columns, the second's from the next multiple of 8 - and
 // the same launch, with the tile configuration and the split-K factor the caller's to force.

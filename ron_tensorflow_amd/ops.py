@@ -246,6 +246,14 @@ def conv2d_nhwc(x, w, bias=None, residual=None, stride=1, dilation=1, relu=True,
     return y
 
 
+def conv_plan(n, h, w, cin, cout, k=3, stride=1, dilation=1, dtype='bf16', tile_cfg=-1, splitk=-1, pool=False, center_from=0, transpose=False):
+    """How conv2d_nhwc would run this convolution (ron_conv_plan): dict(tile_cfg, splitk, tile_order, taps_inner)."""
+    d = _lib.ConvDesc(n, h, w, cin, cout, k, k, stride, dilation, 1, int(transpose), _lib.DTYPES[dtype], tile_cfg, 0, 0, int(pool), splitk, center_from)
+    out = (C.c_int32 * 4)()
+    check(lib().ron_conv_plan(C.byref(d), out))
+    return dict(tile_cfg=out[0], splitk=out[1], tile_order=out[2], taps_inner=out[3])
+
+
 def conv2d_heads_nhwc(x, w, split_first, bias=None, dilation=1, relu=False, dtype='bf16', tile_cfg=-1, splitk=-1):
     """One convolution, two fp32 head tensors (ron_conv2d_heads_nhwc: what the SSD-512 graph does with the class and box convolutions of
     a feature layer, nets/ssd_vgg_300.py:403-431): w HWIO with cout = both heads' channels, the first `split_first` of them -> y_first."""

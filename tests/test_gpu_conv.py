@@ -624,3 +624,26 @@ def test_two_head_outputs_from_one_convolution(ops, dev, heads, cfg, splitk, dty
     assert tuple(y1.shape) == (2, 8, 8, n_cls) and tuple(y2.shape) == (2, 8, 8, n_loc)
     _check(y1.cpu().numpy(), ref[..., :n_cls], dtype)
     _check(y2.cpu().numpy(), ref[..., n_cls:], dtype)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16x3'])
+@pytest.mark.parametrize('case', [(1024, 0, 2), (768, 0, 2), (1280, 0, 2), (1024, 768, 2), (2048, 1536, 2)], ids=lambda c: 'n%d_c%d' % c[:2])
+def test_panel_tile_orders_cover_every_tile(ops, dev, case, dtype):
+    """Round 6: tile orders in panels of P column tiles (ConvArgs::m_fastest >= 2) - even and ragged last panels (1024 = 4, 768 = 3,
+    1280 = 5 column tiles of 256) and the long columns of a launch with centre-tap-only columns.  The plan must say so (ron_conv_plan),
+    and a tile order that skipped or repeated a tile could not reproduce the oracle."""
+    cout, center_from, want_p = case
+    n, h, w, cin = 16, 32, 32, 64                                 # M = 16 384: 64 row tiles of 256, an XCD's 32 resident workgroups are all of this launch
+    plan = ops.conv_plan(n, h, w, cin, cout, k=3, dtype=dtype, tile_cfg=0, splitk=1, center_from=center_from)
+    assert plan['tile_cfg'] == 0 and plan['splitk'] == 1 and plan['tile_order'] == want_p, plan
+    rs = np.random.RandomState(cout + center_from)
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(3, 3, cin, cout) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    if center_from:
+        wt[:, :, :, center_from:] = 0
+        wt[1, 1, :, center_from:] = (rs.randn(cin, cout - center_from) * np.sqrt(2.0 / cin)).astype(np.float32)
+    b = (rs.randn(cout) * 0.1).astype(np.float32)
+    rnd = ROUND[dtype]
+    ref = np.maximum(orf.conv2d_np(rnd(x), rnd(wt)) + b, 0)
+    got = ops.conv2d_nhwc(torch.from_numpy(x).to(dev), wt, b, relu=True, dtype=dtype, tile_cfg=0, splitk=1, center_from=center_from).cpu().numpy()
+    _check(got, ref, dtype)

@@ -42,11 +42,13 @@ def test_gather_records_one_rank(comm):
     n, k = 3, 400
     rs = np.random.RandomState(0)
     det = ops.DetectionBuffers(n, k, dev)
-    det.count = torch.from_numpy(np.array([5, 0, 400], np.int32)).to(dev)
-    det.classes = torch.from_numpy(rs.randint(1, 21, (n, k)).astype(np.int32)).to(dev)
-    det.scores = torch.from_numpy(rs.rand(n, k).astype(np.float32)).to(dev)
-    det.bboxes = torch.from_numpy(rs.rand(n, k, 4).astype(np.float32)).to(dev)
-    det.anchor_index = torch.from_numpy(rs.randint(0, 21250, (n, k)).astype(np.int32)).to(dev)
+    count = np.array([5, 0, 400], np.int32)
+    live = (np.arange(k)[None, :] < count[:, None])                      # rows past an image's count are zero (ron_detect pads with zeros)
+    det.count = torch.from_numpy(count).to(dev)
+    det.classes = torch.from_numpy((rs.randint(1, 21, (n, k)) * live).astype(np.int32)).to(dev)
+    det.scores = torch.from_numpy((rs.rand(n, k) * live).astype(np.float32)).to(dev)
+    det.bboxes = torch.from_numpy((rs.rand(n, k, 4) * live[..., None]).astype(np.float32)).to(dev)
+    det.anchor_index = torch.from_numpy((rs.randint(0, 21250, (n, k)) * live).astype(np.int32)).to(dev)
     rec = parallel.pack_detections(det)                                  # ron_pack_records
     gathered = torch.zeros((1, n, k + 1, parallel.RECORD_WIDTH), dtype=torch.float32, device=dev)
     s = torch.cuda.Stream(device=dev)
