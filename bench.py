@@ -189,8 +189,10 @@ def load_mfma_busy(args):
     with open(files[-1]) as f:
         t = json.load(f)
     w = t.get('whole_run', {})
-    val = {'whole_run': w.get('mfma_busy_fraction'), 'clock_ghz': w.get('clock_ghz'),
-           'busy_x_clock_over_nominal': w.get('mfma_busy_x_clock_over_nominal'),
+    # (round 6: the clock those files derive from GRBM_GUI_ACTIVE / dispatch duration, and busy x clock / 2.4 GHz, are no longer carried:
+    # on dispatches of 60-300 us that quotient reads high - MI355X_MICROARCH.md, DVFS give-back - and the in-kernel stamps of
+    # `roofline.k_loop_clock` are the measurement of the clock)
+    val = {'whole_run': w.get('mfma_busy_fraction'),
            'per_kernel': {k: v.get('mfma_busy_fraction') for k, v in t.get('per_kernel', {}).items() if 'conv' in k or 'stem' in k}}
     src = {'file': os.path.relpath(files[-1], ROOT), 'commit': t.get('commit'), 'command': t.get('command'),
            'note': 'committed rocprofv3 --pmc measurement of an earlier run of this command, one batch in flight (SQ_VALU_MFMA_BUSY_CYCLES '
@@ -218,6 +220,31 @@ def sustained_leg(pipe, images, ms_per_step_estimate, seconds, in_flight, detect
             'burst_over_sustained': burst_images_per_s / overall,
             'note': 'same pipeline, images and loop as the timed region, started right after it; whole job (rank 0\'s marks); burst = the '
                     'timed region of this line'}
+
+
+def load_kloop_clock(args, in_flight):
+    """The shader clock inside the assembly K loop of the four-wave tiles while this command runs: s_memtime / s_memrealtime stamps of a
+    DIAGNOSTIC build of the library (tools/build_stamps_variant.sh, tools/kloop_clock.py -> profiles/<round>/kloop_clock_<dtype>_if<F>.json),
+    after a burst from idle (what the driver's 5 + 20 steps see) and after seconds of load.  A committed measurement like `traffic`
+    (the shipped kernels execute no stamp): returned with its provenance, or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'kloop_clock_%s_if%d.json' % (args.dtype, in_flight))))
+    if not files or args.variant != 'full' or args.batch != 32:
+        return None, None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    val = {}
+    for ph in t.get('phases', []):
+        key = 'burst' if ph['phase'].startswith('burst') else 'sustained'
+        val[key] = {'clock_ghz_median': ph.get('clock_ghz', {}).get('median'), 'clock_ghz_p10': ph.get('clock_ghz', {}).get('p10'),
+                    'clock_ghz_p90': ph.get('clock_ghz', {}).get('p90'),
+                    'cycles_per_k_step': {k: v.get('cycles_per_k_step') for k, v in ph.get('by_tile', {}).items()},
+                    'images_per_s_of_the_stamped_build': ph.get('images_per_s')}
+    src = {'file': os.path.relpath(files[-1], ROOT),
+           'note': 'in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the K loop of every 256 x 256 / 256 x 128 tile of the '
+                   'launches that do not split K, diagnostic library, same workload / pipeline / loop; a K step issues 2048 (256 x 128: 1024) '
+                   'cycles of MFMAs; not collected in this run'}
+    return val, src
 
 
 def parity_mode_leg(args, ron_class, ron_params, weights, images, dev, detect_args, top_k, ref_dets):
@@ -416,6 +443,7 @@ def main():
     algo_bytes = sum(r['bytes_per_launch'] * r['launches'] for r in conv) / max(conv_launches, 1)
     traffic, traffic_source = load_traffic(args)
     mfma_busy, mfma_busy_source = load_mfma_busy(args)
+    k_loop_clock, k_loop_clock_source = load_kloop_clock(args, in_flight)
     peak = {'bf16': PEAK_BF16_TFLOPS, 'fp16': PEAK_F16_TFLOPS, 'fp32': PEAK_F32_TFLOPS, 'f16x3': PEAK_F16X3_TFLOPS}[args.dtype]
 
     if rank == 0:
@@ -446,6 +474,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'conv kernels: conv_igemm_kernel (+ its grouped form conv_igemm_group_kernel), conv3x3_patch_kernel and conv3x3_c64_kernel', 'achieved': achieved, 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_source,
                          'mfma_busy': mfma_busy, 'mfma_busy_source': mfma_busy_source,
+                         'k_loop_clock': k_loop_clock, 'k_loop_clock_source': k_loop_clock_source,
                          'basis': basis,
                          # the per-kernel definition: conv FLOPs per launch / that launch's own duration, one launch at a
                          # time (3 steps after the timed region when several batches were in flight during it)
