@@ -35,49 +35,60 @@ struct ConvArgs {
   void* out;
   const void* res;
   int M, Ho, Wo;
-  int in_Hp, in_Wp, in_cstride, in_org;     // in_org = in.pad - cpad  (first tap of output (0,0))
+  int in_Hp, in_Wp, in_cstride;
   int in_coff;
-  int Cin, kw, KT;                          // KT = kh*kw*Cin / chunk
-  int stride, dil;
+  int Cin, KT;                              // KT = kh*kw*Cin / chunk
   int K;                                    // elements per weight row
   int Cout;
-  int out_Hp, out_Wp, out_cstride, out_pad, out_coff;
-  int up, up_cout;
-  int relu, out_f32;
+  int out_Hp, out_Wp, out_cstride, out_coff;
+  int up_cout;
   float oscale;                             // accumulator * oscale + bias (2^-k of the weight scale in split-precision mode, else 1)
   int tiles_n;
   // split-K: workgroup z of `splitk` covers K steps [z*kt_split, (z+1)*kt_split) and stores raw fp32 sums to
   // partial[z][m][n] (n < Npad); splitk_finalize_kernel adds the slabs and applies the epilogue.
   int splitk, kt_split, tiles_total, Npad;
   float* partial;
+  // The small fields share two dwords: every kernel argument sits in a scalar register from the kernel's first instruction, and
+  // ConvArgs was at the size the scalar register file carries.  Round 6, same box: 66 dwords -> 53 took hipcc's sgpr_spill_count from
+  // 2-8 (plain tiles), 20-38 (four-wave and grouped tiles), 56-71 (mixed-width groups) to 0 everywhere: batch 1 0.702 -> 0.697 ms,
+  // batch 32 two in flight 8 517 / 8 488 -> 8 608 / 8 593 images/s; 28 dwords MORE (multiplier divisions for the set-up) had cost
+  // every launch 1-6 % (tools/experiments/README.md, fastdiv_setup.patch).
+  unsigned in_org : 5;                      // in.pad - cpad  (first tap of output (0,0))
+  unsigned kw : 4, kh : 4;
+  unsigned stride : 3, dil : 5;
+  unsigned out_pad : 4, out2_pad : 4;
+  unsigned up : 3;                          // conv2d_transpose with kernel == stride == up (pixel-shuffle epilogue); 0 = plain conv
+  unsigned relu : 1, out_f32 : 1;
   // fused 2x2 / stride-2 max-pool: tile rows are ordered window-major (rows 4q..4q+3 = the four conv outputs of
   // pooled pixel q), which puts a window into four consecutive accumulator registers of one lane.
-  int pool;
+  unsigned pool : 1;
+  // pos_major: rows ordered by output row first (m = (oy * n_img + img) * Wo + ox) instead of image-major: a tile then covers few
+  // output rows oy, and the filter rows ky whose taps fall into the zero halo for ALL of them are skipped.  (Round 4: the images used to
+  // be the fastest index; consecutive rows were then one image plane apart, a multiple of 16 KB on fc6's input, i.e. on one L2
+  // channel.)  fc6 (7x7 on a 10 x 10 map): 31 % of the MACs multiply halo zeros; skipping whole filter rows per tile recovers half.
+  // taps_inner, the K order: 0 = tap-major (step = tap * chunks + chunk), 1 = chunk-major with the taps innermost (consecutive steps
+  // re-read almost the same input lines one pixel over: the re-reads hit L2).  Centre-tap-only column tiles always walk their one tap
+  // tap-major.
+  unsigned pos_major : 1, taps_inner : 1;
+  unsigned cpad : 6;
+  // tile order inside an XCD's run of workgroups: 0 = N fastest (the column tiles that re-read one activation tile share an L2),
+  // 1 = M fastest (the row tiles that re-read one weight slice do: fc6's 205 MB of weights are then fetched once, not once per XCD),
+  // P >= 2 = panels of P column tiles walked row by row (four-wave tiles only; conv_mfma.hip, pick_m_fastest)
+  unsigned m_fastest : 6;
   // fused pool + the full-resolution map too (conv4_3 / conv5_3 feed both their pool and a reverse-connection conv): `out2` is the
   // un-pooled output view, written from the same accumulators; nullptr = pooled map only
   void* out2;
-  int out2_Hp, out2_Wp, out2_cstride, out2_pad, out2_coff;
+  int out2_Hp, out2_Wp, out2_cstride, out2_coff;
   // Two fp32 head outputs from ONE convolution over a shared input (the loc and cls convolutions of an SSD feature layer,
   // nets/ssd_vgg_300.py:403-431, packed side by side): columns [0, split_first) are channels of `out`, columns [split_n, Cout) are
   // channels [0, Cout - split_n) of `out2` (split_n = split_first rounded up to 8, the columns between are padding).  Both views
   // are un-haloed [n][Ho][Wo][C] tensors, so a row's offset in `out2` is its offset in `out` / out_cstride * out2_cstride.
   // 0: one output.
   int split_n, split_first;
-  // tile order inside an XCD's run of workgroups: 0 = N fastest (the column tiles that re-read one activation tile share an L2),
-  // 1 = M fastest (the row tiles that re-read one weight slice do: fc6's 205 MB of weights are then fetched once, not once per XCD),
-  // 2 = panels of 8 column tiles walked row by row (launches that are both wide and tall)
-  int m_fastest;
-  // Rows ordered by output row first (m = (oy * n_img + img) * Wo + ox) instead of image-major: a tile then covers few output rows
-  // oy, and the filter rows ky whose taps fall into the zero halo for ALL of them are skipped.  (Round 4: the images used to be the
-  // fastest index; consecutive rows were then one image plane apart, a multiple of 16 KB on fc6's input, i.e. on one L2 channel.)
-  // fc6 (7x7 on a 10 x 10 map): 31 % of the MACs multiply halo zeros; skipping whole filter rows per tile recovers half of that.
-  int pos_major, n_img, in_H, cpad, kh;
+  int n_img, in_H;                          // (position-major rows)
   // Column tiles at or beyond output channel center_from_n (0: none) hold a 1x1 branch whose weights sit in the centre tap of the
   // kh x kw filter, zeros elsewhere: they run the K steps of that tap only.
   int center_from_n;
-  // K order: 0 = tap-major (step = tap * chunks + chunk), 1 = chunk-major with the taps innermost (consecutive steps re-read almost the
-  // same input lines one pixel over: the re-reads hit L2).  Centre-tap-only column tiles always walk their one tap tap-major.
-  int taps_inner;
 };
 
 // MFMA shape of a traits class: kMT x kMT output tile per instruction (32: v_mfma_f32_32x32x16, 16 accumulator registers;

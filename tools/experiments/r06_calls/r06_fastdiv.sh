@@ -4,11 +4,11 @@
 set -u
 export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8
-O=gpurun_out/r06_fastdiv
+O=${O:-gpurun_out/r06_fastdiv}
 mkdir -p $O
 timeout 1200 python3 -m pytest tests/test_gpu_conv.py tests/test_gpu_forward.py tests/test_gpu_benched_config.py tests/test_gpu_ssd.py -m gpu -q -x > $O/pytest_subset.txt 2>&1
 tail -4 $O/pytest_subset.txt
-PREV=$PWD/tools/experiments/libron_hip_r06b.so
+PREV=${PREV:-$PWD/tools/experiments/libron_hip_r06b.so}
 for rep in 1 2; do
   RON_HIP_LIB=$PREV python3 bench.py --no-cpu-baseline --no-parity-mode --sustained-seconds 0 > $O/bench_prev_$rep.json 2>> $O/err.txt
   python3 bench.py --no-cpu-baseline --no-parity-mode --sustained-seconds 0 > $O/bench_this_$rep.json 2>> $O/err.txt
