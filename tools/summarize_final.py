@@ -26,9 +26,17 @@ for name in ('bench_cfg2_default', 'bench_cfg2_inflight1', 'bench_cfg2_f16x3', '
     r = j['roofline']
     print('%-36s %8.1f images/s  %7.3f ms  conv %6.0f TF  frac %.3f  per-kernel %.3f  launch %.1f us' % (
         name, j['value'], j['ms_per_step'], r['achieved'], r['frac'], r.get('per_kernel_frac', 0), r.get('avg_launch_us', 0)))
+    if 'sustained' in j:
+        su = j['sustained']
+        w = su['window_images_per_s']
+        print('    sustained %.1f images/s over %.2f s (%d steps): windows min %.0f median %.0f max %.0f, last / first %.3f, burst / sustained %.4f' % (
+            su['images_per_s'], su['seconds'], su['steps'], w['min'], w['median'], w['max'], su['last_over_first_window'], su['burst_over_sustained']))
     if 'parity_mode' in j:
         pm = j['parity_mode']
-        print('    parity_mode %.1f images/s %.2f ms, agreement %s' % (pm['images_per_s'], pm['ms_per_step'], pm['agreement']))
+        print('    parity_mode %.1f images/s %.2f ms, agreement %s' % (pm['images_per_s'], pm['ms_per_step'], pm.get('agreement')))
+        if 'sustained' in pm:
+            su = pm['sustained']
+            print('    parity_mode sustained %.1f images/s over %.2f s, burst / sustained %.4f' % (su['images_per_s'], su['seconds'], su['burst_over_sustained']))
     if 'cpu_baseline' in j:
         cb = j['cpu_baseline']
         print('    cpu %.2f images/s (batch 1: %.2f)' % (cb['value'], cb['batch_1']['end_to_end_images_per_s']))
