@@ -369,13 +369,6 @@ def main():
                               use_dist=use_dist, device=dev, check_gather=args.check_gather, consumer_stream=io_stream,
                               before_timed=before_timed, after_timed=after_timed)
     dt, det, gather_check = res['dt'], res['det'], res['gather_check']
-    # ---- the sustained leg: the same loop for >= --sustained-seconds, right behind the timed region (every rank takes part;
-    # with a process group the gather stays in the loop)
-    sustained = None
-    if args.sustained_seconds > 0:
-        sustained = sustained_leg(pipe, images, dt / args.steps * 1e3, args.sustained_seconds, in_flight, detect_args, top_k,
-                                  world * args.batch, world * args.batch * args.steps / dt, rank=rank, world=world,
-                                  use_dist=use_dist, device=dev, consumer_stream=io_stream)
     ranks_seen = None
     if use_dist:
         # who took part: the process group's size and the distinct GPUs behind its ranks (one process per GPU: they must be equal)
@@ -418,6 +411,15 @@ def main():
         torch.cuda.synchronize()
         _lib.check(lib.ron_profile_enable(contexts[0], 0))
         solo_rows = collect_rows(contexts[:1])
+    # ---- the sustained leg: the same loop for >= --sustained-seconds, behind the timed region and the per-kernel steps (every rank takes
+    # part; with a process group the gather stays in the loop).  It comes AFTER the solo steps: three seconds of two batches in flight leave the
+    # chip in the power state of that load, and solo steps taken right behind them read 10 % slower than the same steps behind a 75 ms
+    # burst (per-kernel 0.465 vs 0.514 of peak, round 6)
+    sustained = None
+    if args.sustained_seconds > 0:
+        sustained = sustained_leg(pipe, images, dt / args.steps * 1e3, args.sustained_seconds, in_flight, detect_args, top_k,
+                                  world * args.batch, world * args.batch * args.steps / dt, rank=rank, world=world,
+                                  use_dist=use_dist, device=dev, consumer_stream=io_stream)
     solo_conv = [r for r in solo_rows if r['is_conv'] and r['launches'] > 0]
     solo_ms = sum(r['total_ms'] for r in solo_conv)
     solo_flop = sum(r['gflop_per_image'] * 1e9 * args.batch * r['launches'] for r in solo_conv)
