@@ -73,6 +73,10 @@ def parse():
                     help='batches in flight per GPU (execution slots over one set of weights, one stream each; '
                          'ron_tensorflow_amd/pipeline.py).  1 = strictly one launch at a time: per-launch durations are then '
                          "each kernel's alone, which is what profiles/*/kernel_stats are taken with")
+    ap.add_argument('--max-queued', type=int, default=8,
+                    help='host flow control of the pipeline (DetectPipeline.max_queued): submit() waits while that many submitted batches '
+                         'have not finished on the GPU; 0 = unbounded (the host enqueues as fast as it can: 1.3 %% slower over the timed '
+                         'region, window-to-window dips of 10 %% in the sustained leg)')
     ap.add_argument('--layers', default='', help='write the per-launch timing table to this file')
     ap.add_argument('--check-gather', action='store_true', default=True,
                     help='under torch.distributed.run (default on): after the timed region every rank compares the all-gathered '
@@ -264,7 +268,7 @@ def parity_mode_leg(args, ron_class, ron_params, weights, images, dev, detect_ar
                         head_plan=args.head_plan)
     net.load_weights(weights)
     in_flight = max(1, args.in_flight)
-    pipe = DetectPipeline(net, slots=in_flight, top_k=top_k)
+    pipe = DetectPipeline(net, slots=in_flight, top_k=top_k, max_queued=args.max_queued)
     steps = max(1, args.parity_steps)
     # (the GPU idled through the cpu_baseline leg: enough warm-up steps for the clocks to come back up before the timed ones)
     res = parallel.bench_loop(pipe, images, steps, PARITY_WARMUP, in_flight, detect_args, top_k, device=dev)
@@ -347,7 +351,7 @@ def main():
     # drives with a stub pipeline.
     from ron_tensorflow_amd.pipeline import DetectPipeline
     in_flight = max(1, args.in_flight)
-    pipe = DetectPipeline(net, slots=in_flight, top_k=top_k)
+    pipe = DetectPipeline(net, slots=in_flight, top_k=top_k, max_queued=args.max_queued)
     detect_args = dict(select_threshold=0.01, nms_threshold=0.45) if ssd else \
         dict(objectness_thres=0.03, select_threshold=0.01, nms_threshold=0.45)
     io_stream = torch.cuda.Stream(device=dev)      # the consumer (record packing + RCCL gather) has its own stream

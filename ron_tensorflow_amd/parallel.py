@@ -106,7 +106,7 @@ def gather_detections(rec, group=None, out=None):
 
 def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=0, world=1, use_dist=False, device=None,
                check_gather=True, pack=pack_detections, synchronize=None, consumer_stream=None, before_timed=None,
-               after_timed=None, window=0, make_mark=None, mark_ms=None, measure_gather=True):
+               after_timed=None, window=0, make_mark=None, mark_ms=None, measure_gather=True, max_ahead=0):
     """The step / consume / gather / check sequence bench.py times, with the pipeline as an argument (bench.py passes a
     DetectPipeline on the GPU; tests/test_parallel_gloo.py a CPU stub at world size 2).
 
@@ -123,6 +123,9 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
     the rate develops over a run of seconds without the host ever waiting inside it; the first `window` steps lead up to the first mark
     and have no entry (a mark in front of the first submission sits on an idle stream: its timestamp came 0.15 s late when tried).
     `make_mark()` / `mark_ms(a, b)` default to torch timing events (the gloo test passes host clocks).
+
+    `max_ahead` > 0: the host never runs more than that many submitted batches ahead of the GPU (it waits for the completion event of
+    batch i - max_ahead before it submits batch i): a serving loop's bounded queue.  0 = unbounded (the host enqueues as fast as it can).
 
     Returns dict(dt, det (this rank's last detections), gathered, gather_check ('ok' | 'MISMATCH' | None), rank_dt (every rank's own
     time of the timed region), gather_ms (one all-gather of the records alone, after the timed region), window_ms (list, or None))."""
@@ -151,8 +154,17 @@ def bench_loop(pipe, images, steps, warmup, in_flight, detect_args, top_k, rank=
             gather_detections(rec, out=gathered)
         return det
 
+    submitted = []
+
     def step():
-        pending.append(pipe.submit(images, **detect_args))
+        if max_ahead > 0 and len(submitted) >= max_ahead:
+            done = getattr(submitted.pop(0), '_done', None)
+            if done is not None:
+                done.synchronize()             # the host waits; the GPU still has max_ahead - 1 batches queued behind this one
+        t = pipe.submit(images, **detect_args)
+        if max_ahead > 0:
+            submitted.append(t)
+        pending.append(t)
         return consume(pending.pop(0)) if len(pending) >= in_flight else None
 
     def drain():

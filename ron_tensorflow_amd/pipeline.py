@@ -78,8 +78,16 @@ class DetectPipeline(object):
     Needs one hardware queue per stream: GPU_MAX_HW_QUEUES >= slots + 3, read by the HIP runtime when it initialises (the package
     sets 8 at import; an application that touches the GPU before importing it exports the variable itself)."""
 
-    def __init__(self, net, slots=2, top_k=400, buffers_per_slot=2):
+    def __init__(self, net, slots=2, top_k=400, buffers_per_slot=2, max_queued=8):
         assert slots >= 1 and buffers_per_slot >= 1
+        # max_queued: submit() blocks the HOST while that many submitted batches have not finished on the GPU (0 = never).  Nothing
+        # makes a host that enqueues faster than the GPU executes stop by itself: it piles up thousands of launches and events, and the
+        # runtime then stalls it in bursts - round 6, batch 32, two slots: the driver's 20 timed steps 8 440 / 8 476 images/s unbounded,
+        # 8 566 / 8 588 / 8 564 with 4 / 8 / 16 batches queued at most, 8 432 with 32; over 4 s the 100-step windows spread 7 632 ... 8 801
+        # unbounded and 8 531 ... 8 737 with 8 (tools/experiments/r06_calls/r06_ahead.sh).  Eight batches are 30 ms of work: the GPU never
+        # runs dry, the host is never more than that ahead.
+        self.max_queued = int(max_queued)
+        self._queued = []
         if slots > 1:
             _check_hw_queues(slots + 3)               # + consumer + RCCL + the default stream
         self.net, self.top_k, self.buffers_per_slot = net, top_k, buffers_per_slot
@@ -95,6 +103,8 @@ class DetectPipeline(object):
         self._next = 0
 
     def submit(self, images, **detect_args):
+        if self.max_queued > 0 and len(self._queued) >= self.max_queued:
+            self._queued.pop(0).synchronize()         # host flow control: the oldest of the queued batches has finished
         b = self._next                                # output set; slot = b % slots
         self._next = (b + 1) % len(self.buffers)
         i = b % len(self.slots)
@@ -118,6 +128,8 @@ class DetectPipeline(object):
             done.record(s)
         t = Ticket(out, done)
         self._tickets[b] = t
+        if self.max_queued > 0:
+            self._queued.append(done)
         return t
 
     def synchronize(self):

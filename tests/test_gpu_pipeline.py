@@ -148,3 +148,40 @@ def test_load_from_tf_checkpoint(tmp_path):
     _same(ref, got)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize('max_queued', [0, 1, 3])
+def test_host_flow_control_bounds_the_queue_and_changes_nothing(max_queued):
+    """DetectPipeline.max_queued (round 6): submit() makes the HOST wait while that many submitted batches have not finished.  Same
+    detections as the unbounded pipeline; never more than max_queued completion events outstanding; with a bound of 1 every batch but
+    the newest has finished on the GPU when submit() returns."""
+    from ron_tensorflow_amd import weights as W
+    from ron_tensorflow_amd.pipeline import DetectPipeline
+    net = _net()
+    batches = [torch.from_numpy(W.synthetic_images(4, seed=40 + i)).cuda() for i in range(6)]
+    refs = []
+    for b in batches:
+        d = net.detect(b)
+        refs.append({k: getattr(d, k).clone() for k in ('count', 'classes', 'scores', 'bboxes', 'anchor_index')})
+    torch.cuda.synchronize()
+    pipe = DetectPipeline(net, slots=2, max_queued=max_queued)
+    pending, done_events = [], []
+    for i, b in enumerate(batches):
+        t = pipe.submit(b)
+        done_events.append(t._done)
+        assert len(pipe._queued) <= max(max_queued, 0) or max_queued == 0
+        if max_queued == 1 and i >= 1:
+            assert all(e.query() for e in done_events[:-1])          # everything but the batch just submitted has finished
+        pending.append((i, t))
+        if len(pending) == 2:
+            j, tj = pending.pop(0)
+            d = tj.wait()
+            for k, v in refs[j].items():
+                assert torch.equal(getattr(d, k), v), (j, k)
+    for j, tj in pending:
+        d = tj.wait()
+        for k, v in refs[j].items():
+            assert torch.equal(getattr(d, k), v), (j, k)
+    torch.cuda.synchronize()
+    pipe.close()
+    net.close()
