@@ -87,6 +87,7 @@ class DetectPipeline(object):
         # unbounded and 8 531 ... 8 737 with 8 (tools/experiments/r06_calls/r06_ahead.sh).  Eight batches are 30 ms of work: the GPU never
         # runs dry, the host is never more than that ahead.
         self.max_queued = int(max_queued)
+        self._slack = 4 if self.max_queued >= 4 else 1
         self._queued = []
         if slots > 1:
             _check_hw_queues(slots + 3)               # + consumer + RCCL + the default stream
@@ -103,8 +104,11 @@ class DetectPipeline(object):
         self._next = 0
 
     def submit(self, images, **detect_args):
-        if self.max_queued > 0 and len(self._queued) >= self.max_queued:
-            self._queued.pop(0).synchronize()         # host flow control: the oldest of the queued batches has finished
+        if self.max_queued > 0 and len(self._queued) >= self.max_queued + self._slack - 1:
+            # host flow control: wait until fewer than max_queued batches are unfinished (one wait per `_slack` submissions, so that
+            # small batches - 0.7 ms steps - do not pay a host wake-up per step; in between up to max_queued + _slack - 1 are queued)
+            del self._queued[:self._slack - 1]
+            self._queued.pop(0).synchronize()
         b = self._next                                # output set; slot = b % slots
         self._next = (b + 1) % len(self.buffers)
         i = b % len(self.slots)
