@@ -6,7 +6,8 @@ The resize is TensorFlow 1.x's kernel, which is not in /root/reference (TF is a 
 algorithm is restated here -- source coordinate ``out_index * (in_size / out_size)`` in float32, lower = floor,
 upper = min(lower + 1, size - 1), ``top = tl + (tr - tl) * xl; bottom = bl + (br - bl) * xl; top + (bottom - top) * yl``.
 **Parity unpinned** (no TF here to generate vectors); anchored on identities: size-preserving resize is exact,
-integer down-scales sample source pixels exactly, constant images stay constant.
+integer down-scales sample source pixels exactly, constant images stay constant; the interpolation arithmetic is cross-checked against
+an independent bilinear engine (torch grid_sample fed with these sampling positions, tests/test_oracle_preprocess.py).
 """
 import numpy as np
 

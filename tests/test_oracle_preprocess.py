@@ -51,3 +51,26 @@ def test_crop_or_pad_and_modes():
     assert np.array_equal(out[110:210, 100:220], small.astype(np.float32) - np.array(op.MEANS, np.float32))
     out, _, rect = op.preprocess_for_eval_mode(small, [], (320, 320), 'NONE')
     assert out.shape == (100, 120, 3) and rect.tolist() == [0., 0., 1., 1.]
+
+
+def test_resize_matches_an_independent_bilinear_sampler():
+    """The restated TF1 resize against torch's grid_sample (an independent bilinear engine) fed with TF1's sampling positions: source
+    coordinate = out_index * (in_size / out_size), no half-pixel offset, indices clamped at the last pixel (align_corners=False of
+    TensorFlow 1.x, tf_image.py:269-282 -> tf.image.resize_images).  Pins the interpolation arithmetic of oracle/preprocess.py; the
+    coordinate convention itself stays what the module header says it is: TensorFlow's published one, restated."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import preprocess as op
+    rs = np.random.RandomState(3)
+    for (h, w), (oh, ow) in (((375, 500), (320, 320)), ((333, 500), (320, 320)), ((97, 61), (320, 320)), ((512, 640), (512, 512)), ((40, 40), (7, 9))):
+        img = rs.uniform(-130, 130, (h, w, 3)).astype(np.float32)
+        ref = op.resize_bilinear(img, (oh, ow))
+        sy = np.arange(oh, dtype=np.float32) * (np.float32(h) / np.float32(oh))
+        sx = np.arange(ow, dtype=np.float32) * (np.float32(w) / np.float32(ow))
+        gy = 2.0 * sy.astype(np.float64) / max(h - 1, 1) - 1.0           # grid_sample, align_corners=True: -1 -> pixel 0, +1 -> pixel size - 1
+        gx = 2.0 * sx.astype(np.float64) / max(w - 1, 1) - 1.0
+        grid = np.stack(np.meshgrid(gx, gy), -1)[None]                     # [1, oh, ow, (x, y)]
+        t = torch.from_numpy(img.transpose(2, 0, 1)[None].astype(np.float64))
+        got = F.grid_sample(t, torch.from_numpy(grid), mode='bilinear', padding_mode='border', align_corners=True)[0].numpy().transpose(1, 2, 0)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-4, ((h, w), (oh, ow), np.abs(got - ref).max())
