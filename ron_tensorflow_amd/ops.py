@@ -205,6 +205,9 @@ def bboxes_filter_min(scores, bboxes, top_k, minsize=0.03):
     bboxes = bboxes.to(torch.float32).contiguous()
     assert scores.dim() == 2 and bboxes.shape == scores.shape + (4,), 'scores [B, N], bboxes [B, N, 4]'
     b, n = scores.shape
+    if n == 0:                                  # nothing to filter: top_k rows of padding (pad_axis)
+        return (torch.zeros((b, int(top_k)), dtype=torch.float32, device=scores.device),
+                torch.zeros((b, int(top_k), 4), dtype=torch.float32, device=scores.device))
     rows = max(n, int(top_k))
     out_s = torch.empty((b, rows), dtype=torch.float32, device=scores.device)
     out_b = torch.empty((b, rows, 4), dtype=torch.float32, device=scores.device)

@@ -47,6 +47,14 @@ def test_bboxes_filter_min_matches_oracle(dev, n, top_k, minsize):
     assert np.array_equal(os_[1].cpu().numpy(), rs_) and np.array_equal(os_[7].cpu().numpy(), r7[0]) and np.array_equal(ob[7].cpu().numpy(), r7[1])
 
 
+def test_bboxes_filter_min_of_an_empty_list(dev):
+    from ron_tensorflow_amd import ops
+    gs, gb = ops.bboxes_filter_min(torch.zeros((1, 0), device=dev), torch.zeros((1, 0, 4), device=dev), 7)
+    assert tuple(gs.shape) == (1, 7) and tuple(gb.shape) == (1, 7, 4) and not gs.any() and not gb.any()
+    rs, rb = tfe_post.bboxes_filter_min(np.zeros((1, 0), np.float32), np.zeros((1, 0, 4), np.float32), 7)
+    assert rs.shape == (1, 7) and rb.shape == (1, 7, 4)
+
+
 def test_bboxes_filter_min_batched_lists(dev):
     """More than one list per call (the reference squeezes axis 0, i.e. takes one): every list is filtered on its own and the result is
     as long as the longest one needs."""

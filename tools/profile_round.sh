@@ -17,13 +17,13 @@ python3 bench.py --dtype fp32 --steps 10 --warmup 3 --layers $O/layers_cfg2_fp32
 python3 bench.py --no-cpu-baseline --no-parity-mode --variant reducedfc --dtype fp16 --batch 64 --layers $O/layers_cfg4.txt > $O/bench_cfg4.json 2>> $O/err.txt
 python3 bench.py --no-cpu-baseline --no-parity-mode --variant ssd512 --batch 16 --layers $O/layers_cfg5.txt > $O/bench_cfg5.json 2>> $O/err.txt
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --no-cpu-baseline --no-parity-mode --check-gather > $O/bench_cfg2_torchrun_1rank.json 2>> $O/err.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if2 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 > $O/bench_cfg2_under_rocprof_inflight2.json 2>> $O/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if2 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 > $O/bench_cfg2_under_rocprof_inflight2.json 2>> $O/err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_if1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --sustained-seconds 0 --in-flight 1 > $O/bench_cfg2_under_rocprof_inflight1.json 2>> $O/err.txt
 for d in if1 if2; do f=$(ls $O/prof_$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$d.csv; done
 # the kernel-level account of the DEFAULT mode (two batches in flight): wall, GPU busy, kernels resident, per launch the time it had the
 # GPU to itself (tools/trace_overlap.py), from the trace of the same command
 T=$(ls $O/prof_if2/*/*kernel_trace.csv 2>/dev/null | head -1)
-[ -n "$T" ] && python3 tools/trace_overlap.py $T --layers $O/layers_cfg2_inflight2.txt --skip-steps 3 --json $O/trace_overlap_if2.json > $O/trace_overlap_if2.txt 2>&1
+[ -n "$T" ] && python3 tools/trace_overlap.py $T --layers $O/layers_cfg2_inflight2.txt --skip-steps 4 --json $O/trace_overlap_if2.json > $O/trace_overlap_if2.txt 2>&1
 # the clock the K loop holds inside the network, after a burst and after seconds of load: s_memtime / s_memrealtime stamps of the
 # diagnostic library (tools/build_stamps_variant.sh builds it; the shipped kernels execute no stamp)
 if [ -f tools/experiments/libron_hip_stamps.so ]; then
