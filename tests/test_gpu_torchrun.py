@@ -28,3 +28,9 @@ def test_single_rank_torchrun_gathers_its_own_records(torchrun_child):
     assert abs(out['per_rank_images_per_s']['max'] - out['value']) / out['value'] < 1e-6       # one rank: its rate is the job's
     assert 0 < out['gather_ms'] < 50
     assert out['weights']['how'].startswith('made') and out['weights']['synthesis_s'] > 0
+    # round 6: the sustained leg ran behind the timed region, with the gather in its loop (>= 3 s in windows of 100 steps)
+    su = out['sustained']
+    assert su['seconds'] >= 2.5 and su['steps'] % su['window_steps'] == 0 and su['steps'] >= 4 * su['window_steps']
+    assert len(su['window_images_per_s']['all']) == su['steps'] // su['window_steps'] - 1
+    assert 0.5 < su['burst_over_sustained'] < 2.0 and su['images_per_s'] > 0
+
